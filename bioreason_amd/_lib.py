@@ -1,0 +1,128 @@
+"""ctypes binding of the C-ABI kernel library (include/bioreason_hip.h).
+
+The prototypes are read from the header itself, so the header stays the single
+statement of the boundary.  The product path opens ``libbioreason_hip.so`` (built
+by ``__graft_entry__.build()`` / ``make -C bioreason_amd/csrc``) and raises if it
+is missing — there is no CPU or PyTorch fallback.  ``use_library_for_tests`` lets
+the CPU test-suite point the same Python host code at the kernel-source emulator
+in ``tests/emu`` (test infrastructure; never used by bench.py / smoke / the
+package itself).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_HEADER = os.path.join(os.path.dirname(_HERE), "include", "bioreason_hip.h")
+_LIB_PATH = os.path.join(_HERE, "libbioreason_hip.so")
+
+_CTYPES = {
+    "int": ctypes.c_int,
+    "unsigned": ctypes.c_uint,
+    "long": ctypes.c_long,
+    "float": ctypes.c_float,
+}
+
+
+def parse_header(path: str = _HEADER) -> Dict[str, List[Tuple[str, str]]]:
+    """-> {function name: [(ctype kind, arg name), ...]} for every `int bra_*(...)` prototype."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos: Dict[str, List[Tuple[str, str]]] = {}
+    for m in re.finditer(r"\bint\s+(bra_\w+)\s*\(([^)]*)\)\s*;", src):
+        name, args = m.group(1), m.group(2).strip()
+        out: List[Tuple[str, str]] = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    out.append(("ptr", a.split("*")[-1].strip()))
+                else:
+                    toks = a.split()
+                    kind = toks[-2] if toks[-2] != "const" else toks[-3]
+                    out.append((kind, toks[-1]))
+        protos[name] = out
+    return protos
+
+
+class KernelLibrary:
+    def __init__(self, path: str, emulated: bool = False):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"bioreason_amd: kernel library {path} is missing. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU / PyTorch fallback for the hot path."
+            )
+        self.path = path
+        self.emulated = emulated
+        self._dll = ctypes.CDLL(path)
+        self.protos = parse_header()
+        self._fn = {}
+        for name, args in self.protos.items():
+            try:
+                f = getattr(self._dll, name)
+            except AttributeError as e:  # header and library out of sync
+                raise RuntimeError(f"{path} does not export {name} declared in {_HEADER}") from e
+            f.restype = ctypes.c_int
+            f.argtypes = [ctypes.c_void_p if k == "ptr" else _CTYPES[k] for k, _ in args]
+            self._fn[name] = f
+
+    def call(self, name: str, *args) -> int:
+        f = self._fn[name]
+        proto = self.protos[name]
+        if len(args) != len(proto):
+            raise TypeError(f"{name}: expected {len(proto)} arguments, got {len(args)}")
+        conv = []
+        for (kind, aname), a in zip(proto, args):
+            if kind == "ptr":
+                if a is None:
+                    conv.append(None)
+                elif isinstance(a, torch.Tensor):
+                    if not self.emulated and not a.is_cuda:
+                        raise RuntimeError(f"{name}: argument {aname} is a CPU tensor; the HIP library needs device memory")
+                    conv.append(a.data_ptr())
+                else:
+                    conv.append(int(a))
+            elif kind == "float":
+                conv.append(float(a))
+            else:
+                conv.append(int(a))
+        rc = f(*conv)
+        if rc != 0:
+            raise RuntimeError(f"{name} failed with status {rc}" + (" (argument error)" if rc < 0 else " (hipError_t)"))
+        return rc
+
+
+_lib: Optional[KernelLibrary] = None
+
+
+def get_lib() -> KernelLibrary:
+    global _lib
+    if _lib is None:
+        _lib = KernelLibrary(_LIB_PATH, emulated=False)
+    return _lib
+
+
+def use_library_for_tests(path: str) -> KernelLibrary:
+    """TEST HOOK: run the host code against the kernel-source emulator (tests/emu)."""
+    global _lib
+    _lib = KernelLibrary(path, emulated=True)
+    return _lib
+
+
+def reset_library() -> None:
+    global _lib
+    _lib = None
+
+
+def current_stream(t: Optional[torch.Tensor] = None) -> int:
+    if t is not None and t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    if torch.cuda.is_available() and (_lib is None or not _lib.emulated):
+        return torch.cuda.current_stream().cuda_stream
+    return 0

@@ -1,0 +1,240 @@
+// bra_device.h — device-side helpers shared by every kernel in this library.
+// gfx950 (CDNA4) only: wave64, MFMA bf16 16x16x32 / 32x32x16, 160 KiB LDS.
+// (With -DBRA_EMU the same sources are compiled for the host test executor in
+// tests/emu/; that build is test infrastructure and never ships.)
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef BRA_EMU
+#include "bra_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+namespace bra {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+
+constexpr int kWave = 64;
+
+// ---- bf16 <-> f32 -----------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    // round-to-nearest-even, NaN kept quiet (same rounding torch uses)
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+// round an f32 to the nearest bf16 and back (the reference rounds module outputs to bf16)
+__device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
+
+// 8 bf16 <-> 8 floats
+__device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+    f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+    f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+    v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]);
+    v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
+    return v;
+}
+
+// ---- wave64 primitives ------------------------------------------------
+#ifdef BRA_EMU
+__device__ __forceinline__ int lane_id() { return bra_emu::lane_id(); }
+__device__ __forceinline__ uint32_t wave_shfl_u32(uint32_t v, int src) {
+    const uint32_t* b = bra_emu::wave_exchange(&v, 1);
+    return b[(src & 63) * 16];
+}
+__device__ __forceinline__ uint32_t wave_shfl_xor_u32(uint32_t v, int m) {
+    return wave_shfl_u32(v, bra_emu::lane_id() ^ m);
+}
+__device__ __forceinline__ uint64_t wave_ballot(bool p) {
+    uint32_t v = p ? 1u : 0u;
+    const uint32_t* b = bra_emu::wave_exchange(&v, 1);
+    uint64_t m = 0;
+    for (int l = 0; l < 64; ++l) if (b[l * 16]) m |= (1ull << l);
+    return m;
+}
+#else
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ uint32_t wave_shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+__device__ __forceinline__ uint32_t wave_shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p); }
+#endif
+__device__ __forceinline__ float wave_shfl_xor(float v, int m) {
+    return __builtin_bit_cast(float, wave_shfl_xor_u32(__builtin_bit_cast(uint32_t, v), m));
+}
+__device__ __forceinline__ float wave_shfl(float v, int src) {
+    return __builtin_bit_cast(float, wave_shfl_u32(__builtin_bit_cast(uint32_t, v), src));
+}
+__device__ __forceinline__ int wave_shfl_i(int v, int src) { return (int)wave_shfl_u32((uint32_t)v, src); }
+__device__ __forceinline__ int wave_shfl_xor_i(int v, int m) { return (int)wave_shfl_xor_u32((uint32_t)v, m); }
+
+// butterfly reductions over `width` consecutive lanes (width = 64, 32, 16, ...)
+template <int WIDTH = 64>
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = WIDTH / 2; m >= 1; m >>= 1) v += wave_shfl_xor(v, m);
+    return v;
+}
+template <int WIDTH = 64>
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = WIDTH / 2; m >= 1; m >>= 1) v = fmaxf(v, wave_shfl_xor(v, m));
+    return v;
+}
+
+// block-wide sum for blocks of NWAVES waves (every thread must call)
+template <int NWAVES>
+__device__ __forceinline__ float block_sum(float v, float* red /* [NWAVES] shared */) {
+    v = wave_sum<64>(v);
+    if (NWAVES == 1) return v;
+    int w = (int)(threadIdx.x >> 6);
+    __syncthreads();
+    if (lane_id() == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWAVES; ++i) t += red[i];
+    return t;
+}
+template <int NWAVES>
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max<64>(v);
+    if (NWAVES == 1) return v;
+    int w = (int)(threadIdx.x >> 6);
+    __syncthreads();
+    if (lane_id() == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < NWAVES; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// ---- MFMA -------------------------------------------------------------
+// v_mfma_f32_16x16x32_bf16:  D[16x16] = A[16x32] * B[32x16] + C
+//   A operand: lane l holds A[l&15][8*(l>>4) + j], j = 0..7   (4 VGPRs)
+//   B operand: lane l holds B[8*(l>>4) + j][l&15]
+//   C/D      : lane l, reg r holds D[4*(l>>4) + r][l&15]
+// v_mfma_f32_32x32x16_bf16:  D[32x32] = A[32x16] * B[16x32] + C
+//   A: lane l holds A[l&31][8*(l>>5) + j];  B: lane l holds B[8*(l>>5) + j][l&31]
+//   C/D: lane l, reg r holds D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]
+#ifdef BRA_EMU
+__device__ inline f32x4 mfma_16x16x32(const u32x4& a, const u32x4& b, f32x4 c) {
+    uint32_t mine[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const uint32_t* x = bra_emu::wave_exchange(mine, 8);
+    int l = bra_emu::lane_id();
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            const uint32_t* la = x + (size_t)(row + 16 * (k >> 3)) * 16;
+            const uint32_t* lb = x + (size_t)(col + 16 * (k >> 3)) * 16 + 4;
+            int j = k & 7;
+            uint32_t wa = la[j >> 1], wb = lb[j >> 1];
+            float fa = (j & 1) ? bf_hi(wa) : bf_lo(wa);
+            float fb = (j & 1) ? bf_hi(wb) : bf_lo(wb);
+            acc += fa * fb;
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+__device__ inline f32x16 mfma_32x32x16(const u32x4& a, const u32x4& b, f32x16 c) {
+    uint32_t mine[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const uint32_t* x = bra_emu::wave_exchange(mine, 8);
+    int l = bra_emu::lane_id();
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t* la = x + (size_t)(row + 32 * (k >> 3)) * 16;
+            const uint32_t* lb = x + (size_t)(col + 32 * (k >> 3)) * 16 + 4;
+            int j = k & 7;
+            uint32_t wa = la[j >> 1], wb = lb[j >> 1];
+            float fa = (j & 1) ? bf_hi(wa) : bf_lo(wa);
+            float fb = (j & 1) ? bf_hi(wb) : bf_lo(wb);
+            acc += fa * fb;
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+#else
+__device__ __forceinline__ f32x4 mfma_16x16x32(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b),
+                                                   c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_32x32x16(const u32x4& a, const u32x4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b),
+                                                   c, 0, 0, 0);
+}
+#endif
+
+// ---- misc ---------------------------------------------------------------
+#ifdef BRA_EMU
+#define BRA_DYN_SMEM(name) char* name = bra_emu::dyn_smem()
+__device__ __forceinline__ void sched_fence() {}
+__device__ __forceinline__ void setprio(int) {}
+#else
+#define BRA_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+#define setprio(p) __builtin_amdgcn_s_setprio(p)
+#endif
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+__device__ __forceinline__ u32x2 ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
+__device__ __forceinline__ void st8(void* p, const u32x2& v) { *reinterpret_cast<u32x2*>(p) = v; }
+
+// XCD-aware bijective remap of a linear workgroup id (8 XCDs; block b runs on
+// XCD b % 8): consecutive remapped ids share an XCD and therefore an L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned nx = 8;
+    unsigned xcd = bid % nx, q = nwg / nx, r = nwg % nx;
+    unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + bid / nx;
+}
+
+}  // namespace bra
+
+// ---- host side: launch + error plumbing ----------------------------------
+#ifdef BRA_EMU
+typedef void* bra_stream_t;
+#define BRA_LAUNCH(kern, grid, block, smem, stream, ...) \
+    bra_emu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+#define BRA_LAUNCH_STATUS() 0
+#define BRA_ALLOW_SMEM(kern, bytes) ((void)0)
+#else
+typedef hipStream_t bra_stream_t;
+#define BRA_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+#define BRA_LAUNCH_STATUS() ((int)hipGetLastError())
+// dynamic LDS above 64 KiB must be opted into once per kernel (gfx950 has 160 KiB per CU)
+#define BRA_ALLOW_SMEM(kern, bytes)                                                                       \
+    do {                                                                                                  \
+        static bool done_ = false;                                                                        \
+        if (!done_ && (bytes) > 65536) {                                                                  \
+            (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                      (int)(bytes));                                                      \
+            done_ = true;                                                                                 \
+        }                                                                                                 \
+    } while (0)
+#endif

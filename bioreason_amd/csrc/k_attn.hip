@@ -1,0 +1,782 @@
+// k_attn.hip — flash-style attention for gfx950, forward and backward.
+//   * bidirectional with key-padding mask, hd = 64      (NT-v2 encoder, TF:esm:292-317)
+//   * causal GQA with key-padding mask, hd = 128        (Qwen3, TF:qwen3:185-207; fp32 softmax :202)
+// Layout of the computation (v_mfma_f32_32x32x16_bf16, wave64):
+//   S^T[key][q] = K[key][:] . Q[q][:]          -> every lane owns ONE query (lane & 31) and 16 keys
+//                                                 per 32-key block; its partner lane ^ 32 owns the
+//                                                 other 16, so row max / row sum are in-lane
+//                                                 reductions plus one exchange with lane ^ 32.
+//   O^T[d][q]   = V^T[d][key] . P^T[key][q]    -> the softmax registers ARE the MFMA B operand
+//                                                 (keys on k-slots, query on lanes): no cross-lane
+//                                                 movement between the two GEMMs; the running
+//                                                 max / sum / rescale are per-lane scalars.
+// Every contraction is "K-contiguous on both operands", so the producer kernels hand over
+// V^T (forward), K^T (dQ) and Q^T / dO^T (dK,dV) as [B, H, hd, S_pad] images (transpose kernels in
+// k_misc.hip); no transposing LDS reads are needed.
+// K / V^T tiles are staged through LDS (register-prefetched, double-buffered, one barrier per
+// 64-key tile) with a 16-byte-chunk XOR swizzle that makes the ds_read_b128 fragment reads
+// conflict-free.
+#include "bra_device.h"
+#include "bra_api_internal.h"
+
+namespace bra {
+
+constexpr float kNeg = -1.0e30f;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+struct AttnArgs {
+    const bf16_t* q;  long q_sb, q_ss, q_sh;     // [B, Sq, Hq, hd] via strides
+    const bf16_t* k;  long k_sb, k_ss, k_sh;     // [B, Sk, Hkv, hd] via strides
+    const bf16_t* v;  long v_sb, v_ss, v_sh;     // (backward only)
+    const bf16_t* vt; long vt_sb, vt_sh, vt_sd;  // V^T [B, Hkv, hd, pitch]
+    const bf16_t* kt; long kt_sb, kt_sh, kt_sd;  // K^T (dQ kernel)
+    const bf16_t* qt; long qt_sb, qt_sh, qt_sd;  // Q^T [B, Hq, hd, pitch] (dKV kernel)
+    const bf16_t* dot; long dot_sb, dot_sh, dot_sd;  // dO^T [B, Hq, hd, pitch] (dKV kernel)
+    const bf16_t* dout; long do_sb, do_ss, do_sh;    // dO
+    bf16_t* o;        long o_sb, o_ss, o_sh;
+    bf16_t* dq;       long dq_sb, dq_ss, dq_sh;
+    bf16_t* dk;       long dk_sb, dk_ss, dk_sh;
+    bf16_t* dv;       long dv_sb, dv_ss, dv_sh;
+    float* lse;                                  // [B, Hq, Sq] natural-log LSE of the scaled scores
+    const float* delta;                          // [B, Hq, Sq] rowsum(dO * O)
+    const uint8_t* kmask;                        // [B, Sk] 1 = key may be attended, or null
+    int B, Hq, Hkv, Sq, Sk;
+    int causal, q_off;                           // causal: key j visible to query i iff j <= i + q_off
+    float scale;
+};
+
+template <int HD>
+struct Tile {
+    static constexpr int CH = HD / 8;            // 16-byte chunks per K row
+    static constexpr int RPB = 16 / CH > 0 ? 16 / CH : 1;
+    static constexpr int DB = HD / 32;           // 32-wide d blocks
+    static constexpr int DS = HD / 16;           // 16-deep contraction steps over d
+    static constexpr int KBYTES = 64 * HD * 2;   // [64 rows][HD]   (row = key or query)
+    static constexpr int TBYTES = HD * 64 * 2;   // [HD rows][64]   (transposed image)
+    __device__ static __forceinline__ int koff(int row, int chunk) {   // byte offset in a [64][HD] tile
+        return row * (HD * 2) + ((chunk ^ ((row / RPB) & (CH - 1))) << 4);
+    }
+    __device__ static __forceinline__ int toff(int d, int chunk) {     // byte offset in a [HD][64] tile
+        return d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4);
+    }
+};
+
+// load a [64][HD] row-major tile (rows r0.., clamped to nrows-1) into registers / LDS
+template <int HD, int NT>
+__device__ __forceinline__ void load_rows(u32x4 (&r)[(64 * (HD / 8)) / NT], const bf16_t* base, long row_stride,
+                                          int r0, int nrows, int tid) {
+    constexpr int CH = HD / 8;
+#pragma unroll
+    for (int i = 0; i < (64 * CH) / NT; ++i) {
+        int q = tid + NT * i;
+        int row = q / CH, c = q % CH;
+        int rr = r0 + row;
+        rr = rr < nrows ? rr : nrows - 1;
+        r[i] = ld16(base + (long)rr * row_stride + c * 8);
+    }
+}
+template <int HD, int NT>
+__device__ __forceinline__ void store_rows(char* lds, const u32x4 (&r)[(64 * (HD / 8)) / NT], int tid) {
+    constexpr int CH = HD / 8;
+#pragma unroll
+    for (int i = 0; i < (64 * CH) / NT; ++i) {
+        int q = tid + NT * i;
+        st16(lds + Tile<HD>::koff(q / CH, q % CH), r[i]);
+    }
+}
+// load a [HD][64] tile of a transposed image (rows = d, 64 consecutive sequence positions from s0)
+template <int HD, int NT>
+__device__ __forceinline__ void load_trans(u32x4 (&r)[(HD * 8) / NT], const bf16_t* base, long d_stride, int s0,
+                                           int tid) {
+#pragma unroll
+    for (int i = 0; i < (HD * 8) / NT; ++i) {
+        int q = tid + NT * i;
+        int d = q >> 3, c = q & 7;
+        r[i] = ld16(base + (long)d * d_stride + s0 + c * 8);
+    }
+}
+template <int HD, int NT>
+__device__ __forceinline__ void store_trans(char* lds, const u32x4 (&r)[(HD * 8) / NT], int tid) {
+#pragma unroll
+    for (int i = 0; i < (HD * 8) / NT; ++i) {
+        int q = tid + NT * i;
+        st16(lds + Tile<HD>::toff(q >> 3, q & 7), r[i]);
+    }
+}
+
+// fragment readers -----------------------------------------------------------
+// operand with rows on lanes (row = rbase + (lane & 31)) and 8 contiguous d at 16*ds + 8*(lane >> 5)
+template <int HD>
+__device__ __forceinline__ u32x4 frag_rows(const char* lds, int rbase, int ds, int lane) {
+    return ld16(lds + Tile<HD>::koff(rbase + (lane & 31), ds * 2 + (lane >> 5)));
+}
+// operand from a transposed tile: row d = dbase + (lane & 31); sequence positions matching the
+// register order of a 32x32 C/D fragment: {16s + 4h + 0..3, 16s + 4h + 8 + 0..3}, h = lane >> 5
+template <int HD>
+__device__ __forceinline__ u32x4 frag_trans(const char* lds, int dbase, int s, int lane) {
+    const int d = dbase + (lane & 31), h = lane >> 5;
+    u32x2 p0 = ld8(lds + Tile<HD>::toff(d, 2 * s) + 8 * h);
+    u32x2 p1 = ld8(lds + Tile<HD>::toff(d, 2 * s + 1) + 8 * h);
+    u32x4 o; o.x = p0.x; o.y = p0.y; o.z = p1.x; o.w = p1.y;
+    return o;
+}
+// sequence index (within a 32-block) held in register r of a 32x32 C/D fragment
+__device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ uint64_t key_valid_word(const AttnArgs& a, int b, int kv0, int lane) {
+    int kj = kv0 + lane;
+    bool ok = kj < a.Sk;
+    if (ok && a.kmask) ok = a.kmask[(long)b * a.Sk + kj] != 0;
+    return wave_ballot(ok);
+}
+
+// ---------------------------------------------------------------------------
+// forward
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    using T = Tile<HD>;
+    BRA_DYN_SMEM(smem);   // [2][K tile | V^T tile]
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int b = (int)blockIdx.z, hq = (int)blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
+    const int q0 = (int)blockIdx.x * 128;
+    const int qw0 = q0 + wave * 32;
+    const int qi = qw0 + (lane & 31);                 // this lane's query
+    const bf16_t* kb_ = a.k + b * a.k_sb + hkv * a.k_sh;
+    const bf16_t* vtb = a.vt + b * a.vt_sb + hkv * a.vt_sh;
+
+    // Q fragments (B operand of S^T): row = query, 8 d per lane per step
+    u32x4 qf[T::DS];
+    {
+        int qr = qi < a.Sq ? qi : a.Sq - 1;
+        const bf16_t* qp = a.q + b * a.q_sb + (long)qr * a.q_ss + hq * a.q_sh;
+#pragma unroll
+        for (int ds = 0; ds < T::DS; ++ds) qf[ds] = ld16(qp + ds * 16 + 8 * h);
+    }
+    f32x16 o[T::DB];
+#pragma unroll
+    for (int i = 0; i < T::DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = kNeg, l_run = 0.f;
+    const float sc = a.scale * kLog2e;
+
+    int kv_end = a.Sk;
+    if (a.causal) {
+        int last = q0 + 127 + a.q_off + 1;
+        kv_end = last < kv_end ? last : kv_end;
+    }
+    const int ntile = kv_end > 0 ? (kv_end + 63) / 64 : 0;
+
+    u32x4 rk[(64 * T::CH) / 256], rv[(HD * 8) / 256];
+    if (ntile > 0) {
+        load_rows<HD, 256>(rk, kb_, a.k_ss, 0, a.Sk, tid);
+        load_trans<HD, 256>(rv, vtb, a.vt_sd, 0, tid);
+        store_rows<HD, 256>(smem, rk, tid);
+        store_trans<HD, 256>(smem + T::KBYTES, rv, tid);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+        const int kv0 = t * 64;
+        const char* sk = smem + (t & 1) * (T::KBYTES + T::TBYTES);
+        const char* sv = sk + T::KBYTES;
+        const bool more = t + 1 < ntile;
+        if (more) {
+            load_rows<HD, 256>(rk, kb_, a.k_ss, kv0 + 64, a.Sk, tid);
+            load_trans<HD, 256>(rv, vtb, a.vt_sd, kv0 + 64, tid);
+        }
+        const uint64_t valid = key_valid_word(a, b, kv0, lane);
+        // wave-uniform skip: every key of this tile is after every query of this wave
+        const bool skip = a.causal && (kv0 > qw0 + 31 + a.q_off);
+        if (!skip) {
+            f32x16 st[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+                for (int ds = 0; ds < T::DS; ++ds)
+                    st[kb] = mfma_32x32x16(frag_rows<HD>(sk, kb * 32, ds, lane), qf[ds], st[kb]);
+            }
+            // scale + mask, tile max
+            float mx = kNeg;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = kb * 32 + crow(r, h);
+                    bool ok = (valid >> kl) & 1ull;
+                    if (a.causal) ok = ok && (kv0 + kl <= qi + a.q_off);
+                    float s = ok ? st[kb][r] * sc : kNeg;
+                    st[kb][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            mx = fmaxf(mx, wave_shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f(m_run - m_new);
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = st[kb][r] > 0.5f * kNeg ? exp2f(st[kb][r] - m_new) : 0.f;
+                    st[kb][r] = p;
+                    rs += p;
+                }
+            rs += wave_shfl_xor(rs, 32);
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < T::DB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            // O^T += V^T . P^T
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int kb = s >> 1, r0 = 8 * (s & 1);
+                u32x4 pf;
+                pf.x = pack_bf2(st[kb][r0 + 0], st[kb][r0 + 1]);
+                pf.y = pack_bf2(st[kb][r0 + 2], st[kb][r0 + 3]);
+                pf.z = pack_bf2(st[kb][r0 + 4], st[kb][r0 + 5]);
+                pf.w = pack_bf2(st[kb][r0 + 6], st[kb][r0 + 7]);
+#pragma unroll
+                for (int db = 0; db < T::DB; ++db)
+                    o[db] = mfma_32x32x16(frag_trans<HD>(sv, db * 32, s, lane), pf, o[db]);
+            }
+        }
+        if (more) {
+            char* nk = smem + ((t + 1) & 1) * (T::KBYTES + T::TBYTES);
+            store_rows<HD, 256>(nk, rk, tid);
+            store_trans<HD, 256>(nk + T::KBYTES, rv, tid);
+        }
+        __syncthreads();
+    }
+
+    if (qi < a.Sq) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        bf16_t* op = a.o + b * a.o_sb + (long)qi * a.o_ss + hq * a.o_sh;
+#pragma unroll
+        for (int db = 0; db < T::DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w.x = pack_bf2(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
+                w.y = pack_bf2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                st8(op + db * 32 + 8 * g + 4 * h, w);
+            }
+        if (a.lse && h == 0)
+            a.lse[((long)b * a.Hq + hq) * a.Sq + qi] = l_run > 0.f ? (m_run + log2f(l_run)) * kLn2 : kNeg;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward, dQ:   one workgroup = 128 queries of one (batch, q-head); loops over key tiles.
+//   S^T = K Q^T, dP^T = V dO^T (both [key][q], query on lanes), dS^T = P^T * (dP^T - delta[q]) * scale
+//   dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    using T = Tile<HD>;
+    BRA_DYN_SMEM(smem);   // [2][K tile | V tile | K^T tile]
+    constexpr int STAGE = 2 * T::KBYTES + T::TBYTES;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int b = (int)blockIdx.z, hq = (int)blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
+    const int q0 = (int)blockIdx.x * 128;
+    const int qw0 = q0 + wave * 32;
+    const int qi = qw0 + (lane & 31);
+    const int qr = qi < a.Sq ? qi : a.Sq - 1;
+    const bf16_t* kb_ = a.k + b * a.k_sb + hkv * a.k_sh;
+    const bf16_t* vb_ = a.v + b * a.v_sb + hkv * a.v_sh;
+    const bf16_t* ktb = a.kt + b * a.kt_sb + hkv * a.kt_sh;
+
+    u32x4 qf[T::DS], dof[T::DS];
+    {
+        const bf16_t* qp = a.q + b * a.q_sb + (long)qr * a.q_ss + hq * a.q_sh;
+        const bf16_t* dp = a.dout + b * a.do_sb + (long)qr * a.do_ss + hq * a.do_sh;
+#pragma unroll
+        for (int ds = 0; ds < T::DS; ++ds) { qf[ds] = ld16(qp + ds * 16 + 8 * h); dof[ds] = ld16(dp + ds * 16 + 8 * h); }
+    }
+    const long lidx = ((long)b * a.Hq + hq) * a.Sq + qr;
+    const float lse2 = a.lse[lidx] * kLog2e;
+    const float dlt = a.delta[lidx];
+    const float sc = a.scale * kLog2e;
+
+    f32x16 dq[T::DB];
+#pragma unroll
+    for (int i = 0; i < T::DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+    int kv_end = a.Sk;
+    if (a.causal) { int last = q0 + 127 + a.q_off + 1; kv_end = last < kv_end ? last : kv_end; }
+    const int ntile = kv_end > 0 ? (kv_end + 63) / 64 : 0;
+
+    u32x4 rk[(64 * T::CH) / 256], rv[(64 * T::CH) / 256], rt[(HD * 8) / 256];
+    if (ntile > 0) {
+        load_rows<HD, 256>(rk, kb_, a.k_ss, 0, a.Sk, tid);
+        load_rows<HD, 256>(rv, vb_, a.v_ss, 0, a.Sk, tid);
+        load_trans<HD, 256>(rt, ktb, a.kt_sd, 0, tid);
+        store_rows<HD, 256>(smem, rk, tid);
+        store_rows<HD, 256>(smem + T::KBYTES, rv, tid);
+        store_trans<HD, 256>(smem + 2 * T::KBYTES, rt, tid);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+        const int kv0 = t * 64;
+        const char* sk = smem + (t & 1) * STAGE;
+        const char* sv = sk + T::KBYTES;
+        const char* skt = sk + 2 * T::KBYTES;
+        const bool more = t + 1 < ntile;
+        if (more) {
+            load_rows<HD, 256>(rk, kb_, a.k_ss, kv0 + 64, a.Sk, tid);
+            load_rows<HD, 256>(rv, vb_, a.v_ss, kv0 + 64, a.Sk, tid);
+            load_trans<HD, 256>(rt, ktb, a.kt_sd, kv0 + 64, tid);
+        }
+        const uint64_t valid = key_valid_word(a, b, kv0, lane);
+        const bool skip = a.causal && (kv0 > qw0 + 31 + a.q_off);
+        if (!skip) {
+            f32x16 st[2], dp[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = 0.f; }
+#pragma unroll
+                for (int ds = 0; ds < T::DS; ++ds) {
+                    st[kb] = mfma_32x32x16(frag_rows<HD>(sk, kb * 32, ds, lane), qf[ds], st[kb]);
+                    dp[kb] = mfma_32x32x16(frag_rows<HD>(sv, kb * 32, ds, lane), dof[ds], dp[kb]);
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = kb * 32 + crow(r, h);
+                    bool ok = (valid >> kl) & 1ull;
+                    if (a.causal) ok = ok && (kv0 + kl <= qi + a.q_off);
+                    const float p = ok ? exp2f(st[kb][r] * sc - lse2) : 0.f;
+                    st[kb][r] = p * (dp[kb][r] - dlt) * a.scale;   // dS^T
+                }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int kb = s >> 1, r0 = 8 * (s & 1);
+                u32x4 sf;
+                sf.x = pack_bf2(st[kb][r0 + 0], st[kb][r0 + 1]);
+                sf.y = pack_bf2(st[kb][r0 + 2], st[kb][r0 + 3]);
+                sf.z = pack_bf2(st[kb][r0 + 4], st[kb][r0 + 5]);
+                sf.w = pack_bf2(st[kb][r0 + 6], st[kb][r0 + 7]);
+#pragma unroll
+                for (int db = 0; db < T::DB; ++db)
+                    dq[db] = mfma_32x32x16(frag_trans<HD>(skt, db * 32, s, lane), sf, dq[db]);
+            }
+        }
+        if (more) {
+            char* nk = smem + ((t + 1) & 1) * STAGE;
+            store_rows<HD, 256>(nk, rk, tid);
+            store_rows<HD, 256>(nk + T::KBYTES, rv, tid);
+            store_trans<HD, 256>(nk + 2 * T::KBYTES, rt, tid);
+        }
+        __syncthreads();
+    }
+    if (qi < a.Sq) {
+        bf16_t* op = a.dq + b * a.dq_sb + (long)qi * a.dq_ss + hq * a.dq_sh;
+#pragma unroll
+        for (int db = 0; db < T::DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w.x = pack_bf2(dq[db][4 * g + 0], dq[db][4 * g + 1]);
+                w.y = pack_bf2(dq[db][4 * g + 2], dq[db][4 * g + 3]);
+                st8(op + db * 32 + 8 * g + 4 * h, w);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward, dK/dV: one workgroup = 128 keys of one (batch, kv-head); loops over the group's
+// q-heads and over query tiles (so GQA's sum over the group needs no atomics).
+//   S[q][key] = Q K^T, dP[q][key] = dO V^T  (key on lanes, query on registers)
+//   dV^T[d][key] += dO^T[d][q] . P[q][key]      dK^T[d][key] += Q^T[d][q] . dS[q][key]
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+    using T = Tile<HD>;
+    BRA_DYN_SMEM(smem);   // [2][Q tile | dO tile | Q^T tile | dO^T tile | lse(64) delta(64)]
+    constexpr int STAGE = 2 * T::KBYTES + 2 * T::TBYTES + 512;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int b = (int)blockIdx.z, hkv = (int)blockIdx.y;
+    const int group = a.Hq / a.Hkv;
+    const int k0 = (int)blockIdx.x * 128;
+    const int kw0 = k0 + wave * 32;
+    const int kj = kw0 + (lane & 31);                 // this lane's key
+    const int kr = kj < a.Sk ? kj : a.Sk - 1;
+    bool kvalid = kj < a.Sk;
+    if (kvalid && a.kmask) kvalid = a.kmask[(long)b * a.Sk + kj] != 0;
+
+    u32x4 kf[T::DS], vf[T::DS];
+    {
+        const bf16_t* kp = a.k + b * a.k_sb + (long)kr * a.k_ss + hkv * a.k_sh;
+        const bf16_t* vp = a.v + b * a.v_sb + (long)kr * a.v_ss + hkv * a.v_sh;
+#pragma unroll
+        for (int ds = 0; ds < T::DS; ++ds) { kf[ds] = ld16(kp + ds * 16 + 8 * h); vf[ds] = ld16(vp + ds * 16 + 8 * h); }
+    }
+    f32x16 dk[T::DB], dv[T::DB];
+#pragma unroll
+    for (int i = 0; i < T::DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+    const float sc = a.scale * kLog2e;
+
+    // first query tile that can see any key of this workgroup
+    int qt_begin = 0;
+    if (a.causal) { int first = k0 - a.q_off; qt_begin = first > 0 ? first / 64 : 0; }
+    const int qt_end = (a.Sq + 63) / 64;
+    const int per_head = qt_end > qt_begin ? qt_end - qt_begin : 0;
+    const int nit = per_head * group;
+
+    u32x4 rq[(64 * T::CH) / 256], rd[(64 * T::CH) / 256], rqt[(HD * 8) / 256], rdt[(HD * 8) / 256];
+    float rl = 0.f;   // threads 0..63: lse, 64..127: delta
+    auto issue = [&](int it) {
+        const int hq = hkv * group + it / per_head;
+        const int s0 = (qt_begin + it % per_head) * 64;
+        load_rows<HD, 256>(rq, a.q + b * a.q_sb + hq * a.q_sh, a.q_ss, s0, a.Sq, tid);
+        load_rows<HD, 256>(rd, a.dout + b * a.do_sb + hq * a.do_sh, a.do_ss, s0, a.Sq, tid);
+        load_trans<HD, 256>(rqt, a.qt + b * a.qt_sb + hq * a.qt_sh, a.qt_sd, s0, tid);
+        load_trans<HD, 256>(rdt, a.dot + b * a.dot_sb + hq * a.dot_sh, a.dot_sd, s0, tid);
+        if (tid < 128) {
+            int qq = s0 + (tid & 63);
+            qq = qq < a.Sq ? qq : a.Sq - 1;
+            const long li = ((long)b * a.Hq + hq) * a.Sq + qq;
+            rl = tid < 64 ? a.lse[li] * kLog2e : a.delta[li];
+        }
+    };
+    auto commit = [&](int buf) {
+        char* s = smem + buf * STAGE;
+        store_rows<HD, 256>(s, rq, tid);
+        store_rows<HD, 256>(s + T::KBYTES, rd, tid);
+        store_trans<HD, 256>(s + 2 * T::KBYTES, rqt, tid);
+        store_trans<HD, 256>(s + 2 * T::KBYTES + T::TBYTES, rdt, tid);
+        if (tid < 128) reinterpret_cast<float*>(s + 2 * T::KBYTES + 2 * T::TBYTES)[tid] = rl;
+    };
+    if (nit > 0) { issue(0); commit(0); }
+    __syncthreads();
+
+    for (int it = 0; it < nit; ++it) {
+        const int s0 = (qt_begin + it % per_head) * 64;
+        const char* sq = smem + (it & 1) * STAGE;
+        const char* sd = sq + T::KBYTES;
+        const char* sqt = sq + 2 * T::KBYTES;
+        const char* sdt = sqt + T::TBYTES;
+        const float* sl = reinterpret_cast<const float*>(sdt + T::TBYTES);
+        const bool more = it + 1 < nit;
+        if (more) issue(it + 1);
+        // wave-uniform skip: every query of this tile is before every key of this wave
+        const bool skip = a.causal && (s0 + 63 + a.q_off < kw0);
+        if (!skip) {
+            f32x16 st[2], dp[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st[qb][r] = 0.f; dp[qb][r] = 0.f; }
+#pragma unroll
+                for (int ds = 0; ds < T::DS; ++ds) {
+                    st[qb] = mfma_32x32x16(frag_rows<HD>(sq, qb * 32, ds, lane), kf[ds], st[qb]);
+                    dp[qb] = mfma_32x32x16(frag_rows<HD>(sd, qb * 32, ds, lane), vf[ds], dp[qb]);
+                }
+            }
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = qb * 32 + crow(r, h);
+                    const int qi = s0 + ql;
+                    bool ok = kvalid && qi < a.Sq;
+                    if (a.causal) ok = ok && (kj <= qi + a.q_off);
+                    const float p = ok ? exp2f(st[qb][r] * sc - sl[ql]) : 0.f;
+                    st[qb][r] = p;                                              // P
+                    dp[qb][r] = p * (dp[qb][r] - sl[64 + ql]) * a.scale;         // dS
+                }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int qb = s >> 1, r0 = 8 * (s & 1);
+                u32x4 pf, sf;
+                pf.x = pack_bf2(st[qb][r0 + 0], st[qb][r0 + 1]); pf.y = pack_bf2(st[qb][r0 + 2], st[qb][r0 + 3]);
+                pf.z = pack_bf2(st[qb][r0 + 4], st[qb][r0 + 5]); pf.w = pack_bf2(st[qb][r0 + 6], st[qb][r0 + 7]);
+                sf.x = pack_bf2(dp[qb][r0 + 0], dp[qb][r0 + 1]); sf.y = pack_bf2(dp[qb][r0 + 2], dp[qb][r0 + 3]);
+                sf.z = pack_bf2(dp[qb][r0 + 4], dp[qb][r0 + 5]); sf.w = pack_bf2(dp[qb][r0 + 6], dp[qb][r0 + 7]);
+#pragma unroll
+                for (int db = 0; db < T::DB; ++db) {
+                    dv[db] = mfma_32x32x16(frag_trans<HD>(sdt, db * 32, s, lane), pf, dv[db]);
+                    dk[db] = mfma_32x32x16(frag_trans<HD>(sqt, db * 32, s, lane), sf, dk[db]);
+                }
+            }
+        }
+        if (more) commit((it + 1) & 1);
+        __syncthreads();
+    }
+    if (kj < a.Sk) {
+        bf16_t* kp = a.dk + b * a.dk_sb + (long)kj * a.dk_ss + hkv * a.dk_sh;
+        bf16_t* vp = a.dv + b * a.dv_sb + (long)kj * a.dv_ss + hkv * a.dv_sh;
+#pragma unroll
+        for (int db = 0; db < T::DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w.x = pack_bf2(dk[db][4 * g + 0], dk[db][4 * g + 1]);
+                w.y = pack_bf2(dk[db][4 * g + 2], dk[db][4 * g + 3]);
+                st8(kp + db * 32 + 8 * g + 4 * h, w);
+                w.x = pack_bf2(dv[db][4 * g + 0], dv[db][4 * g + 1]);
+                w.y = pack_bf2(dv[db][4 * g + 2], dv[db][4 * g + 3]);
+                st8(vp + db * 32 + 8 * g + 4 * h, w);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// single-token decode attention over a KV cache (HF DynamicCache step, TF:generation/utils.py:2876-2925).
+// HBM-bound: one wave per (sequence, kv-head, key chunk); lane-per-key dot products for the scores,
+// lane-per-dimension accumulation for the values; chunk partials (max, sum, O) are merged by a
+// second tiny kernel (split over the context so that B*Hkv waves are not the only parallelism).
+struct DecodeArgs {
+    const bf16_t* q;      // [B, Hq, hd]
+    const bf16_t* kc;     // K cache [B, Hkv, Smax, hd]
+    const bf16_t* vc;     // V cache [B, Hkv, Smax, hd]
+    const uint8_t* kmask; // [B, Smax] validity of cached positions (left padding) or null
+    float* part_o;        // [B, Hq, nchunk, hd]
+    float* part_ml;       // [B, Hq, nchunk, 2]
+    bf16_t* o;            // [B, Hq*hd]
+    int B, Hq, Hkv, hd, Smax, len, chunk, nchunk;
+    float scale;
+};
+
+// partial kernel: a wave owns CK = 128 consecutive cached positions of one (sequence, kv-head).
+// A K/V row (hd bf16) is covered by LPK = hd/8 lanes with one 16-byte load each, so one wave-load
+// touches 64/LPK whole rows; every lane keeps its 8-dim slice of the (pre-scaled) queries of the
+// G q-heads of the group in registers.  Two passes over the chunk (scores -> max -> exp/accumulate)
+// keep everything statically indexed in registers.
+template <int HD, int G>
+__global__ __launch_bounds__(256) void attn_decode_partial_kernel(DecodeArgs a) {
+    constexpr int CK = 128;
+    constexpr int LPK = HD / 8;
+    constexpr int KPI = 64 / LPK;
+    constexpr int NIT = CK / KPI;
+    const int lane = lane_id();
+    const int c = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int hkv = (int)blockIdx.y, b = (int)blockIdx.z;
+    if (c >= a.nchunk) return;
+    const int s_begin = c * CK;
+    int s_end = s_begin + CK;
+    s_end = s_end < a.len ? s_end : a.len;
+    const int kg = lane / LPK, dl = lane % LPK;
+    const bf16_t* kb_ = a.kc + ((long)b * a.Hkv + hkv) * a.Smax * HD + dl * 8;
+    const bf16_t* vb_ = a.vc + ((long)b * a.Hkv + hkv) * a.Smax * HD + dl * 8;
+    const float sc = a.scale * kLog2e;
+    float qv[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        unpack8(ld16(a.q + ((long)b * a.Hq + hkv * G + g) * HD + dl * 8), qv[g]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[g][i] *= sc;
+    }
+    float sco[NIT][G];
+    float m[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) m[g] = kNeg;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int key = s_begin + it * KPI + kg;
+        bool ok = key < s_end;
+        const int kc_ = ok ? key : s_end - 1;
+        if (ok && a.kmask) ok = a.kmask[(long)b * a.Smax + key] != 0;
+        float f[8];
+        unpack8(ld16(kb_ + (long)kc_ * HD), f);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d += f[i] * qv[g][i];
+#pragma unroll
+            for (int mk = LPK >> 1; mk >= 1; mk >>= 1) d += wave_shfl_xor(d, mk);
+            d = ok ? d : kNeg;
+            sco[it][g] = d;
+            m[g] = fmaxf(m[g], d);
+        }
+    }
+    float l[G], acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int mk = 32; mk >= LPK; mk >>= 1) m[g] = fmaxf(m[g], wave_shfl_xor(m[g], mk));
+        l[g] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[g][i] = 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int key = s_begin + it * KPI + kg;
+        const int kc_ = key < s_end ? key : s_end - 1;
+        float f[8];
+        unpack8(ld16(vb_ + (long)kc_ * HD), f);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float p = sco[it][g] > 0.5f * kNeg ? exp2f(sco[it][g] - m[g]) : 0.f;
+            l[g] += p;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[g][i] += p * f[i];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int mk = 32; mk >= LPK; mk >>= 1) {
+            l[g] += wave_shfl_xor(l[g], mk);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[g][i] += wave_shfl_xor(acc[g][i], mk);
+        }
+        const int hq = hkv * G + g;
+        const long base = ((long)b * a.Hq + hq) * a.nchunk + c;
+        if (kg == 0) {
+            f32x4 lo = {acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
+            f32x4 hi = {acc[g][4], acc[g][5], acc[g][6], acc[g][7]};
+            *reinterpret_cast<f32x4*>(a.part_o + base * HD + dl * 8) = lo;
+            *reinterpret_cast<f32x4*>(a.part_o + base * HD + dl * 8 + 4) = hi;
+        }
+        if (lane == 0) { a.part_ml[base * 2] = m[g]; a.part_ml[base * 2 + 1] = l[g]; }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(64) void attn_decode_merge_kernel(DecodeArgs a) {
+    const int lane = lane_id();
+    const int hq = (int)blockIdx.x, b = (int)blockIdx.y;
+    const long base = ((long)b * a.Hq + hq) * a.nchunk;
+    float m = kNeg;
+    for (int c = 0; c < a.nchunk; ++c) m = fmaxf(m, a.part_ml[(base + c) * 2]);
+    float l = 0.f;
+    constexpr int EPL = HD / 64 > 0 ? HD / 64 : 1;
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int c = 0; c < a.nchunk; ++c) {
+        const float w = exp2f(a.part_ml[(base + c) * 2] - m);
+        l += a.part_ml[(base + c) * 2 + 1] * w;
+        if (lane * EPL < HD)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] += a.part_o[(base + c) * HD + lane * EPL + e] * w;
+    }
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    if (lane * EPL < HD)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) a.o[((long)b * a.Hq + hq) * HD + lane * EPL + e] = f2bf(acc[e] * inv);
+}
+
+}  // namespace bra
+
+using namespace bra;
+
+template <int HD>
+static int launch_fwd(const AttnArgs& a, bra_stream_t st) {
+    const size_t smem = 2 * (Tile<HD>::KBYTES + Tile<HD>::TBYTES);
+    BRA_ALLOW_SMEM((attn_fwd_kernel<HD>), smem);
+    BRA_LAUNCH((attn_fwd_kernel<HD>), dim3((a.Sq + 127) / 128, a.Hq, a.B), dim3(256), smem, st, a);
+    return BRA_LAUNCH_STATUS();
+}
+template <int HD>
+static int launch_dq(const AttnArgs& a, bra_stream_t st) {
+    const size_t smem = 2 * (2 * Tile<HD>::KBYTES + Tile<HD>::TBYTES);
+    BRA_ALLOW_SMEM((attn_bwd_dq_kernel<HD>), smem);
+    BRA_LAUNCH((attn_bwd_dq_kernel<HD>), dim3((a.Sq + 127) / 128, a.Hq, a.B), dim3(256), smem, st, a);
+    return BRA_LAUNCH_STATUS();
+}
+template <int HD>
+static int launch_dkv(const AttnArgs& a, bra_stream_t st) {
+    const size_t smem = 2 * (2 * Tile<HD>::KBYTES + 2 * Tile<HD>::TBYTES + 512);
+    BRA_ALLOW_SMEM((attn_bwd_dkv_kernel<HD>), smem);
+    BRA_LAUNCH((attn_bwd_dkv_kernel<HD>), dim3((a.Sk + 127) / 128, a.Hkv, a.B), dim3(256), smem, st, a);
+    return BRA_LAUNCH_STATUS();
+}
+
+static int attn_check(int B, int Hq, int Hkv, int Sq, int Sk, int hd) {
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0 || Hq % Hkv) return BRA_ERR_ARG;
+    if (hd != 32 && hd != 64 && hd != 128) return BRA_ERR_UNSUPPORTED;
+    return 0;
+}
+
+extern "C" int bra_attn_fwd(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss,
+                            long k_sh, const void* vt, long vt_sb, long vt_sh, long vt_sd, void* o, long o_sb,
+                            long o_ss, long o_sh, float* lse, const void* kmask, int B, int Hq, int Hkv, int Sq,
+                            int Sk, int hd, int causal, int q_off, float scale, void* stream) {
+    int e = attn_check(B, Hq, Hkv, Sq, Sk, hd);
+    if (e) return e;
+    if (!q || !k || !vt || !o || vt_sd % 8 || vt_sd < ((Sk + 63) / 64) * 64) return BRA_ERR_ARG;
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.q_sb = q_sb; a.q_ss = q_ss; a.q_sh = q_sh;
+    a.k = (const bf16_t*)k; a.k_sb = k_sb; a.k_ss = k_ss; a.k_sh = k_sh;
+    a.vt = (const bf16_t*)vt; a.vt_sb = vt_sb; a.vt_sh = vt_sh; a.vt_sd = vt_sd;
+    a.o = (bf16_t*)o; a.o_sb = o_sb; a.o_ss = o_ss; a.o_sh = o_sh;
+    a.lse = lse; a.kmask = (const uint8_t*)kmask;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = Sq; a.Sk = Sk; a.causal = causal; a.q_off = q_off; a.scale = scale;
+    bra_stream_t st = (bra_stream_t)stream;
+    if (hd == 128) return launch_fwd<128>(a, st);
+    if (hd == 64) return launch_fwd<64>(a, st);
+    return launch_fwd<32>(a, st);
+}
+
+extern "C" int bra_attn_bwd(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss,
+                            long k_sh, const void* v, long v_sb, long v_ss, long v_sh, const void* dout, long do_sb,
+                            long do_ss, long do_sh, const void* kt, long kt_sb, long kt_sh, long kt_sd,
+                            const void* qt, long qt_sb, long qt_sh, long qt_sd, const void* dot, long dot_sb,
+                            long dot_sh, long dot_sd, const float* lse, const float* delta, const void* kmask,
+                            void* dq, long dq_sb, long dq_ss, long dq_sh, void* dk, long dk_sb, long dk_ss,
+                            long dk_sh, void* dv, long dv_sb, long dv_ss, long dv_sh, int B, int Hq, int Hkv,
+                            int Sq, int Sk, int hd, int causal, int q_off, float scale, void* stream) {
+    int e = attn_check(B, Hq, Hkv, Sq, Sk, hd);
+    if (e) return e;
+    if (!q || !k || !v || !dout || !kt || !qt || !dot || !lse || !delta || !dq || !dk || !dv) return BRA_ERR_ARG;
+    const int sk_pad = ((Sk + 63) / 64) * 64, sq_pad = ((Sq + 63) / 64) * 64;
+    if (kt_sd % 8 || qt_sd % 8 || dot_sd % 8 || kt_sd < sk_pad || qt_sd < sq_pad || dot_sd < sq_pad) return BRA_ERR_ARG;
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.q_sb = q_sb; a.q_ss = q_ss; a.q_sh = q_sh;
+    a.k = (const bf16_t*)k; a.k_sb = k_sb; a.k_ss = k_ss; a.k_sh = k_sh;
+    a.v = (const bf16_t*)v; a.v_sb = v_sb; a.v_ss = v_ss; a.v_sh = v_sh;
+    a.dout = (const bf16_t*)dout; a.do_sb = do_sb; a.do_ss = do_ss; a.do_sh = do_sh;
+    a.kt = (const bf16_t*)kt; a.kt_sb = kt_sb; a.kt_sh = kt_sh; a.kt_sd = kt_sd;
+    a.qt = (const bf16_t*)qt; a.qt_sb = qt_sb; a.qt_sh = qt_sh; a.qt_sd = qt_sd;
+    a.dot = (const bf16_t*)dot; a.dot_sb = dot_sb; a.dot_sh = dot_sh; a.dot_sd = dot_sd;
+    a.lse = const_cast<float*>(lse); a.delta = delta; a.kmask = (const uint8_t*)kmask;
+    a.dq = (bf16_t*)dq; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dq_sh = dq_sh;
+    a.dk = (bf16_t*)dk; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dk_sh = dk_sh;
+    a.dv = (bf16_t*)dv; a.dv_sb = dv_sb; a.dv_ss = dv_ss; a.dv_sh = dv_sh;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = Sq; a.Sk = Sk; a.causal = causal; a.q_off = q_off; a.scale = scale;
+    bra_stream_t st = (bra_stream_t)stream;
+    int r;
+    if (hd == 128) { r = launch_dq<128>(a, st); if (r) return r; return launch_dkv<128>(a, st); }
+    if (hd == 64) { r = launch_dq<64>(a, st); if (r) return r; return launch_dkv<64>(a, st); }
+    r = launch_dq<32>(a, st); if (r) return r; return launch_dkv<32>(a, st);
+}
+
+extern "C" int bra_attn_decode_nchunk(int len) { return (len + 127) / 128; }
+
+extern "C" int bra_attn_decode(const void* q, const void* kc, const void* vc, const void* kmask, float* part_o,
+                               float* part_ml, void* o, int B, int Hq, int Hkv, int hd, int Smax, int len,
+                               float scale, void* stream) {
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || len <= 0 || len > Smax) return BRA_ERR_ARG;
+    if (!q || !kc || !vc || !part_o || !part_ml || !o) return BRA_ERR_ARG;
+    const int G = Hq / Hkv;
+    DecodeArgs a = {(const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc, (const uint8_t*)kmask, part_o, part_ml,
+                    (bf16_t*)o, B, Hq, Hkv, hd, Smax, len, 128, (len + 127) / 128, scale};
+    bra_stream_t st = (bra_stream_t)stream;
+    dim3 grid((a.nchunk + 3) / 4, Hkv, B);
+#define BRA_DEC(HD_, G_)                                                                              \
+    if (hd == HD_ && G == G_) {                                                                       \
+        BRA_LAUNCH((attn_decode_partial_kernel<HD_, G_>), grid, dim3(256), 0, st, a);                 \
+        int r = BRA_LAUNCH_STATUS();                                                                  \
+        if (r) return r;                                                                              \
+        BRA_LAUNCH((attn_decode_merge_kernel<HD_>), dim3(Hq, B), dim3(64), 0, st, a);                 \
+        return BRA_LAUNCH_STATUS();                                                                   \
+    }
+    BRA_DEC(128, 1) BRA_DEC(128, 2) BRA_DEC(128, 4)
+    BRA_DEC(64, 1) BRA_DEC(64, 2) BRA_DEC(64, 4)
+    BRA_DEC(32, 1) BRA_DEC(32, 2) BRA_DEC(32, 4)
+#undef BRA_DEC
+    return BRA_ERR_UNSUPPORTED;
+}

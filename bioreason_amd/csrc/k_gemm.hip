@@ -1,0 +1,358 @@
+// k_gemm.hip — bf16 MFMA GEMM for gfx950 (CDNA4), "NT" form:
+//     C[M,N] = alpha * ( A[M,K] * B[N,K]^T  +  A2[M,K2] * B2[N,K2]^T ) (+ epilogue)
+// Every linear layer of the hot path is this contraction (both operands
+// K-contiguous): nn.Linear forward  y = x W^T  (TF:qwen3:225-236, TF:qwen3:81-83,
+// TF:esm:336-338,402, dna_llm.py:159-160), its dgrad dx = dy (W^T)^T against a
+// pre-transposed frozen weight, and the tied lm_head (TF:qwen3:495).  The
+// second operand pair (A2,B2,K2) carries the LoRA update  y += (x A^T) B^T
+// (PEFT, configured at train_dna_qwen.py:155-167 / reason.py:376-388) inside
+// the same accumulators, so LoRA costs K2/K extra MFMA work and no extra pass
+// over y.
+//
+// Structure: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, each
+// 64x64 = 4x4 fragments of v_mfma_f32_16x16x32_bf16), BK = 64 (or 32), LDS
+// double-buffered with a 16-byte-chunk XOR swizzle (conflict-free
+// ds_read_b128), register-staged global->LDS pipeline with one barrier per
+// K-step, XCD-aware grouped tile order.  Operand roles are swapped
+// (D[n][m]) so every lane owns 4 consecutive output columns of one row.
+#include "bra_device.h"
+#include "bra_api_internal.h"
+
+namespace bra {
+
+enum : int {
+    EPI_BF16 = 0,     // C bf16 = rnd(alpha*acc [+bias]) [+res, rounded again]
+    EPI_F32 = 1,      // C f32  = alpha*acc [+bias] (+ C when accumulate)
+    EPI_LSE = 2,      // no C; per (row, 64-col chunk) running max / sum-exp of rnd(acc), + target logit
+    EPI_DLOGIT = 3,   // C bf16 = rnd(coef[m] * ((n==tgt[m]) - exp(rnd(acc) - lse[m])))
+    EPI_ATOMIC = 4,   // C f32 += alpha*acc with atomics (split-K)
+};
+
+struct GemmArgs {
+    const bf16_t* A;  long lda;
+    const bf16_t* B;  long ldb;
+    const bf16_t* A2; long lda2;
+    const bf16_t* B2; long ldb2;
+    void* C;          long ldc;
+    int M, N, K, K2;
+    float alpha;
+    const bf16_t* bias;   // [N] or null
+    const bf16_t* res;    // [M, ldres] or null
+    long ldres;
+    int accumulate;       // EPI_F32: C += result
+    int split_k;          // number of K slices (EPI_ATOMIC)
+    // EPI_LSE / EPI_DLOGIT
+    const int* tgt;       // [M] target column per row (or -1)
+    float* part_max;      // [M, nchunk]
+    float* part_sum;      // [M, nchunk]
+    float* tgt_logit;     // [M]
+    const float* lse;     // [M]
+    const float* coef;    // [M]
+    int nchunk;
+};
+
+template <int BK>
+__device__ __forceinline__ int swz_chunk(int row, int c) {
+    return BK == 64 ? (c ^ (row & 7)) : (c ^ ((row >> 2) & 3));
+}
+
+template <int BK, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+    constexpr int BM = 128, BN = 128;
+    constexpr int CH = BK / 8;              // 16-byte chunks per tile row
+    constexpr int LPT = (BM * CH) / 256;    // 16-byte loads per thread per operand per K-step
+    constexpr int TILE_BYTES = BM * BK * 2;
+    BRA_DYN_SMEM(smem);                     // [2 buffers][A tile | B tile]
+
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;   // wave position in the 2x2 grid
+
+    // ---- tile order: XCD-aware, grouped along M so a group re-uses B panels from L2
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = (int)blockIdx.x;
+    int kslice = 0;
+    if (EPI == EPI_ATOMIC) { kslice = bid / ntiles; bid -= kslice * ntiles; }
+    bid = (int)xcd_remap((unsigned)bid, (unsigned)ntiles);
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int gid = bid / per_group;
+    const int first_m = gid * GROUP;
+    const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int tile_m = first_m + (bid % per_group) % gsize;
+    const int tile_n = (bid % per_group) / gsize;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- K range (main + LoRA operand pair, optionally sliced)
+    const int nk1 = g.K / BK, nk2 = g.K2 / BK;
+    int kt_begin = 0, kt_end = nk1 + nk2;
+    if (EPI == EPI_ATOMIC && g.split_k > 1) {
+        int per = (kt_end + g.split_k - 1) / g.split_k;
+        kt_begin = kslice * per;
+        kt_end = kt_begin + per < kt_end ? kt_begin + per : kt_end;
+        if (kt_begin >= kt_end) return;
+    }
+
+    // ---- per-thread global->LDS staging slots
+    int ld_row[LPT], ld_c[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        int q = tid + 256 * i;
+        ld_row[i] = q / CH;
+        ld_c[i] = q % CH;
+    }
+    u32x4 ra[LPT], rb[LPT];
+
+    auto issue_loads = [&](int kt) {
+        const bf16_t* Ap; const bf16_t* Bp; long la, lb; int k0;
+        if (kt < nk1) { Ap = g.A; Bp = g.B; la = g.lda; lb = g.ldb; k0 = kt * BK; }
+        else { Ap = g.A2; Bp = g.B2; la = g.lda2; lb = g.ldb2; k0 = (kt - nk1) * BK; }
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            int rm = m0 + ld_row[i]; rm = rm < g.M ? rm : g.M - 1;   // clamp: rows past M are never stored
+            int rn = n0 + ld_row[i]; rn = rn < g.N ? rn : g.N - 1;
+            ra[i] = ld16(Ap + (long)rm * la + k0 + ld_c[i] * 8);
+            rb[i] = ld16(Bp + (long)rn * lb + k0 + ld_c[i] * 8);
+        }
+    };
+    auto write_lds = [&](int buf) {
+        char* sa = smem + buf * 2 * TILE_BYTES;
+        char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            int off = ld_row[i] * (BK * 2) + swz_chunk<BK>(ld_row[i], ld_c[i]) * 16;
+            st16(sa + off, ra[i]);
+            st16(sb + off, rb[i]);
+        }
+    };
+
+    f32x4 acc[4][4];   // acc[ni][mi]: D[n = 16*ni + 4*(lane>>4) + r][m = 16*mi + (lane&15)]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue_loads(kt_begin);
+    write_lds(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        const bool more = (kt + 1 < kt_end);
+        if (more) issue_loads(kt + 1);
+        const char* sa = smem + buf * 2 * TILE_BYTES;
+        const char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            u32x4 fa[4], fb[4];
+            const int c = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int rowa = wm * 64 + i * 16 + fr;
+                int rowb = wn * 64 + i * 16 + fr;
+                fa[i] = ld16(sa + rowa * (BK * 2) + swz_chunk<BK>(rowa, c) * 16);
+                fb[i] = ld16(sb + rowb * (BK * 2) + swz_chunk<BK>(rowb, c) * 16);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma_16x16x32(fb[ni], fa[mi], acc[ni][mi]);
+        }
+        if (more) write_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns C[m][n..n+3], m = m0 + wm*64 + 16*mi + fr, n = n0 + wn*64 + 16*ni + 4*fq
+    const float alpha = g.alpha;
+    if (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_ATOMIC || EPI == EPI_DLOGIT) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + fr;
+            if (m >= g.M) continue;
+            float lse_m = 0.f, coef_m = 0.f; int tgt_m = -1;
+            if (EPI == EPI_DLOGIT) { lse_m = g.lse[m]; coef_m = g.coef[m]; tgt_m = g.tgt[m]; }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+                if (n >= g.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] * alpha;
+                const bool full = (n + 3 < g.N);
+                if (EPI == EPI_BF16) {
+                    if (g.bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += bf2f(g.bias[n + r]);
+                    }
+                    if (g.res) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < g.N) v[r] = round_bf(v[r]) + bf2f(g.res[(long)m * g.ldres + n + r]);
+                    }
+                    bf16_t* cp = (bf16_t*)g.C + (long)m * g.ldc + n;
+                    if (full) {
+                        u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                        st8(cp, o);
+                    } else {
+                        for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = f2bf(v[r]);
+                    }
+                } else if (EPI == EPI_DLOGIT) {
+                    bf16_t* cp = (bf16_t*)g.C + (long)m * g.ldc + n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p = __expf(round_bf(v[r]) - lse_m);
+                        v[r] = coef_m * (((n + r) == tgt_m ? 1.f : 0.f) - p);
+                    }
+                    if (full) {
+                        u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                        st8(cp, o);
+                    } else {
+                        for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = f2bf(v[r]);
+                    }
+                } else if (EPI == EPI_F32) {
+                    float* cp = (float*)g.C + (long)m * g.ldc + n;
+                    if (g.bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += bf2f(g.bias[n + r]);
+                    }
+                    if (full) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        if (g.accumulate) o += *reinterpret_cast<const f32x4*>(cp);
+                        *reinterpret_cast<f32x4*>(cp) = o;
+                    } else {
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < g.N) cp[r] = g.accumulate ? cp[r] + v[r] : v[r];
+                    }
+                } else {  // EPI_ATOMIC
+                    float* cp = (float*)g.C + (long)m * g.ldc + n;
+                    for (int r = 0; r < 4; ++r) if (n + r < g.N) atomicAdd(cp + r, v[r]);
+                }
+            }
+        }
+    } else {  // EPI_LSE: each wave reduces its 64 columns per row
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + fr;
+            const int tgt_m = (m < g.M) ? g.tgt[m] : -1;
+            float vmax = -3.0e38f;
+            float vals[16];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = round_bf(acc[ni][mi][r] * alpha);
+                    bool ok = (n + r) < g.N;
+                    vals[ni * 4 + r] = ok ? x : -3.0e38f;
+                    if (ok) vmax = fmaxf(vmax, x);
+                    if (ok && (n + r) == tgt_m) g.tgt_logit[m] = x;
+                }
+            }
+            // lanes fr, fr+16, fr+32, fr+48 hold the same row: reduce over fq
+            vmax = fmaxf(vmax, wave_shfl_xor(vmax, 16));
+            vmax = fmaxf(vmax, wave_shfl_xor(vmax, 32));
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += (vals[i] > -1.0e38f) ? __expf(vals[i] - vmax) : 0.f;
+            s += wave_shfl_xor(s, 16);
+            s += wave_shfl_xor(s, 32);
+            const int chunk = tile_n * 2 + wn;
+            if (fq == 0 && m < g.M && chunk < g.nchunk) {
+                g.part_max[(long)m * g.nchunk + chunk] = vmax;
+                g.part_sum[(long)m * g.nchunk + chunk] = s;
+            }
+        }
+    }
+}
+
+template <int BK, int EPI>
+static int launch_gemm(const GemmArgs& g, bra_stream_t stream) {
+    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    int grid = tiles;
+    if (EPI == EPI_ATOMIC) grid = tiles * (g.split_k > 0 ? g.split_k : 1);
+    const size_t smem = 2 * 2 * 128 * BK * 2;
+    BRA_LAUNCH((gemm_nt_kernel<BK, EPI>), dim3(grid), dim3(256), smem, stream, g);
+    return BRA_LAUNCH_STATUS();
+}
+
+template <int EPI>
+static int dispatch_bk(const GemmArgs& g, bra_stream_t stream) {
+    if (g.K % 64 == 0 && g.K2 % 64 == 0) return launch_gemm<64, EPI>(g, stream);
+    return launch_gemm<32, EPI>(g, stream);
+}
+
+static int check_common(const GemmArgs& g) {
+    if (g.M <= 0 || g.N <= 0) return BRA_ERR_ARG;
+    if (g.K < 0 || g.K2 < 0 || (g.K + g.K2) <= 0) return BRA_ERR_ARG;
+    if (g.K % 32 || g.K2 % 32) return BRA_ERR_ARG;
+    if (g.K && (g.lda % 8 || g.ldb % 8 || !g.A || !g.B)) return BRA_ERR_ARG;
+    if (g.K2 && (g.lda2 % 8 || g.ldb2 % 8 || !g.A2 || !g.B2)) return BRA_ERR_ARG;
+    return 0;
+}
+
+}  // namespace bra
+
+using namespace bra;
+
+extern "C" int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2,
+                                const void* B2, long ldb2, int K2, void* C, long ldc, int M, int N, int K,
+                                float alpha, const void* bias, const void* res, long ldres, int out_f32,
+                                int accumulate, void* stream) {
+    GemmArgs g = {};
+    g.A = (const bf16_t*)A; g.lda = lda; g.B = (const bf16_t*)B; g.ldb = ldb;
+    g.A2 = (const bf16_t*)A2; g.lda2 = lda2; g.B2 = (const bf16_t*)B2; g.ldb2 = ldb2;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.K2 = K2; g.alpha = alpha;
+    g.bias = (const bf16_t*)bias; g.res = (const bf16_t*)res; g.ldres = ldres; g.accumulate = accumulate;
+    if (M == 0 || N == 0) return 0;
+    int e = check_common(g);
+    if (e) return e;
+    if (!C || ldc % 4) return BRA_ERR_ARG;
+    if (out_f32) {
+        if (res) return BRA_ERR_ARG;
+        return dispatch_bk<EPI_F32>(g, (bra_stream_t)stream);
+    }
+    return dispatch_bk<EPI_BF16>(g, (bra_stream_t)stream);
+}
+
+extern "C" int bra_gemm_bf16_nt_splitk(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M,
+                                       int N, int K, float alpha, int split_k, void* stream) {
+    GemmArgs g = {};
+    g.A = (const bf16_t*)A; g.lda = lda; g.B = (const bf16_t*)B; g.ldb = ldb;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.split_k = split_k < 1 ? 1 : split_k;
+    if (M == 0 || N == 0) return 0;
+    int e = check_common(g);
+    if (e) return e;
+    if (!C) return BRA_ERR_ARG;
+    return dispatch_bk<EPI_ATOMIC>(g, (bra_stream_t)stream);
+}
+
+extern "C" int bra_lmhead_lse_partials(const void* H, long ldh, const void* E, long lde, int M, int V, int K,
+                                       const int* tgt, float* part_max, float* part_sum, float* tgt_logit,
+                                       void* stream) {
+    GemmArgs g = {};
+    g.A = (const bf16_t*)H; g.lda = ldh; g.B = (const bf16_t*)E; g.ldb = lde;
+    g.M = M; g.N = V; g.K = K; g.alpha = 1.f;
+    g.tgt = tgt; g.part_max = part_max; g.part_sum = part_sum; g.tgt_logit = tgt_logit;
+    g.nchunk = (V + 63) / 64;
+    if (M == 0) return 0;
+    int e = check_common(g);
+    if (e) return e;
+    if (!tgt || !part_max || !part_sum || !tgt_logit) return BRA_ERR_ARG;
+    return dispatch_bk<EPI_LSE>(g, (bra_stream_t)stream);
+}
+
+extern "C" int bra_lmhead_dlogits(const void* H, long ldh, const void* E, long lde, int M, int V, int K,
+                                  const int* tgt, const float* lse, const float* coef, void* dlogits, long ldd,
+                                  void* stream) {
+    GemmArgs g = {};
+    g.A = (const bf16_t*)H; g.lda = ldh; g.B = (const bf16_t*)E; g.ldb = lde;
+    g.C = dlogits; g.ldc = ldd; g.M = M; g.N = V; g.K = K; g.alpha = 1.f;
+    g.tgt = tgt; g.lse = lse; g.coef = coef;
+    if (M == 0) return 0;
+    int e = check_common(g);
+    if (e) return e;
+    if (!tgt || !lse || !coef || !dlogits || ldd % 4) return BRA_ERR_ARG;
+    return dispatch_bk<EPI_DLOGIT>(g, (bra_stream_t)stream);
+}

@@ -1,0 +1,218 @@
+// k_grpo.hip — rollout-side and loss-side GRPO arithmetic:
+//   * next-token sampler: temperature -> top-k -> top-p -> multinomial / argmax
+//     (HF warpers TF:generation/logits_process.py:238,473,542 and _sample
+//      TF:generation/utils.py:2897-2925 with the GenerationConfig of grpo_trainer.py:384-391)
+//   * first-EOS completion mask            (grpo_trainer.py:605-609)
+//   * group-normalised advantages          (grpo_trainer.py:682-699)
+//   * clipped-ratio + k3-KL loss, fwd+bwd  (grpo_trainer.py:786-814)
+#include "bra_device.h"
+#include "bra_api_internal.h"
+
+namespace bra {
+
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// uniform in [0,1) from (seed, step, row): counter-based, so replaying a captured graph with a new
+// `step` word in device memory yields a new draw without host involvement.
+__device__ __forceinline__ float uniform01(uint32_t seed, uint32_t step, uint32_t row) {
+    uint32_t h = hash_u32(seed ^ hash_u32(step * 0x9e3779b9u + 0x85ebca6bu) ^ hash_u32(row + 0xc2b2ae35u));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+// One workgroup per sequence.  logits: fp32 [B, V].  Top-k by k rounds of a block-wide arg-max
+// under the strict total order (value desc, index asc) — k <= 64.
+template <int NT>
+__global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ldl, int V, float temperature,
+                                                    int top_k, float top_p, int do_sample, uint32_t seed,
+                                                    const int* step_ptr, const uint8_t* finished, int pad_id,
+                                                    int* out_ids, float* out_logp) {
+    __shared__ float s_val[NT / 64];
+    __shared__ int s_idx[NT / 64];
+    __shared__ float top_v[64];
+    __shared__ int top_i[64];
+    const int row = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lr = logits + (long)row * ldl;
+    const int k = do_sample ? (top_k > 0 ? (top_k < 64 ? top_k : 64) : 64) : 1;
+    float last_v = 3.0e38f;
+    int last_i = -1;
+    for (int round = 0; round < k; ++round) {
+        float bv = -3.0e38f;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < V; i += NT) {
+            const float v = lr[i];
+            // candidates strictly after (last_v, last_i) in the order (value desc, index asc)
+            const bool after = (v < last_v) || (v == last_v && i > last_i);
+            if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+        }
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = wave_shfl_xor(bv, m);
+            const int oi = wave_shfl_xor_i(bi, m);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NT / 64; ++w)
+                if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+            top_v[round] = bv; top_i[round] = bi;
+        }
+        __syncthreads();
+        last_v = top_v[round];
+        last_i = top_i[round];
+    }
+    if (tid == 0) {
+        int choice = top_i[0];
+        float lp = 0.f;
+        if (do_sample) {
+            // temperature, softmax over the top-k survivors
+            const float inv_t = 1.f / temperature;
+            float p[64];
+            const float mx = top_v[0] * inv_t;
+            float z = 0.f;
+            for (int j = 0; j < k; ++j) { p[j] = __expf(top_v[j] * inv_t - mx); z += p[j]; }
+            for (int j = 0; j < k; ++j) p[j] /= z;
+            // top-p (HF: sort ascending, drop tokens whose cumulative prob <= 1 - top_p, keep >= 1)
+            int keep = k;
+            if (top_p < 1.f) {
+                float cum = 0.f;
+                for (int j = k - 1; j >= 1; --j) {   // ascending order = from the tail of our descending list
+                    cum += p[j];
+                    if (cum <= 1.f - top_p) keep = j; else break;
+                }
+            }
+            float z2 = 0.f;
+            for (int j = 0; j < keep; ++j) z2 += p[j];
+            const float u = uniform01(seed, (uint32_t)(step_ptr ? step_ptr[0] : 0), (uint32_t)row) * z2;
+            float acc = 0.f;
+            int pick = keep - 1;
+            for (int j = 0; j < keep; ++j) { acc += p[j]; if (u < acc) { pick = j; break; } }
+            choice = top_i[pick];
+            lp = __logf(p[pick] / z2);
+        }
+        if (finished && finished[row]) choice = pad_id;   // HF: finished sequences emit pad_token_id
+        out_ids[row] = choice;
+        if (out_logp) out_logp[row] = lp;
+    }
+}
+
+// completion_mask[b, c] = c <= first_eos(b) ; also lengths[b] = mask.sum()
+__global__ __launch_bounds__(64) void eos_mask_kernel(const int* ids, int C, int eos_id, int* mask, int* lengths) {
+    const int b = (int)blockIdx.x, lane = lane_id();
+    int first = C;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        const bool e = c < C && ids[(long)b * C + c] == eos_id;
+        const uint64_t bal = wave_ballot(e);
+        if (bal && first == C) first = c0 + __builtin_ctzll(bal);
+    }
+    for (int c = lane; c < C; c += 64) mask[(long)b * C + c] = c <= first ? 1 : 0;
+    if (lane == 0 && lengths) lengths[b] = first < C ? first + 1 : C;
+}
+
+// advantages over all gathered rewards: rewards [N, F] -> sum over F -> per group of G mean / unbiased std
+__global__ __launch_bounds__(64) void group_advantage_kernel(const float* rewards, int F, int G, float* adv,
+                                                             float* grp_mean, float* grp_std) {
+    const int grp = (int)blockIdx.x, lane = lane_id();
+    float r = 0.f;
+    if (lane < G) for (int f = 0; f < F; ++f) r += rewards[((long)grp * G + lane) * F + f];
+    const float mean = wave_sum<64>(lane < G ? r : 0.f) / (float)G;
+    const float d = lane < G ? r - mean : 0.f;
+    const float var = wave_sum<64>(d * d) / (float)(G - 1);   // torch.std default: unbiased (NaN for G == 1)
+    const float sd = sqrtf(var);
+    if (lane < G) adv[(long)grp * G + lane] = (r - mean) / (sd + 1e-4f);
+    if (lane == 0) { if (grp_mean) grp_mean[grp] = mean; if (grp_std) grp_std[grp] = sd; }
+}
+
+// loss = mean_b( sum_c(ptl * mask) / sum_c(mask) ),  ptl = -min(r A, clip(r) A) + beta * k3
+// outputs: out[0] loss, out[1] mean_kl, out[2] clip_ratio; dlogp [B, C] = d loss / d logp
+__global__ __launch_bounds__(256) void grpo_loss_kernel(const float* logp, const float* old_logp, const float* ref_logp,
+                                                        const float* adv, const int* mask, int B, int C, float eps_lo,
+                                                        float eps_hi, float beta, float* out, float* dlogp) {
+    __shared__ float red[4];
+    const int tid = (int)threadIdx.x;
+    float loss_acc = 0.f, kl_acc = 0.f, clip_num = 0.f, mask_tot = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float ms = 0.f;
+        for (int c = tid; c < C; c += 256) ms += (float)mask[(long)b * C + c];
+        ms = block_sum<4>(ms, red);
+        const float A = adv[b];
+        float ls = 0.f, ks = 0.f, cs = 0.f;
+        for (int c = tid; c < C; c += 256) {
+            const long i = (long)b * C + c;
+            const float lp = logp[i];
+            const float ol = old_logp ? old_logp[i] : lp;
+            const float mk = (float)mask[i];
+            const float c1 = __expf(lp - ol);
+            const float c2 = fminf(fmaxf(c1, 1.f - eps_lo), 1.f + eps_hi);
+            const float l1 = c1 * A, l2 = c2 * A;
+            float ptl = -fminf(l1, l2);
+            // d(-min(l1,l2))/dlp ; d c1/dlp = c1 ; clamp passes gradient inside [lo, hi]; ties split evenly
+            const float g1 = -A * c1;
+            const float g2 = (c1 >= 1.f - eps_lo && c1 <= 1.f + eps_hi) ? -A * c1 : 0.f;
+            float g = l1 < l2 ? g1 : (l1 > l2 ? g2 : 0.5f * (g1 + g2));
+            if (beta != 0.f && ref_logp) {
+                const float dl = ref_logp[i] - lp;
+                const float e = __expf(dl);
+                const float kl = e - dl - 1.f;
+                ptl += beta * kl;
+                g += beta * (1.f - e);
+                ks += kl * mk;
+            }
+            ls += ptl * mk;
+            cs += (l1 < l2 ? 1.f : 0.f) * mk;
+            if (dlogp) dlogp[i] = ms > 0.f ? g * mk / (ms * (float)B) : 0.f;
+        }
+        ls = block_sum<4>(ls, red);
+        ks = block_sum<4>(ks, red);
+        cs = block_sum<4>(cs, red);
+        loss_acc += ls / ms;
+        kl_acc += ks / ms;
+        clip_num += cs;
+        mask_tot += ms;
+    }
+    if (tid == 0) {
+        out[0] = loss_acc / (float)B;
+        out[1] = kl_acc / (float)B;
+        out[2] = clip_num / mask_tot;
+    }
+}
+
+}  // namespace bra
+
+using namespace bra;
+
+extern "C" int bra_sample(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p,
+                          int do_sample, unsigned seed, const int* step_ptr, const void* finished, int pad_id,
+                          int* out_ids, float* out_logp, void* stream) {
+    if (B == 0) return 0;
+    if (!logits || !out_ids || V <= 0 || (do_sample && temperature <= 0.f)) return BRA_ERR_ARG;
+    BRA_LAUNCH((sample_kernel<1024>), dim3(B), dim3(1024), 0, stream, logits, ldl, V, temperature, top_k, top_p,
+               do_sample, (uint32_t)seed, step_ptr, (const uint8_t*)finished, pad_id, out_ids, out_logp);
+    return BRA_LAUNCH_STATUS();
+}
+
+extern "C" int bra_eos_mask(const int* ids, int B, int C, int eos_id, int* mask, int* lengths, void* stream) {
+    if (B == 0 || C == 0) return 0;
+    if (!ids || !mask) return BRA_ERR_ARG;
+    BRA_LAUNCH(eos_mask_kernel, dim3(B), dim3(64), 0, stream, ids, C, eos_id, mask, lengths);
+    return BRA_LAUNCH_STATUS();
+}
+
+extern "C" int bra_group_advantage(const float* rewards, int N, int F, int G, float* adv, float* grp_mean,
+                                   float* grp_std, void* stream) {
+    if (N == 0) return 0;
+    if (!rewards || !adv || G <= 0 || G > 64 || N % G || F <= 0) return BRA_ERR_ARG;
+    BRA_LAUNCH(group_advantage_kernel, dim3(N / G), dim3(64), 0, stream, rewards, F, G, adv, grp_mean, grp_std);
+    return BRA_LAUNCH_STATUS();
+}
+
+extern "C" int bra_grpo_loss(const float* logp, const float* old_logp, const float* ref_logp, const float* adv,
+                             const int* mask, int B, int C, float eps_lo, float eps_hi, float beta, float* out3,
+                             float* dlogp, void* stream) {
+    if (B <= 0 || C <= 0 || !logp || !adv || !mask || !out3) return BRA_ERR_ARG;
+    BRA_LAUNCH(grpo_loss_kernel, dim3(1), dim3(256), 0, stream, logp, old_logp, ref_logp, adv, mask, B, C, eps_lo,
+               eps_hi, beta, out3, dlogp);
+    return BRA_LAUNCH_STATUS();
+}

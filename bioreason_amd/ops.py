@@ -1,0 +1,322 @@
+"""Thin tensor-level wrappers over the C-ABI kernels (one function per entry point).
+
+PyTorch supplies device memory and the stream; every arithmetic step is a HIP
+kernel from ``libbioreason_hip.so``.  No function here falls back to torch math.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import current_stream, get_lib
+
+BF16 = torch.bfloat16
+
+
+def _ld(t: torch.Tensor) -> int:
+    """leading dimension (elements) of a 2-D-viewable tensor with contiguous last dim"""
+    assert t.stride(-1) == 1, "last dim must be contiguous"
+    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+
+
+def _rows(t: torch.Tensor) -> int:
+    return t.numel() // t.shape[-1]
+
+
+def _as2d(t: torch.Tensor) -> torch.Tensor:
+    return t.reshape(-1, t.shape[-1]) if t.dim() != 2 else t
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm_nt(
+    a: torch.Tensor,
+    b: torch.Tensor,
+    *,
+    a2: Optional[torch.Tensor] = None,
+    b2: Optional[torch.Tensor] = None,
+    bias: Optional[torch.Tensor] = None,
+    res: Optional[torch.Tensor] = None,
+    out: Optional[torch.Tensor] = None,
+    alpha: float = 1.0,
+    out_f32: bool = False,
+    accumulate: bool = False,
+) -> torch.Tensor:
+    """out[M,N] = alpha * (a[M,K] @ b[N,K]^T + a2[M,K2] @ b2[N,K2]^T) (+bias) (+res)"""
+    a = _as2d(a)
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and a.dtype == BF16 and b.dtype == BF16
+    K2 = 0
+    if a2 is not None:
+        a2 = _as2d(a2)
+        K2 = a2.shape[1]
+        assert b2 is not None and b2.shape == (N, K2) and a2.shape[0] == M
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+    else:
+        assert out.shape == (M, N) and out.dtype == (torch.float32 if out_f32 else BF16)
+    if res is not None:
+        res = _as2d(res)
+        assert res.shape == (M, N) and res.dtype == BF16
+    get_lib().call(
+        "bra_gemm_bf16_nt", a, _ld(a), b, _ld(b), a2, _ld(a2) if a2 is not None else 0, b2,
+        _ld(b2) if b2 is not None else 0, K2, out, _ld(out), M, N, K, alpha, bias, res,
+        _ld(res) if res is not None else 0, int(out_f32), int(accumulate), current_stream(a),
+    )
+    return out
+
+
+def gemm_nt_splitk(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, split_k: int = 0) -> torch.Tensor:
+    """out[M,N] (f32) += alpha * a[M,K] @ b[N,K]^T, K sliced over workgroups (atomics)."""
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and out.shape == (M, N) and out.dtype == torch.float32
+    if split_k <= 0:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        split_k = max(1, min(K // 256 if K >= 256 else 1, (512 + tiles - 1) // tiles))
+    get_lib().call("bra_gemm_bf16_nt_splitk", a, _ld(a), b, _ld(b), out, _ld(out), M, N, K, alpha, split_k, current_stream(a))
+    return out
+
+
+def lmhead_logprob(h: torch.Tensor, emb: torch.Tensor, tgt: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (logp[M], lse[M]) of target tokens under softmax(h @ emb^T) without materialising logits."""
+    M, K = h.shape
+    V = emb.shape[0]
+    nchunk = (V + 63) // 64
+    dev = h.device
+    pm = torch.empty((M, nchunk), dtype=torch.float32, device=dev)
+    ps = torch.empty((M, nchunk), dtype=torch.float32, device=dev)
+    tl = torch.zeros((M,), dtype=torch.float32, device=dev)
+    lse = torch.empty((M,), dtype=torch.float32, device=dev)
+    logp = torch.empty((M,), dtype=torch.float32, device=dev)
+    st = current_stream(h)
+    lib = get_lib()
+    lib.call("bra_lmhead_lse_partials", h, _ld(h), emb, _ld(emb), M, V, K, tgt, pm, ps, tl, st)
+    lib.call("bra_lse_merge", pm, ps, tl, lse, logp, M, nchunk, st)
+    return logp, lse
+
+
+def lmhead_dlogits(h: torch.Tensor, emb: torch.Tensor, tgt: torch.Tensor, lse: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
+    M, K = h.shape
+    V = emb.shape[0]
+    out = torch.empty((M, V), dtype=BF16, device=h.device)
+    get_lib().call("bra_lmhead_dlogits", h, _ld(h), emb, _ld(emb), M, V, K, tgt, lse, coef, out, _ld(out), current_stream(h))
+    return out
+
+
+# --------------------------------------------------------------------------- norms / activations
+def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    x2 = _as2d(x)
+    y = torch.empty_like(x2)
+    get_lib().call("bra_rmsnorm_fwd", x2, _ld(x2), w, y, _ld(y), None, x2.shape[0], x2.shape[1], eps, current_stream(x))
+    return y.view(x.shape)
+
+
+def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, eps: float, dres: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x2, dy2 = _as2d(x), _as2d(dy)
+    dx = torch.empty_like(x2)
+    d2 = _as2d(dres) if dres is not None else None
+    get_lib().call("bra_rmsnorm_bwd", dy2, _ld(dy2), x2, _ld(x2), w, d2, _ld(d2) if d2 is not None else 0, dx, _ld(dx),
+                   x2.shape[0], x2.shape[1], eps, current_stream(x))
+    return dx.view(x.shape)
+
+
+def layernorm_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    x2 = _as2d(x)
+    y = torch.empty_like(x2)
+    get_lib().call("bra_layernorm_fwd", x2, _ld(x2), w, b, y, _ld(y), x2.shape[0], x2.shape[1], eps, current_stream(x))
+    return y.view(x.shape)
+
+
+def swiglu_fwd(gu: torch.Tensor) -> torch.Tensor:
+    gu2 = _as2d(gu)
+    F = gu2.shape[1] // 2
+    act = torch.empty((gu2.shape[0], F), dtype=BF16, device=gu.device)
+    get_lib().call("bra_swiglu_fwd", gu2, _ld(gu2), act, _ld(act), gu2.shape[0], F, current_stream(gu))
+    return act
+
+
+def swiglu_bwd(gu: torch.Tensor, dact: torch.Tensor) -> torch.Tensor:
+    gu2, d2 = _as2d(gu), _as2d(dact)
+    F = gu2.shape[1] // 2
+    dgu = torch.empty_like(gu2)
+    get_lib().call("bra_swiglu_bwd", gu2, _ld(gu2), d2, _ld(d2), dgu, _ld(dgu), gu2.shape[0], F, current_stream(gu))
+    return dgu
+
+
+def _bsh_strides(t: torch.Tensor) -> Tuple[int, int, int]:
+    """t is [B, S, H, hd] (any permutation underneath) -> element strides (b, s, h)"""
+    assert t.dim() == 4 and t.stride(3) == 1
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def qk_norm_rope_fwd(qkv, qw, kw, cosT, sinT, pos, S, Hq, Hkv, hd, eps, qscale, q, k, v, s_off=0):
+    """qkv [T, (Hq+2Hkv)*hd]; q/k/v: 4-D views indexed [B, S, H, hd] (arbitrary strides, hd contiguous)."""
+    T = qkv.shape[0]
+    get_lib().call("bra_qk_norm_rope_fwd", qkv, _ld(qkv), qw, kw, cosT, sinT, pos, T, S, Hq, Hkv, hd, eps, qscale,
+                   q, *_bsh_strides(q), k, *_bsh_strides(k), v, *_bsh_strides(v), s_off, current_stream(qkv))
+
+
+def qk_norm_rope_bwd(qkv, qw, kw, cosT, sinT, pos, S, Hq, Hkv, hd, eps, qscale, dq, dk, dv):
+    T = qkv.shape[0]
+    dqkv = torch.empty_like(qkv)
+    get_lib().call("bra_qk_norm_rope_bwd", qkv, _ld(qkv), qw, kw, cosT, sinT, pos, T, S, Hq, Hkv, hd, eps, qscale,
+                   dq, *_bsh_strides(dq), dk, *_bsh_strides(dk), dv, *_bsh_strides(dv), dqkv, _ld(dqkv), current_stream(qkv))
+    return dqkv
+
+
+# --------------------------------------------------------------------------- attention
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+def head_transpose(x: torch.Tensor) -> torch.Tensor:
+    """x: [B, S, H, hd] view -> [B, H, hd, pad64(S)] (zero padded)"""
+    B, S, H, hd = x.shape
+    out = torch.empty((B, H, hd, pad64(S)), dtype=BF16, device=x.device)
+    sb, ss, sh = _bsh_strides(x)
+    get_lib().call("bra_head_transpose", x, sb, ss, sh, out, out.stride(0), out.stride(1), out.stride(2), B, S, H, hd, current_stream(x))
+    return out
+
+
+def attn_fwd(q, k, vt, kmask, causal: bool, scale: float, q_off: Optional[int] = None, need_lse: bool = True,
+             out: Optional[torch.Tensor] = None):
+    """q: [B,Sq,Hq,hd] view, k: [B,Sk,Hkv,hd] view, vt: [B,Hkv,hd,pitch]; -> (o [B,Sq,Hq,hd] contiguous, lse [B,Hq,Sq])"""
+    B, Sq, Hq, hd = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    if q_off is None:
+        q_off = Sk - Sq
+    o = out if out is not None else torch.empty((B, Sq, Hq, hd), dtype=BF16, device=q.device)
+    lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device) if need_lse else None
+    get_lib().call("bra_attn_fwd", q, *_bsh_strides(q), k, *_bsh_strides(k), vt, vt.stride(0), vt.stride(1), vt.stride(2),
+                   o, *_bsh_strides(o), lse, kmask, B, Hq, Hkv, Sq, Sk, hd, int(causal), q_off, scale, current_stream(q))
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, dout, lse, kmask, causal: bool, scale: float, q_off: Optional[int] = None):
+    """all of q,k,v,o,dout are [B,S,H,hd] views; returns dq, dk, dv (contiguous [B,S,H,hd])"""
+    B, Sq, Hq, hd = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    if q_off is None:
+        q_off = Sk - Sq
+    lib = get_lib()
+    st = current_stream(q)
+    delta = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device)
+    lib.call("bra_attn_delta", dout, *_bsh_strides(dout), o, *_bsh_strides(o), delta, B, Sq, Hq, hd, st)
+    kt = head_transpose(k)
+    qt = head_transpose(q)
+    dot = head_transpose(dout)
+    dq = torch.empty((B, Sq, Hq, hd), dtype=BF16, device=q.device)
+    dk = torch.empty((B, Sk, Hkv, hd), dtype=BF16, device=q.device)
+    dv = torch.empty((B, Sk, Hkv, hd), dtype=BF16, device=q.device)
+    lib.call("bra_attn_bwd", q, *_bsh_strides(q), k, *_bsh_strides(k), v, *_bsh_strides(v), dout, *_bsh_strides(dout),
+             kt, kt.stride(0), kt.stride(1), kt.stride(2), qt, qt.stride(0), qt.stride(1), qt.stride(2),
+             dot, dot.stride(0), dot.stride(1), dot.stride(2), lse, delta, kmask,
+             dq, *_bsh_strides(dq), dk, *_bsh_strides(dk), dv, *_bsh_strides(dv),
+             B, Hq, Hkv, Sq, Sk, hd, int(causal), q_off, scale, st)
+    return dq, dk, dv
+
+
+def attn_decode(q, kc, vc, kmask, length: int, scale: float, ws=None):
+    """q [B,Hq,hd]; kc/vc [B,Hkv,Smax,hd] contiguous; -> o [B, Hq*hd]"""
+    B, Hq, hd = q.shape
+    Hkv, Smax = kc.shape[1], kc.shape[2]
+    nchunk = (length + 127) // 128
+    if ws is None:
+        po = torch.empty((B, Hq, nchunk, hd), dtype=torch.float32, device=q.device)
+        pml = torch.empty((B, Hq, nchunk, 2), dtype=torch.float32, device=q.device)
+        o = torch.empty((B, Hq * hd), dtype=BF16, device=q.device)
+    else:
+        po, pml, o = ws
+    get_lib().call("bra_attn_decode", q, kc, vc, kmask, po, pml, o, B, Hq, Hkv, hd, Smax, length, scale, current_stream(q))
+    return o
+
+
+# --------------------------------------------------------------------------- data movement
+def dna_scatter_plan(ids32, dna_id, dna_mask_u8, seq_order, tok_src, counts):
+    nseq, Sd = (dna_mask_u8.shape if dna_mask_u8 is not None else (0, 0))
+    get_lib().call("bra_dna_scatter_plan", ids32, ids32.numel(), dna_id, dna_mask_u8, nseq, Sd, seq_order, tok_src, counts,
+                   current_stream(ids32))
+
+
+def embed_scatter_fwd(ids32, tok_src, emb, dna_rows, out):
+    H = emb.shape[1]
+    get_lib().call("bra_embed_scatter_fwd", ids32, tok_src, emb, _ld(emb), dna_rows, _ld(dna_rows) if dna_rows is not None else 0,
+                   out, _ld(out), ids32.numel(), H, current_stream(emb))
+    return out
+
+
+def embed_scatter_bwd(tok_src, dout, ddna):
+    H = dout.shape[-1]
+    d2 = _as2d(dout)
+    get_lib().call("bra_embed_scatter_bwd", tok_src, d2, _ld(d2), ddna, _ld(ddna), d2.shape[0], H, current_stream(dout))
+    return ddna
+
+
+def gather_rows(rows32, x):
+    out = torch.empty((rows32.numel(), x.shape[1]), dtype=BF16, device=x.device)
+    get_lib().call("bra_gather_rows", rows32, x, _ld(x), out, _ld(out), rows32.numel(), x.shape[1], current_stream(x))
+    return out
+
+
+def scatter_rows(rows32, x, nrows_out):
+    out = torch.zeros((nrows_out, x.shape[1]), dtype=BF16, device=x.device)
+    get_lib().call("bra_scatter_rows", rows32, x, _ld(x), out, _ld(out), rows32.numel(), x.shape[1], current_stream(x))
+    return out
+
+
+def transpose2d(x: torch.Tensor, pad_to: int = 8) -> torch.Tensor:
+    """x [R, C] -> [C, Rp] view [:, :R] with row pitch Rp = R rounded up to `pad_to` (zero padded)"""
+    R, C = x.shape
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    buf = torch.zeros((C, Rp), dtype=BF16, device=x.device) if Rp != R else torch.empty((C, Rp), dtype=BF16, device=x.device)
+    get_lib().call("bra_transpose2d", x, _ld(x), buf, _ld(buf), R, C, current_stream(x))
+    return buf
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    get_lib().call("bra_colsum", x, _ld(x), out, x.shape[0], x.shape[1], current_stream(x))
+    return out
+
+
+# --------------------------------------------------------------------------- GRPO / optimiser
+def sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished, pad_id, out_ids, out_logp=None):
+    B, V = logits.shape
+    get_lib().call("bra_sample", logits, _ld(logits), B, V, temperature, top_k, top_p, int(do_sample), seed & 0xFFFFFFFF,
+                   step_t, finished, pad_id, out_ids, out_logp, current_stream(logits))
+    return out_ids
+
+
+def eos_mask(ids32: torch.Tensor, eos_id: int):
+    B, C = ids32.shape
+    mask = torch.empty((B, C), dtype=torch.int32, device=ids32.device)
+    lengths = torch.empty((B,), dtype=torch.int32, device=ids32.device)
+    get_lib().call("bra_eos_mask", ids32, B, C, eos_id, mask, lengths, current_stream(ids32))
+    return mask, lengths
+
+
+def group_advantage(rewards: torch.Tensor, G: int):
+    N, F = rewards.shape
+    adv = torch.empty((N,), dtype=torch.float32, device=rewards.device)
+    gm = torch.empty((N // G,), dtype=torch.float32, device=rewards.device)
+    gs = torch.empty((N // G,), dtype=torch.float32, device=rewards.device)
+    get_lib().call("bra_group_advantage", rewards, N, F, G, adv, gm, gs, current_stream(rewards))
+    return adv, gm, gs
+
+
+def grpo_loss(logp, old_logp, ref_logp, adv, mask, eps_lo, eps_hi, beta, need_grad=True):
+    B, C = logp.shape
+    out3 = torch.empty((3,), dtype=torch.float32, device=logp.device)
+    dlogp = torch.empty_like(logp) if need_grad else None
+    get_lib().call("bra_grpo_loss", logp, old_logp, ref_logp, adv, mask, B, C, eps_lo, eps_hi, beta, out3, dlogp, current_stream(logp))
+    return out3, dlogp
+
+
+def sumsq(g: torch.Tensor, out: torch.Tensor):
+    get_lib().call("bra_sumsq", g, g.numel(), out, current_stream(g))
+
+
+def adamw(p, g, m, v, lr, b1, b2, eps, wd, step, sumsq_t=None, max_norm=0.0, grad_scale=1.0):
+    get_lib().call("bra_adamw", p, g, m, v, p.numel(), lr, b1, b2, eps, wd, step, sumsq_t, max_norm, grad_scale, current_stream(p))

@@ -1,0 +1,159 @@
+/* bioreason_hip.h — C ABI of libbioreason_hip.so (gfx950 / MI355X).
+ *
+ * The reference (bowang-lab/BioReason) has no FFI: its hot path is executed by
+ * third-party Python (HF transformers Qwen3 / ESM modelling, torch SDPA, PEFT)
+ * underneath bioreason/models/dna_llm.py and bioreason/trainer/grpo_trainer.py.
+ * This header is the boundary introduced UNDER those modules: every entry
+ * point names the reference arithmetic it replaces ("TF:" = the installed
+ * transformers package, the reference's unpinned dependency).
+ *
+ * Conventions
+ *   - plain C, POD arguments only: raw device pointers, sizes, element strides
+ *     ("ld*" = leading dimension in ELEMENTS), `stream` = a hipStream_t.
+ *   - bf16 tensors are raw 16-bit words; "f32" tensors are float.
+ *   - every function returns 0 on success, a positive hipError_t if the launch
+ *     failed, or a negative BRA_ERR_* for a rejected argument; nothing throws,
+ *     nothing allocates, nothing synchronises; workspaces come from the caller.
+ *   - all functions are re-entrant (no global mutable state).
+ */
+#ifndef BIOREASON_HIP_H
+#define BIOREASON_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRA_ERR_ARG (-1)
+#define BRA_ERR_UNSUPPORTED (-2)
+
+/* ---- GEMM family (k_gemm.hip) ------------------------------------------------
+ * C[M,N] = alpha * (A[M,K] B[N,K]^T + A2[M,K2] B2[N,K2]^T) [+ bias[N]] [+ res[M,N]]
+ * Replaces nn.Linear forward / dgrad everywhere on the path: Qwen3 q/k/v/o and MLP
+ * (TF:models/qwen3/modeling_qwen3.py:225-236, :81-83), ESM q/k/v/o/FFN
+ * (TF:models/esm/modeling_esm.py:336-338, :402, :448-466), dna_projection
+ * (bioreason/models/dna_llm.py:97,159-160), tied lm_head (TF:qwen3:495); the
+ * (A2,B2,K2) pair is PEFT-LoRA's  + (x A^T) B^T  (train_dna_qwen.py:155-167,
+ * reason.py:376-388).  K, K2 multiples of 32; ld* multiples of 8.
+ * out_f32: C is float (optionally accumulated into), else bf16.
+ * With `res`, the product is rounded to bf16 before the add, as the reference's
+ * `residual + module(x)` does (TF:qwen3:309,315). */
+int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
+                     long ldb2, int K2, void* C, long ldc, int M, int N, int K, float alpha, const void* bias,
+                     const void* res, long ldres, int out_f32, int accumulate, void* stream);
+
+/* C[M,N] (f32, pre-zeroed or holding a running gradient) += alpha * A[M,K] B[N,K]^T with the K range cut
+ * into `split_k` slices and combined by atomics: weight gradients of LoRA A/B and dna_projection, where
+ * K is the token count (autograd of PEFT's lora_A / lora_B, and of dna_llm.py:159-160). */
+int bra_gemm_bf16_nt_splitk(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                            float alpha, int split_k, void* stream);
+
+/* Fused lm_head + log-softmax statistics WITHOUT materialising logits
+ * (grpo_trainer.py:510-520 `_get_per_token_logps`; TF:loss/loss_utils.py:49-71 ForCausalLMLoss):
+ * for every row m of H[M,K] (bf16) against E[V,K]: per 64-column chunk running max and sum-exp of the
+ * bf16-rounded logits, and the logit of column tgt[m].  nchunk = ceil(V/64). */
+int bra_lmhead_lse_partials(const void* H, long ldh, const void* E, long lde, int M, int V, int K, const int* tgt,
+                            float* part_max, float* part_sum, float* tgt_logit, void* stream);
+/* merge of the partials: lse[m], logp[m] = tgt_logit[m] - lse[m] */
+int bra_lse_merge(const float* part_max, const float* part_sum, const float* tgt_logit, float* lse, float* logp,
+                  int rows, int nchunk, void* stream);
+/* backward of the above: dlogits[m,n] = coef[m] * ((n == tgt[m]) - exp(logit[m,n] - lse[m]))  (bf16) */
+int bra_lmhead_dlogits(const void* H, long ldh, const void* E, long lde, int M, int V, int K, const int* tgt,
+                       const float* lse, const float* coef, void* dlogits, long ldd, void* stream);
+
+/* ---- normalisation / activation (k_norm.hip) --------------------------------- */
+/* Qwen3RMSNorm.forward (TF:qwen3:59-64); rstd (f32 [rows]) optional */
+int bra_rmsnorm_fwd(const void* x, long ldx, const void* w, void* y, long ldy, float* rstd, int rows, int cols,
+                    float eps, void* stream);
+/* its input gradient (+ optional residual-stream gradient dres); norm weights are frozen under LoRA */
+int bra_rmsnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const void* w, const void* dres, long lddres,
+                    void* dx, long lddx, int rows, int cols, float eps, void* stream);
+/* nn.LayerNorm forward of the ESM encoder (TF:esm:418,480,529) */
+int bra_layernorm_fwd(const void* x, long ldx, const void* w, const void* b, void* y, long ldy, int rows, int cols,
+                      float eps, void* stream);
+/* SwiGLU: act = silu(gu[:, :F]) * gu[:, F:]  (Qwen3MLP TF:qwen3:81-83; NT-v2 hub EsmIntermediate) */
+int bra_swiglu_fwd(const void* gu, long ldgu, void* act, long ldact, int rows, int F, void* stream);
+int bra_swiglu_bwd(const void* gu, long ldgu, const void* dact, long lddact, void* dgu, long lddgu, int rows, int F,
+                   void* stream);
+/* per-head q_norm/k_norm (optional) + rotate-half RoPE on a fused QKV projection
+ * (Qwen3Attention.forward TF:qwen3:252-256 + apply_rotary_pos_emb :140-170;
+ *  EsmSelfAttention.forward TF:esm:366-378 with qscale = hd^-0.5 and no norm).
+ * q/k/v destinations are addressed by (batch, seq, head) element strides; K/V rows are written at
+ * sequence index s + s_off (KV-cache append). */
+int bra_qk_norm_rope_fwd(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT,
+                         const float* sinT, const int* pos, int T, int S, int Hq, int Hkv, int hd, float eps,
+                         float qscale, void* q, long q_sb, long q_ss, long q_sh, void* k, long k_sb, long k_ss,
+                         long k_sh, void* v, long v_sb, long v_ss, long v_sh, int s_off, void* stream);
+int bra_qk_norm_rope_bwd(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT,
+                         const float* sinT, const int* pos, int T, int S, int Hq, int Hkv, int hd, float eps,
+                         float qscale, const void* dq, long q_sb, long q_ss, long q_sh, const void* dk, long k_sb,
+                         long k_ss, long k_sh, const void* dv, long v_sb, long v_ss, long v_sh, void* dqkv,
+                         long lddqkv, void* stream);
+
+/* ---- attention (k_attn.hip) --------------------------------------------------
+ * softmax(scale * Q K^T + mask) V with fp32 softmax: Qwen3 causal GQA (TF:qwen3:185-207, hd 128) and the
+ * ESM bidirectional encoder (TF:esm:292-317, hd 64).  kmask[B,Sk] (bytes, 1 = attendable) is the
+ * reference's 0/1 attention_mask; causal: key j visible to query i iff j <= i + q_off.
+ * vt / kt / qt / dot are [B,H,hd,pitch] transposed images (bra_head_transpose), pitch % 64 == 0. */
+int bra_attn_fwd(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss, long k_sh,
+                 const void* vt, long vt_sb, long vt_sh, long vt_sd, void* o, long o_sb, long o_ss, long o_sh,
+                 float* lse, const void* kmask, int B, int Hq, int Hkv, int Sq, int Sk, int hd, int causal,
+                 int q_off, float scale, void* stream);
+int bra_attn_bwd(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss, long k_sh,
+                 const void* v, long v_sb, long v_ss, long v_sh, const void* dout, long do_sb, long do_ss, long do_sh,
+                 const void* kt, long kt_sb, long kt_sh, long kt_sd, const void* qt, long qt_sb, long qt_sh,
+                 long qt_sd, const void* dot, long dot_sb, long dot_sh, long dot_sd, const float* lse,
+                 const float* delta, const void* kmask, void* dq, long dq_sb, long dq_ss, long dq_sh, void* dk,
+                 long dk_sb, long dk_ss, long dk_sh, void* dv, long dv_sb, long dv_ss, long dv_sh, int B, int Hq,
+                 int Hkv, int Sq, int Sk, int hd, int causal, int q_off, float scale, void* stream);
+/* one decode step over the KV cache [B,Hkv,Smax,hd] (HF DynamicCache + sdpa, TF:generation/utils.py:2876-2925).
+ * part_o f32 [B,Hq,nchunk,hd], part_ml f32 [B,Hq,nchunk,2], nchunk = bra_attn_decode_nchunk(len). */
+int bra_attn_decode_nchunk(int len);
+int bra_attn_decode(const void* q, const void* kc, const void* vc, const void* kmask, float* part_o, float* part_ml,
+                    void* o, int B, int Hq, int Hkv, int hd, int Smax, int len, float scale, void* stream);
+
+/* ---- data movement around the kernels (k_misc.hip) ---------------------------- */
+int bra_head_transpose(const void* x, long sb, long ss, long sh, void* xt, long t_sb, long t_sh, long pitch, int B,
+                       int S, int H, int hd, void* stream);
+int bra_attn_delta(const void* dout, long do_sb, long do_ss, long do_sh, const void* o, long o_sb, long o_ss,
+                   long o_sh, float* delta, int B, int S, int H, int hd, void* stream);
+/* DNALLMModel.process_dna_embeddings regrouping + `text_inputs_embeds[mask] = dna_embeds_flat`
+ * (dna_llm.py:163-177, :216-229) as a device-side plan: tok_src[t] = projected-DNA row feeding token t or -1;
+ * counts = {#placeholder tokens, #DNA feature rows} for the reference's mismatch ValueError (:222-225). */
+int bra_dna_scatter_plan(const int* ids, int ntok, int dna_id, const void* dna_mask, int nseq, int Sd,
+                         const int* seq_order, int* tok_src, int* counts, void* stream);
+/* embed_tokens(input_ids) with the DNA rows written over the placeholders (dna_llm.py:211,229) and its backward */
+int bra_embed_scatter_fwd(const int* ids, const int* tok_src, const void* E, long lde, const void* dna, long ldd,
+                          void* out, long ldo, int ntok, int H, void* stream);
+int bra_embed_scatter_bwd(const int* tok_src, const void* dout, long ldo, void* ddna, long ldd, int ntok, int H,
+                          void* stream);
+int bra_gather_rows(const int* rows, const void* x, long ldx, void* out, long ldo, int n, int H, void* stream);
+int bra_scatter_rows(const int* rows, const void* x, long ldx, void* out, long ldo, int n, int H, void* stream);
+int bra_transpose2d(const void* in, long ldi, void* out, long ldo, int rows, int cols, void* stream);
+int bra_colsum(const void* x, long ldx, float* out, int rows, int cols, void* stream);
+/* fp32 master -> bf16 working images of the trainable parameters; descs_dev = device array of
+ * {const float* src; long src_ld; bf16* dst; long dst_ld; int rows, cols, transpose, pad;} */
+int bra_pack_desc_size(void);
+int bra_pack_params(const void* descs_dev, int ndesc, long max_elems, void* stream);
+/* AdamW over one flat arena with device-side global-norm clip (train_dna_qwen.py:393-411, :1003 clip 1.0) */
+int bra_sumsq(const float* g, long n, float* out, void* stream);
+int bra_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+              float wd, int step, const float* sumsq, float max_norm, float grad_scale, void* stream);
+
+/* ---- GRPO arithmetic (k_grpo.hip) --------------------------------------------- */
+/* temperature -> top-k -> top-p -> multinomial, or argmax when do_sample == 0
+ * (TF:generation/logits_process.py:238,473,542; TF:generation/utils.py:2897-2925; grpo_trainer.py:384-391) */
+int bra_sample(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p,
+               int do_sample, unsigned seed, const int* step_ptr, const void* finished, int pad_id, int* out_ids,
+               float* out_logp, void* stream);
+/* completion mask up to and including the first EOS (grpo_trainer.py:605-609) */
+int bra_eos_mask(const int* ids, int B, int C, int eos_id, int* mask, int* lengths, void* stream);
+/* rewards [N,F] -> sum over F -> (r - mean_group) / (std_group + 1e-4), groups of G (grpo_trainer.py:682-691) */
+int bra_group_advantage(const float* rewards, int N, int F, int G, float* adv, float* grp_mean, float* grp_std,
+                        void* stream);
+/* compute_loss (grpo_trainer.py:786-814): out3 = {loss, mean_kl, clip_ratio}; dlogp = dloss/dlogp */
+int bra_grpo_loss(const float* logp, const float* old_logp, const float* ref_logp, const float* adv, const int* mask,
+                  int B, int C, float eps_lo, float eps_hi, float beta, float* out3, float* dlogp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIOREASON_HIP_H */

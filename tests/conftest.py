@@ -1,0 +1,58 @@
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libbioreason_emu.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _build_emu():
+    subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "bioreason_amd", "csrc"), "emu"], check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+@pytest.fixture(scope="session")
+def emu_lib_path():
+    """The kernel-source emulator (tests/emu): same .hip sources, host fibers. Test infrastructure only."""
+    _build_emu()
+    return EMU_LIB
+
+
+@pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request, emu_lib_path):
+    """Runs a kernel test twice: on the CPU emulator (CI without GPU) and on the real HIP library (-m gpu)."""
+    from bioreason_amd import _lib
+    if request.param == "emu":
+        _lib.use_library_for_tests(emu_lib_path)
+        yield torch.device("cpu")
+        _lib.reset_library()
+    else:
+        if not torch.cuda.is_available():
+            pytest.skip("no GPU")
+        _lib.reset_library()
+        lib = _lib.get_lib()          # raises if libbioreason_hip.so is missing
+        assert not lib.emulated
+        yield torch.device("cuda:0")
+        torch.cuda.synchronize()
+
+
+@pytest.fixture
+def hip_device():
+    """Real-GPU-only tests."""
+    from bioreason_amd import _lib
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _lib.reset_library()
+    _lib.get_lib()
+    yield torch.device("cuda:0")
+    torch.cuda.synchronize()
