@@ -17,8 +17,12 @@ def pytest_configure(config):
 
 
 def _build_emu():
-    subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "bioreason_amd", "csrc"), "emu"], check=True,
-                   stdout=subprocess.DEVNULL)
+    import fcntl
+    os.makedirs(os.path.join(ROOT, "tests", "emu", "build"), exist_ok=True)
+    with open(os.path.join(ROOT, "tests", "emu", "build", ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)      # xdist workers build once, the others wait
+        subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "bioreason_amd", "csrc"), "emu"], check=True,
+                       stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")

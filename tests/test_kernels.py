@@ -1,0 +1,416 @@
+"""Kernel-level parity: every C-ABI entry point against a plain PyTorch fp32 statement of the same op.
+
+Each test runs on the CPU kernel-source emulator (`backend == cpu`, part of `-m "not gpu"`) and on the real
+gfx950 library (`-m gpu`).  Inputs are bf16; tolerances are those of one bf16 rounding of the output
+(rel Frobenius <= 4e-3) unless the op is exact.
+"""
+import math
+
+import pytest
+import torch
+
+from bioreason_amd import ops
+
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def rnd(*shape, dev, scale=1.0, seed=None):
+    g = torch.Generator().manual_seed(seed if seed is not None else sum(shape) + len(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(dev)
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,K2", [(128, 128, 64, 0), (200, 96, 128, 64), (130, 260, 32, 32), (1, 8, 64, 0), (257, 136, 192, 0)])
+def test_gemm_nt(backend, M, N, K, K2):
+    a, b = rnd(M, K, dev=backend), rnd(N, K, dev=backend)
+    a2 = rnd(M, K2, dev=backend) if K2 else None
+    b2 = rnd(N, K2, dev=backend) if K2 else None
+    bias, res = rnd(N, dev=backend), rnd(M, N, dev=backend)
+    ref = a.float() @ b.float().T + (a2.float() @ b2.float().T if K2 else 0)
+    c = ops.gemm_nt(a, b, a2=a2, b2=b2, bias=bias, res=res, alpha=0.5)
+    want = (0.5 * ref + bias.float()).to(BF).float() + res.float()
+    assert rel(c, want) < 4e-3
+    c32 = ops.gemm_nt(a, b, a2=a2, b2=b2, out_f32=True)
+    assert rel(c32, ref) < 1e-5
+    acc = torch.ones(M, N, device=backend)
+    ops.gemm_nt(a, b, a2=a2, b2=b2, out=acc, out_f32=True, accumulate=True)
+    assert rel(acc, ref + 1) < 1e-5
+    sk = torch.zeros(M, N, device=backend)
+    ops.gemm_nt_splitk(a, b, sk, alpha=2.0, split_k=3)
+    assert rel(sk, 2 * (a.float() @ b.float().T)) < 1e-5
+
+
+def test_gemm_transpose_detect(backend):
+    """A = I-like with asymmetric B: catches a C written transposed (guide §3)."""
+    M = N = 128
+    K = 128
+    a = torch.eye(M, K).to(BF).to(backend)
+    b = (torch.arange(N * K).reshape(N, K) % 37).float().to(BF).to(backend)
+    c = ops.gemm_nt(a, b, out_f32=True)
+    assert torch.equal(c.cpu(), b.float().T.cpu()[:M, :N].contiguous())
+
+
+def test_gemm_strided_slices(backend):
+    M, K, N = 96, 64, 64
+    big_a = rnd(M, 3 * K, dev=backend)
+    big_c = torch.zeros(M, 4 * N, dtype=BF, device=backend)
+    b = rnd(N, K, dev=backend)
+    a_slice = big_a[:, K:2 * K]
+    c_slice = big_c[:, 2 * N:3 * N]
+    ops.gemm_nt(a_slice, b, out=c_slice)
+    assert rel(c_slice, a_slice.float() @ b.float().T) < 4e-3
+    assert big_c[:, :2 * N].abs().sum() == 0 and big_c[:, 3 * N:].abs().sum() == 0
+
+
+@pytest.mark.parametrize("M,V,K", [(70, 300, 64), (130, 1000, 128)])
+def test_lmhead_logprob_and_dlogits(backend, M, V, K):
+    h, e = rnd(M, K, dev=backend, scale=0.5), rnd(V, K, dev=backend, scale=0.5)
+    tgt = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(1)).to(torch.int32).to(backend)
+    logp, lse = ops.lmhead_logprob(h, e, tgt)
+    logits = (h.float() @ e.float().T).to(BF).float()          # the reference's lm_head output is bf16
+    ref_lse = torch.logsumexp(logits, -1)
+    ref_lp = logits.gather(1, tgt.long()[:, None])[:, 0] - ref_lse
+    assert (lse.cpu() - ref_lse.cpu()).abs().max() < 2e-3
+    assert (logp.cpu() - ref_lp.cpu()).abs().max() < 2e-3
+    coef = torch.randn(M, generator=torch.Generator().manual_seed(2)).to(backend)
+    dl = ops.lmhead_dlogits(h, e, tgt, lse, coef)
+    onehot = torch.zeros(M, V, device=backend).scatter_(1, tgt.long()[:, None], 1.0)
+    want = coef[:, None] * (onehot - torch.softmax(logits, -1))
+    assert rel(dl, want) < 6e-3
+
+
+# ----------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,cols", [(5, 64), (9, 2048), (4, 520)])
+def test_rmsnorm_fwd_bwd(backend, rows, cols):
+    x, w = rnd(rows, cols, dev=backend), (1 + 0.1 * rnd(cols, dev=backend).float()).to(BF)
+    eps = 1e-6
+    y = ops.rmsnorm_fwd(x, w, eps)
+    xf = x.float().requires_grad_(True)
+    normed = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    ref = w.float() * normed
+    assert rel(y, w.float() * normed.detach().to(BF).float()) < 4e-3
+    dy, dres = rnd(rows, cols, dev=backend, seed=5), rnd(rows, cols, dev=backend, seed=6)
+    ref.backward(dy.float())
+    dx = ops.rmsnorm_bwd(dy, x, w, eps, dres=dres)
+    assert rel(dx, xf.grad + dres.float()) < 4e-3
+    dx2 = ops.rmsnorm_bwd(dy, x, w, eps)
+    assert rel(dx2, xf.grad) < 4e-3
+
+
+def test_layernorm_fwd(backend):
+    x, w, b = rnd(7, 1024, dev=backend), rnd(1024, dev=backend), rnd(1024, dev=backend)
+    y = ops.layernorm_fwd(x, w, b, 1e-12)
+    ref = torch.nn.functional.layer_norm(x.float(), (1024,), w.float(), b.float(), 1e-12)
+    assert rel(y, ref) < 4e-3
+
+
+def test_swiglu_fwd_bwd(backend):
+    rows, F = 9, 136
+    gu = rnd(rows, 2 * F, dev=backend)
+    act = ops.swiglu_fwd(gu)
+    guf = gu.float().requires_grad_(True)
+    ref = torch.nn.functional.silu(guf[:, :F]) * guf[:, F:]
+    assert rel(act, ref) < 5e-3
+    dact = rnd(rows, F, dev=backend, seed=3)
+    ref.backward(dact.float())
+    dgu = ops.swiglu_bwd(gu, dact)
+    assert rel(dgu, guf.grad) < 5e-3
+
+
+def _rope_tables(npos, hd, theta, dev):
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = torch.arange(npos, dtype=torch.float32)[:, None] * inv[None, :]
+    return fr.cos().contiguous().to(dev), fr.sin().contiguous().to(dev)
+
+
+def _rope_ref(x, cos, sin, pos):
+    # x [B,S,H,hd] float; rotate-half
+    half = x.shape[-1] // 2
+    c = torch.cat([cos[pos], cos[pos]], -1)[:, :, None, :]
+    s = torch.cat([sin[pos], sin[pos]], -1)[:, :, None, :]
+    rot = torch.cat([-x[..., half:], x[..., :half]], -1)
+    return x * c + rot * s
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,norm,qscale", [(128, 4, 2, True, 1.0), (64, 2, 2, False, 64 ** -0.5), (32, 4, 1, True, 1.0)])
+def test_qk_norm_rope_fwd_bwd(backend, hd, Hq, Hkv, norm, qscale):
+    B, S = 2, 9
+    T = B * S
+    eps = 1e-6
+    qkv = rnd(T, (Hq + 2 * Hkv) * hd, dev=backend)
+    qw = (1 + 0.1 * rnd(hd, dev=backend).float()).to(BF) if norm else None
+    kw = (1 + 0.1 * rnd(hd, dev=backend, seed=9).float()).to(BF) if norm else None
+    cos, sin = _rope_tables(64, hd, 10000.0, backend)
+    pos = (torch.arange(S).repeat(B) + 3).to(torch.int32).to(backend)
+    q = torch.empty(B, S, Hq, hd, dtype=BF, device=backend)
+    kc = torch.zeros(B, Hkv, S + 5, hd, dtype=BF, device=backend)     # cache layout, append at offset 5
+    vc = torch.zeros(B, Hkv, S + 5, hd, dtype=BF, device=backend)
+    ops.qk_norm_rope_fwd(qkv, qw, kw, cos, sin, pos, S, Hq, Hkv, hd, eps, qscale, q, kc.permute(0, 2, 1, 3), vc.permute(0, 2, 1, 3), s_off=5)
+
+    def ref_fn(x):
+        x = x.view(B, S, Hq + 2 * Hkv, hd)
+        qq, kk, vv = x[:, :, :Hq], x[:, :, Hq:Hq + Hkv], x[:, :, Hq + Hkv:]
+        if norm:
+            qq = qw.float() * (qq * torch.rsqrt(qq.pow(2).mean(-1, keepdim=True) + eps))
+            kk = kw.float() * (kk * torch.rsqrt(kk.pow(2).mean(-1, keepdim=True) + eps))
+        qq = qq * qscale
+        p = pos.long().view(B, S)
+        return _rope_ref(qq, cos, sin, p), _rope_ref(kk, cos, sin, p), vv
+
+    xf = qkv.float().requires_grad_(True)
+    rq, rk, rv = ref_fn(xf)
+    assert rel(q, rq) < 6e-3
+    assert rel(kc[:, :, 5:].permute(0, 2, 1, 3), rk) < 6e-3
+    assert torch.equal(vc[:, :, 5:].permute(0, 2, 1, 3).float().cpu(), rv.detach().cpu())
+    assert kc[:, :, :5].abs().sum() == 0
+    dq, dk, dv = rnd(B, S, Hq, hd, dev=backend, seed=1), rnd(B, S, Hkv, hd, dev=backend, seed=2), rnd(B, S, Hkv, hd, dev=backend, seed=3)
+    (rq * dq.float()).sum().backward(retain_graph=True)
+    (rk * dk.float()).sum().backward(retain_graph=True)
+    (rv * dv.float()).sum().backward()
+    dqkv = ops.qk_norm_rope_bwd(qkv, qw, kw, cos, sin, pos, S, Hq, Hkv, hd, eps, qscale, dq, dk, dv)
+    assert rel(dqkv, xf.grad) < 6e-3
+
+
+# ----------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, kmask, causal, scale, q_off):
+    # q [B,Sq,Hq,hd], k/v [B,Sk,Hkv,hd] float -> o [B,Sq,Hq,hd], lse [B,Hq,Sq]
+    B, Sq, Hq, hd = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    g = Hq // Hkv
+    kk = k.repeat_interleave(g, dim=2)
+    vv = v.repeat_interleave(g, dim=2)
+    s = torch.einsum("bqhd,bkhd->bhqk", q, kk) * scale
+    ok = torch.ones(B, 1, Sq, Sk, dtype=torch.bool, device=q.device)
+    if kmask is not None:
+        ok = ok & (kmask.bool()[:, None, None, :])
+    if causal:
+        i = torch.arange(Sq, device=q.device)[:, None]
+        j = torch.arange(Sk, device=q.device)[None, :]
+        ok = ok & (j <= i + q_off)[None, None]
+    s = s.masked_fill(~ok, float("-inf"))
+    lse = torch.logsumexp(s, -1)
+    p = torch.exp(s - lse[..., None])
+    p = torch.nan_to_num(p, nan=0.0)
+    o = torch.einsum("bhqk,bkhd->bqhd", p, vv)
+    return o, lse
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,Sq,Sk,causal,pad", [
+    (128, 4, 2, 150, 150, True, "left"),
+    (64, 2, 2, 100, 100, False, "right"),
+    (32, 2, 1, 70, 70, True, None),
+    (128, 2, 1, 40, 200, True, "left"),      # chunked prefill against a longer key range
+])
+def test_attn_fwd_bwd(backend, hd, Hq, Hkv, Sq, Sk, causal, pad):
+    B = 2
+    q, k, v = rnd(B, Sq, Hq, hd, dev=backend, seed=1), rnd(B, Sk, Hkv, hd, dev=backend, seed=2), rnd(B, Sk, Hkv, hd, dev=backend, seed=3)
+    kmask = torch.ones(B, Sk, dtype=torch.uint8, device=backend)
+    if pad == "left":
+        kmask[0, :7] = 0
+    elif pad == "right":
+        kmask[1, Sk - 13:] = 0
+    scale = hd ** -0.5
+    q_off = Sk - Sq
+    vt = ops.head_transpose(v)
+    assert torch.equal(vt[..., :Sk].cpu(), v.permute(0, 2, 3, 1).cpu()) and vt[..., Sk:].abs().sum() == 0
+    o, lse = ops.attn_fwd(q, k, vt, kmask if pad else None, causal, scale)
+    qf, kf, vf = q.float().requires_grad_(True), k.float().requires_grad_(True), v.float().requires_grad_(True)
+    ro, rlse = _attn_ref(qf, kf, vf, kmask if pad else None, causal, scale, q_off)
+    # rows with no visible key are unspecified in the reference (pad queries); compare the others
+    valid_q = torch.isfinite(rlse)                        # [B,Hq,Sq]
+    vq = valid_q.permute(0, 2, 1)[..., None].cpu()
+    assert rel(o.cpu() * vq, ro.detach().cpu() * vq) < 6e-3
+    assert ((lse.cpu() - rlse.detach().cpu()).abs() * valid_q.cpu()).nan_to_num(0).max() < 2e-2
+    dout = rnd(B, Sq, Hq, hd, dev=backend, seed=4) * vq.to(backend).to(BF)
+    (ro.nan_to_num(0) * dout.float()).sum().backward()
+    dq, dk, dv = ops.attn_bwd(q, k, v, o, dout, lse, kmask if pad else None, causal, scale)
+    assert rel(dq.cpu() * vq, qf.grad.cpu() * vq) < 1.5e-2
+    assert rel(dk, kf.grad) < 1.5e-2
+    assert rel(dv, vf.grad) < 1.5e-2
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,L", [(128, 4, 2, 300), (64, 2, 2, 129), (32, 4, 1, 64)])
+def test_attn_decode(backend, hd, Hq, Hkv, L):
+    B, Smax = 3, 320
+    q = rnd(B, Hq, hd, dev=backend, seed=1)
+    kc, vc = rnd(B, Hkv, Smax, hd, dev=backend, seed=2), rnd(B, Hkv, Smax, hd, dev=backend, seed=3)
+    kmask = torch.ones(B, Smax, dtype=torch.uint8, device=backend)
+    kmask[1, :11] = 0
+    o = ops.attn_decode(q, kc, vc, kmask, L, hd ** -0.5)
+    ro, _ = _attn_ref(q.float()[:, None], kc[:, :, :L].permute(0, 2, 1, 3).float(), vc[:, :, :L].permute(0, 2, 1, 3).float(),
+                      kmask[:, :L], False, hd ** -0.5, 0)
+    assert rel(o.view(B, Hq, hd), ro[:, 0]) < 6e-3
+
+
+# ----------------------------------------------------------------------------- scatter / movement
+def test_dna_scatter_plan_and_embed(backend):
+    B, P, H, V = 3, 50, 64, 97
+    nseq, Sd = 5, 12
+    dna_id = 90
+    g = torch.Generator().manual_seed(0)
+    batch_idx_map = [0, 0, 1, 2, 2]
+    dmask = torch.ones(nseq, Sd, dtype=torch.uint8)
+    dmask[1, 7:] = 0
+    dmask[3, 10:] = 0
+    valid = dmask.sum(1).tolist()
+    per_sample = [sum(valid[i] for i in range(nseq) if batch_idx_map[i] == b) for b in range(B)]
+    ids = torch.randint(0, 89, (B, P), generator=g)
+    for b in range(B):
+        start = 3 + b
+        ids[b, start:start + per_sample[b]] = dna_id
+    order = sorted(range(nseq), key=lambda i: batch_idx_map[i])
+    ids32 = ids.to(torch.int32).to(backend)
+    tok_src = torch.empty(B * P, dtype=torch.int32, device=backend)
+    counts = torch.zeros(2, dtype=torch.int32, device=backend)
+    ops.dna_scatter_plan(ids32.view(-1), dna_id, dmask.to(backend), torch.tensor(order, dtype=torch.int32, device=backend), tok_src, counts)
+    assert counts.tolist() == [sum(per_sample), sum(valid)]
+    emb = rnd(V, H, dev=backend, seed=1)
+    proj = rnd(nseq * Sd, H, dev=backend, seed=2)
+    out = torch.empty(B * P, H, dtype=BF, device=backend)
+    ops.embed_scatter_fwd(ids32.view(-1), tok_src, emb, proj, out)
+    # reference: dna_llm.py:163-177 + :216-229
+    ref = emb.float()[ids.view(-1).to(backend).long()].clone()
+    result = [[] for _ in range(B)]
+    pv = proj.float().view(nseq, Sd, H)
+    for si, bi in enumerate(batch_idx_map):
+        result[bi].append(pv[si, :valid[si]])
+    flat = torch.cat([torch.cat(r, 0) for r in result], 0)
+    ref[(ids.view(-1) == dna_id).to(backend)] = flat
+    assert torch.equal(out.float().cpu(), ref.cpu())
+    dout = rnd(B * P, H, dev=backend, seed=3)
+    ddna = torch.zeros(nseq * Sd, H, dtype=BF, device=backend)
+    ops.embed_scatter_bwd(tok_src, dout, ddna)
+    want = torch.zeros(nseq * Sd, H)
+    src = tok_src.cpu().long()
+    want[src[src >= 0]] = dout.float().cpu()[src >= 0]
+    assert torch.equal(ddna.float().cpu(), want)
+
+
+def test_dna_scatter_mismatch_counts(backend):
+    ids32 = torch.tensor([5, 9, 9, 9, 1], dtype=torch.int32, device=backend)
+    dmask = torch.ones(1, 2, dtype=torch.uint8, device=backend)
+    tok_src = torch.empty(5, dtype=torch.int32, device=backend)
+    counts = torch.zeros(2, dtype=torch.int32, device=backend)
+    ops.dna_scatter_plan(ids32, 9, dmask, torch.zeros(1, dtype=torch.int32, device=backend), tok_src, counts)
+    assert counts.tolist() == [3, 2]      # caller raises ValueError as dna_llm.py:222-225 does
+
+
+def test_transpose_gather_colsum(backend):
+    x = rnd(70, 104, dev=backend)[:, :100]       # 100 used columns, row pitch 104
+    xt = ops.transpose2d(x)
+    assert xt.shape == (100, 72)
+    assert torch.equal(xt[:, :70].cpu(), x.T.cpu()) and xt[:, 70:].abs().sum() == 0
+    rows = torch.tensor([3, 0, 69, 5], dtype=torch.int32, device=backend)
+    x2 = rnd(70, 64, dev=backend)
+    assert torch.equal(ops.gather_rows(rows, x2).cpu(), x2[rows.long()].cpu())
+    sc = ops.scatter_rows(rows, x2[:4].contiguous(), 70)
+    assert torch.equal(sc[rows.long()].cpu(), x2[:4].cpu()) and sc.float().abs().sum() == x2[:4].float().abs().sum()
+    cs = torch.ones(100, device=backend)
+    ops.colsum(x, cs)
+    assert rel(cs, x.float().sum(0) + 1) < 1e-5
+
+
+# ----------------------------------------------------------------------------- GRPO math / optimiser
+def test_eos_mask_and_advantage(backend):
+    ids = torch.tensor([[4, 5, 2, 7, 2], [1, 1, 1, 1, 1], [2, 0, 0, 0, 0]], dtype=torch.int32, device=backend)
+    mask, lengths = ops.eos_mask(ids, 2)
+    assert mask.tolist() == [[1, 1, 1, 0, 0], [1, 1, 1, 1, 1], [1, 0, 0, 0, 0]]
+    assert lengths.tolist() == [3, 5, 1]
+    r = torch.tensor([[1.0, 0.5], [0.0, 0.0], [2.0, 0.5], [0.5, 0.5], [1.0, 1.0], [1.0, 1.0], [1.0, 1.0], [1.0, 1.0]], device=backend)
+    adv, gm, gs = ops.group_advantage(r, 4)
+    tot = r.sum(1).view(-1, 4)
+    want = ((tot - tot.mean(1, keepdim=True)) / (tot.std(1, keepdim=True) + 1e-4)).view(-1)
+    assert torch.allclose(adv.cpu(), want.cpu(), atol=1e-5)
+
+
+@pytest.mark.parametrize("use_old,beta", [(False, 0.04), (True, 0.04), (True, 0.0)])
+def test_grpo_loss(backend, use_old, beta):
+    B, C = 4, 37
+    g = torch.Generator().manual_seed(0)
+    lp = (-torch.rand(B, C, generator=g) * 3).to(backend)
+    old = (lp + 0.3 * torch.randn(B, C, generator=g).to(backend)) if use_old else None
+    ref = lp + 0.2 * torch.randn(B, C, generator=g).to(backend)
+    adv = torch.randn(B, generator=g).to(backend)
+    mask = (torch.rand(B, C, generator=g) > 0.3).to(torch.int32).to(backend)
+    mask[:, 0] = 1
+    out3, dlogp = ops.grpo_loss(lp, old, ref if beta else None, adv, mask, 0.2, 0.2, beta)
+    # grpo_trainer.py:786-814 restated
+    lpt = lp.clone().requires_grad_(True)
+    o = old if use_old else lpt.detach()
+    c1 = torch.exp(lpt - o)
+    c2 = torch.clamp(c1, 0.8, 1.2)
+    l1, l2 = c1 * adv[:, None], c2 * adv[:, None]
+    ptl = -torch.min(l1, l2)
+    if beta:
+        kl = torch.exp(ref - lpt) - (ref - lpt) - 1
+        ptl = ptl + beta * kl
+    m = mask.float()
+    loss = ((ptl * m).sum(1) / m.sum(1)).mean()
+    loss.backward()
+    assert abs(out3[0].item() - loss.item()) < 1e-5
+    assert torch.allclose(dlogp.cpu(), lpt.grad.cpu(), atol=1e-6)
+    if beta:
+        assert abs(out3[1].item() - ((kl * m).sum(1) / m.sum(1)).mean().item()) < 1e-5
+    assert abs(out3[2].item() - (((l1 < l2).float() * m).sum() / m.sum()).item()) < 1e-6
+
+
+def test_adamw_with_clip(backend):
+    n = 1000
+    g0 = torch.Generator().manual_seed(0)
+    p = torch.randn(n, generator=g0).to(backend)
+    grads = [torch.randn(n, generator=g0).to(backend) * 3 for _ in range(3)]
+    ref_p = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    m, v = torch.zeros(n, device=backend), torch.zeros(n, device=backend)
+    for step, g in enumerate(grads, 1):
+        ref_p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        ss = torch.zeros(1, device=backend)
+        ops.sumsq(g, ss)
+        ops.adamw(p, g, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.01, step, sumsq_t=ss, max_norm=1.0)
+    assert torch.allclose(p.cpu(), ref_p.detach().cpu(), atol=2e-6)
+
+
+def test_sampler_greedy_and_topk(backend):
+    B, V = 3, 5000
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(B, V, generator=g).to(backend)
+    logits[1, 77] = logits[1].max() + 1      # unique max
+    logits[2, 10] = logits[2, 4000] = logits[2].max() + 2   # tie -> first index (torch.argmax)
+    out = torch.empty(B, dtype=torch.int32, device=backend)
+    ops.sample(logits, 1.0, 0, 1.0, False, 0, None, None, 0, out)
+    assert out.tolist() == logits.argmax(-1).tolist()
+    assert out[2].item() == 10
+    # sampling: draws must come from the top-k / top-p support with plausible frequencies
+    step = torch.zeros(1, dtype=torch.int32, device=backend)
+    T, k, p = 0.6, 20, 0.95
+    draws = []
+    for s in range(200):
+        step.fill_(s)
+        ops.sample(logits, T, k, p, True, 1234, step, None, 0, out)
+        draws.append(out.clone().cpu())
+    draws = torch.stack(draws)                      # [200, B]
+    sc = logits.cpu() / T
+    topv, topi = sc.topk(k, -1)
+    pr = torch.softmax(topv, -1)
+    # HF top-p on the ascending list
+    asc = torch.flip(pr, [-1])
+    remove = torch.flip(asc.cumsum(-1) <= (1 - p), [-1])
+    remove[:, 0] = False
+    pr = pr.masked_fill(remove, 0)
+    pr = pr / pr.sum(-1, keepdim=True)
+    for b in range(B):
+        support = set(topi[b][pr[b] > 0].tolist())
+        assert set(draws[:, b].tolist()) <= support
+        top_tok = topi[b, 0].item()
+        freq = (draws[:, b] == top_tok).float().mean().item()
+        assert abs(freq - pr[b, 0].item()) < 0.15
+    fin = torch.tensor([0, 1, 0], dtype=torch.uint8, device=backend)
+    ops.sample(logits, T, k, p, True, 1, step, fin, 42, out)
+    assert out[1].item() == 42
