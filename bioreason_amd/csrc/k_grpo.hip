@@ -26,8 +26,9 @@ __device__ __forceinline__ float uniform01(uint32_t seed, uint32_t step, uint32_
 template <int NT>
 __global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ldl, int V, float temperature,
                                                     int top_k, float top_p, int do_sample, uint32_t seed,
-                                                    const int* step_ptr, const uint8_t* finished, int pad_id,
-                                                    int* out_ids, float* out_logp) {
+                                                    const int* step_ptr, uint8_t* finished, int pad_id,
+                                                    int eos_id, int* out_ids, float* out_logp, int* tokens_out,
+                                                    long ldt) {
     __shared__ float s_val[NT / 64];
     __shared__ int s_idx[NT / 64];
     __shared__ float top_v[64];
@@ -94,6 +95,8 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ld
         if (finished && finished[row]) choice = pad_id;   // HF: finished sequences emit pad_token_id
         out_ids[row] = choice;
         if (out_logp) out_logp[row] = lp;
+        if (tokens_out) tokens_out[(long)row * ldt + (step_ptr ? step_ptr[0] : 0)] = choice;
+        if (finished && eos_id >= 0 && choice == eos_id) finished[row] = 1;   // unfinished &= (token != eos)
     }
 }
 
@@ -184,12 +187,12 @@ __global__ __launch_bounds__(256) void grpo_loss_kernel(const float* logp, const
 using namespace bra;
 
 extern "C" int bra_sample(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p,
-                          int do_sample, unsigned seed, const int* step_ptr, const void* finished, int pad_id,
-                          int* out_ids, float* out_logp, void* stream) {
+                          int do_sample, unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id,
+                          int* out_ids, float* out_logp, int* tokens_out, long ldt, void* stream) {
     if (B == 0) return 0;
     if (!logits || !out_ids || V <= 0 || (do_sample && temperature <= 0.f)) return BRA_ERR_ARG;
     BRA_LAUNCH((sample_kernel<1024>), dim3(B), dim3(1024), 0, stream, logits, ldl, V, temperature, top_k, top_p,
-               do_sample, (uint32_t)seed, step_ptr, (const uint8_t*)finished, pad_id, out_ids, out_logp);
+               do_sample, (uint32_t)seed, step_ptr, (uint8_t*)finished, pad_id, eos_id, out_ids, out_logp, tokens_out, ldt);
     return BRA_LAUNCH_STATUS();
 }
 

@@ -268,18 +268,31 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(const float* part_max, c
     }
 }
 
+// out[0] = scale * sum(x[0..n)) — the mean reduction of the cross-entropy / per-token losses
+__global__ __launch_bounds__(256) void vec_sum_kernel(const float* x, long n, float scale, float* out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) acc += x[i];
+    acc = block_sum<4>(acc, red);
+    if (threadIdx.x == 0) out[0] = acc * scale;
+}
+
 // ---------------------------------------------------------------------------
 // AdamW over one flat fp32 arena (train_dna_qwen.py:393-411; ds_config_stage2.json:5-21), with the
 // global-norm clip (max_grad_norm) read from a device scalar so no host sync is needed.
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* out) {
+// `mask` (bytes, optional): 0 marks structural zeros of the packed LoRA layout (off-diagonal blocks of a fused
+// B matrix, padding rows) — excluded from the norm and never updated.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, const uint8_t* mask, long n, float* out) {
     float acc = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += g[i] * g[i];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        if (!mask || mask[i]) acc += g[i] * g[i];
     acc = wave_sum<64>(acc);
     if (lane_id() == 0) atomicAdd(out, acc);
 }
-__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long n, float lr,
-                                                    float b1, float b2, float eps, float wd, float bc1, float bc2,
-                                                    const float* sumsq, float max_norm, float grad_scale) {
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v,
+                                                    const uint8_t* mask, long n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2, const float* sumsq,
+                                                    float max_norm, float grad_scale) {
     float clip = grad_scale;
     if (sumsq && max_norm > 0.f) {
         const float nrm = sqrtf(sumsq[0]) * grad_scale;
@@ -287,6 +300,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
         if (c < 1.f) clip *= c;
     }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        if (mask && !mask[i]) continue;
         const float gi = g[i] * clip;
         float pi = p[i];
         pi *= (1.f - lr * wd);
@@ -412,20 +426,26 @@ extern "C" int bra_lse_merge(const float* part_max, const float* part_sum, const
     return BRA_LAUNCH_STATUS();
 }
 
-extern "C" int bra_sumsq(const float* g, long n, float* out, void* stream) {
-    if (n == 0) return 0;
-    if (!g || !out) return BRA_ERR_ARG;
-    BRA_LAUNCH(sumsq_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, g, n, out);
+extern "C" int bra_vec_sum(const float* x, long n, float scale, float* out, void* stream) {
+    if (!x || !out || n <= 0) return BRA_ERR_ARG;
+    BRA_LAUNCH(vec_sum_kernel, dim3(1), dim3(256), 0, stream, x, n, scale, out);
     return BRA_LAUNCH_STATUS();
 }
 
-extern "C" int bra_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
-                         float eps, float wd, int step, const float* sumsq, float max_norm, float grad_scale,
-                         void* stream) {
+extern "C" int bra_sumsq(const float* g, const void* mask, long n, float* out, void* stream) {
+    if (n == 0) return 0;
+    if (!g || !out) return BRA_ERR_ARG;
+    BRA_LAUNCH(sumsq_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, g, (const uint8_t*)mask, n, out);
+    return BRA_LAUNCH_STATUS();
+}
+
+extern "C" int bra_adamw(float* p, const float* g, float* m, float* v, const void* mask, long n, float lr, float b1,
+                         float b2, float eps, float wd, int step, const float* sumsq, float max_norm,
+                         float grad_scale, void* stream) {
     if (n == 0) return 0;
     if (!p || !g || !m || !v || step < 1) return BRA_ERR_ARG;
     const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
-    BRA_LAUNCH(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2,
+    BRA_LAUNCH(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, p, g, m, v, (const uint8_t*)mask, n, lr, b1, b2, eps, wd, bc1, bc2,
                sumsq, max_norm, grad_scale);
     return BRA_LAUNCH_STATUS();
 }

@@ -1,0 +1,252 @@
+"""DNALLMModel — drop-in for bioreason.models.dna_llm.DNALLMModel on MI355X.
+
+Same constructor signature, attributes and methods as the reference class (bioreason/models/dna_llm.py:18-306):
+`process_dna_embeddings`, `forward`, `generate`, `.text_model`, `.dna_model`, `.dna_projection`, `.dna_token_id`,
+`.max_length_dna/.max_length_text`, `.text_config/.dna_config`, `.text_hidden_size/.dna_hidden_size`, plus what
+the HF Trainer-based GRPO trainer needs and the reference class lacks: `.config`,
+`.warnings_issued`, `gradient_checkpointing_enable`, `enable_input_require_grads`, and the `debug` kwarg that
+reason.py:418 passes.  Underneath, every tensor operation is a HIP kernel.
+
+Differences that are deliberate and result-preserving:
+  * the per-sequence `.item()` syncs of dna_llm.py:168,218 are replaced by one device-side scatter plan; the
+    reference's feature/placeholder-count ValueError (dna_llm.py:222-225) is kept (one 8-byte read-back);
+  * the encoder's unused MLM head is not evaluated (the reference discards it);
+  * `dna_alias` (optional) lets a caller that knows sequences repeat (GRPO's G copies of a prompt) run the frozen
+    encoder once per unique sequence — identical outputs, since the encoder is deterministic and under no_grad.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Any, Dict, List, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from . import generation, ops
+from .arena import TrainableArena
+from .engine import BF16
+from .modeling import NTEncoderForMaskedLM, Qwen3ForCausalLM
+
+
+class ProjectionLinear(nn.Module):
+    """nn.Linear(dna_hidden, text_hidden) (dna_llm.py:97) whose fp32 weight/bias live in the TrainableArena."""
+
+    def __init__(self, in_features: int, out_features: int, arena: TrainableArena):
+        super().__init__()
+        self.in_features, self.out_features, self.arena = in_features, out_features, arena
+        arena.add("dna_projection.weight", out_features, in_features)
+        arena.add("dna_projection.bias", 1, out_features)
+        arena.on_rebind(self._bind)
+        self.w_bf = self.b_bf = None
+
+    def _bind(self):
+        a = self.arena
+        w, b = a.param("dna_projection.weight"), a.param("dna_projection.bias").view(-1)
+        if "weight" in self._parameters:
+            self.weight.data, self.bias.data = w, b
+        else:
+            self.weight, self.bias = nn.Parameter(w), nn.Parameter(b)
+        self.weight.grad, self.bias.grad = a.grad("dna_projection.weight"), a.grad("dna_projection.bias").view(-1)
+        a.mask_view("dna_projection.weight").fill_(1)
+        a.mask_view("dna_projection.bias").fill_(1)
+        dev = a.device
+        if self.w_bf is None or self.w_bf.device != dev:
+            self.w_bf = torch.zeros((self.out_features, self.in_features), dtype=BF16, device=dev)
+            self.b_bf = torch.zeros((1, self.out_features), dtype=BF16, device=dev)
+        a.register_pack(a.param("dna_projection.weight"), self.w_bf, False)
+        a.register_pack(a.param("dna_projection.bias"), self.b_bf, False)
+
+    @torch.no_grad()
+    def reset_parameters(self, seed: int = 0):
+        g = torch.Generator().manual_seed(seed)
+        bound = 1.0 / self.in_features ** 0.5          # nn.Linear default init range
+        self.weight.data.copy_(((torch.rand(self.weight.shape, generator=g) * 2 - 1) * bound).to(self.weight.device))
+        self.bias.data.copy_(((torch.rand(self.bias.shape, generator=g) * 2 - 1) * bound).to(self.bias.device))
+        self.arena.pack()
+
+    def forward(self, x):
+        self.arena.pack_if_stale()
+        return _ProjFn.apply(x.reshape(-1, x.shape[-1]).to(BF16).contiguous(), self.arena.anchor, self).view(*x.shape[:-1], self.out_features)
+
+
+class _ProjFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, anchor, shell):
+        ctx.shell = shell
+        ctx.save_for_backward(enc)
+        return ops.gemm_nt(enc, shell.w_bf, bias=shell.b_bf.view(-1))
+
+    @staticmethod
+    def backward(ctx, dy):
+        (enc,) = ctx.saved_tensors
+        sh = ctx.shell
+        dy = dy.contiguous()
+        dyT = ops.transpose2d(dy, pad_to=32)
+        encT = ops.transpose2d(enc, pad_to=32)
+        ops.gemm_nt_splitk(dyT, encT, sh.arena.grad("dna_projection.weight"))
+        ops.colsum(dy, sh.arena.grad("dna_projection.bias").view(-1))
+        return None, None, None
+
+
+class _EmbedScatterFn(torch.autograd.Function):
+    """embed_tokens(input_ids) with projected DNA rows written over the <|dna_pad|> rows (dna_llm.py:211,229)."""
+
+    @staticmethod
+    def forward(ctx, dna_rows, ids32, tok_src, E):
+        out = torch.empty((ids32.numel(), E.shape[1]), dtype=BF16, device=E.device)
+        ops.embed_scatter_fwd(ids32, tok_src, E, dna_rows, out)
+        ctx.save_for_backward(tok_src)
+        ctx.shape = None if dna_rows is None else dna_rows.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tok_src,) = ctx.saved_tensors
+        if ctx.shape is None:
+            return None, None, None, None
+        ddna = torch.zeros(ctx.shape, dtype=BF16, device=dout.device)
+        ops.embed_scatter_bwd(tok_src, dout.contiguous(), ddna)
+        return ddna, None, None, None
+
+
+class DNALLMModel(nn.Module):
+    def __init__(
+        self,
+        text_model_name: Union[str, Any],
+        dna_model_name: Union[str, Any],
+        cache_dir: Optional[str] = None,
+        max_length_dna: int = 2048,
+        max_length_text: int = 512,
+        text_model_finetune: bool = True,
+        dna_model_finetune: bool = True,
+        dna_is_evo2: bool = False,
+        dna_embedding_layer: str = None,
+        debug: bool = False,
+        device: Optional[Union[str, torch.device]] = None,
+        dna_token_id: Optional[int] = None,
+    ):
+        super().__init__()
+        if dna_is_evo2:
+            raise NotImplementedError("Evo2 encoder: SURVEY §8f N3 (no oracle offline); NT-v2 path only")
+        self.text_model_finetune, self.dna_model_finetune = text_model_finetune, dna_model_finetune
+        self.max_length_dna, self.max_length_text = max_length_dna, max_length_text
+        self.dna_is_evo2, self.dna_embedding_layer = dna_is_evo2, dna_embedding_layer
+        dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        if isinstance(text_model_name, str) or isinstance(dna_model_name, str):
+            from .checkpoint import load_pretrained_pair
+            self.text_model, self.dna_model, toks = load_pretrained_pair(text_model_name, dna_model_name, cache_dir, dev)
+            self.text_tokenizer, self.dna_tokenizer, self.processor = toks
+            self.dna_token_id = self.text_tokenizer.convert_tokens_to_ids("<|dna_pad|>")
+        else:                                   # config objects: random init (no weights / tokenizers offline)
+            self.text_model = Qwen3ForCausalLM(text_model_name, device=dev)
+            self.dna_model = NTEncoderForMaskedLM(dna_model_name, device=dev)
+            self.text_tokenizer = self.dna_tokenizer = self.processor = None
+            self.dna_token_id = dna_token_id if dna_token_id is not None else 151670   # Qwen3 id of the 2nd added token
+        self.text_config, self.dna_config = self.text_model.config, self.dna_model.config
+        self.config = self.text_config
+        self.text_hidden_size, self.dna_hidden_size = self.text_config.hidden_size, self.dna_config.hidden_size
+        self.arena = TrainableArena(dev)
+        self.dna_projection = ProjectionLinear(self.dna_hidden_size, self.text_hidden_size, self.arena)
+        self.arena.commit()
+        self.dna_projection.reset_parameters()
+        self.text_model.arena = self.arena
+        for p in self.dna_model.parameters():   # frozen at run time whatever dna_model_finetune says (dna_llm.py:121)
+            p.requires_grad_(False)
+        self.warnings_issued: Dict[str, bool] = {}
+        self.check_counts = True
+
+    # ---- HF-Trainer conveniences the reference class lacks ----------------------------------------
+    def gradient_checkpointing_enable(self, *a, **k):
+        return None
+
+    def enable_input_require_grads(self):
+        return None
+
+    def get_input_embeddings(self):
+        return self.text_model.get_input_embeddings()
+
+    @property
+    def device(self):
+        return self.text_model.device
+
+    # ---- DNA side ------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_dna(self, dna_tokenized: Dict[str, torch.Tensor], dna_alias: Optional[List[int]] = None) -> torch.Tensor:
+        """frozen encoder forward -> hidden_states[-1] as rows [n_seq * Sd, H_dna]; with `dna_alias` only the
+        representative sequences are encoded and the rows are expanded."""
+        ids, mask = dna_tokenized["input_ids"], dna_tokenized["attention_mask"]
+        n, Sd = ids.shape
+        if dna_alias is None:
+            return self.dna_model(input_ids=ids, attention_mask=mask).hidden_states[-1].reshape(n * Sd, -1)
+        reps = sorted(set(dna_alias))
+        where = {r: i for i, r in enumerate(reps)}
+        sel = torch.tensor(reps, device=ids.device)
+        enc = self.dna_model(input_ids=ids[sel], attention_mask=mask[sel]).hidden_states[-1].reshape(len(reps) * Sd, -1)
+        rows = torch.tensor([where[a] for a in dna_alias], dtype=torch.int32, device=ids.device)
+        rows = (rows[:, None] * Sd + torch.arange(Sd, dtype=torch.int32, device=ids.device)[None, :]).reshape(-1)
+        return ops.gather_rows(rows.contiguous(), enc)
+
+    def process_dna_embeddings(self, dna_tokenized: Dict[str, torch.Tensor], batch_idx_map: List[int], batch_size: int) -> List[torch.Tensor]:
+        """Reference-shaped output (dna_llm.py:103-179): per batch item, the projected rows of its sequences
+        (first `attention_mask.sum()` rows of each) concatenated."""
+        enc = self.encode_dna(dna_tokenized)
+        n, Sd = dna_tokenized["input_ids"].shape
+        proj = self.dna_projection(enc).view(n, Sd, -1)
+        lengths = dna_tokenized["attention_mask"].sum(dim=1).tolist()
+        per: List[List[torch.Tensor]] = [[] for _ in range(batch_size)]
+        for s, b in enumerate(batch_idx_map):
+            per[b].append(proj[s, : int(lengths[s])])
+        return [torch.cat(c, dim=0) if c else torch.zeros((0, self.text_hidden_size), device=proj.device) for c in per]
+
+    def _inputs_embeds(self, input_ids, dna_tokenized, batch_idx_map, dna_alias=None):
+        eng = self.text_model.ensure_packed()
+        B, P = input_ids.shape
+        ids32 = input_ids.to(torch.int32).reshape(-1).contiguous()
+        dev = ids32.device
+        if dna_tokenized is not None and batch_idx_map:
+            enc = self.encode_dna(dna_tokenized, dna_alias)
+            proj = self.dna_projection(enc)                                        # [n*Sd, H_text], differentiable
+            n, Sd = dna_tokenized["input_ids"].shape
+            order = sorted(range(n), key=lambda i: batch_idx_map[i])               # stable: per-sample concat order
+            tok_src = torch.empty(B * P, dtype=torch.int32, device=dev)
+            counts = torch.zeros(2, dtype=torch.int32, device=dev)
+            ops.dna_scatter_plan(ids32, self.dna_token_id, dna_tokenized["attention_mask"].to(torch.uint8).contiguous(),
+                                 torch.tensor(order, dtype=torch.int32, device=dev), tok_src, counts)
+            if self.check_counts:
+                n_tok, n_feat = counts.tolist()
+                if n_tok != n_feat:                                                # dna_llm.py:222-225
+                    raise ValueError(f"DNA features and DNA tokens do not match: features {n_feat}, tokens: {n_tok}")
+            emb = _EmbedScatterFn.apply(proj, ids32, tok_src, eng.E)
+        else:
+            emb = _EmbedScatterFn.apply(None, ids32, None, eng.E)
+        return emb.view(B, P, -1)
+
+    # ---- the reference's two entry points ----------------------------------------------------------------------------
+    def forward(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                dna_tokenized: Optional[Dict[str, torch.Tensor]] = None, batch_idx_map: Optional[List[int]] = None,
+                labels: Optional[torch.Tensor] = None, dna_alias: Optional[List[int]] = None, **kwargs):
+        if input_ids is None or attention_mask is None:
+            raise ValueError("Either 'inputs' or 'input_ids'/'attention_mask' must be provided")
+        embeds = self._inputs_embeds(input_ids, dna_tokenized, batch_idx_map, dna_alias)
+        return self.text_model(inputs_embeds=embeds, attention_mask=attention_mask, labels=labels, **kwargs)
+
+    @torch.no_grad()
+    def generate(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                 dna_tokenized: Optional[Dict[str, torch.Tensor]] = None, batch_idx_map: Optional[List[int]] = None,
+                 dna_alias: Optional[List[int]] = None, **generation_kwargs) -> torch.Tensor:
+        if input_ids is None or attention_mask is None:
+            raise ValueError("Either 'inputs' or 'input_ids'/'attention_mask' must be provided")
+        embeds = self._inputs_embeds(input_ids, dna_tokenized, batch_idx_map, dna_alias)
+        gc = generation_kwargs.pop("generation_config", None)
+        kw = {}
+        for k in ("max_new_tokens", "do_sample", "temperature", "top_k", "top_p", "eos_token_id", "pad_token_id"):
+            if gc is not None and getattr(gc, k, None) is not None:
+                kw[k] = getattr(gc, k)
+            if k in generation_kwargs and generation_kwargs[k] is not None:
+                kw[k] = generation_kwargs[k]
+        for k in ("seed", "check_every", "return_full_length", "force_tokens"):
+            if k in generation_kwargs:
+                kw[k] = generation_kwargs[k]
+        if not kw.get("do_sample", False):
+            kw.pop("temperature", None); kw.pop("top_k", None); kw.pop("top_p", None)
+        return generation.generate(self.text_model, embeds, attention_mask, **kw)

@@ -1,0 +1,308 @@
+"""Kernel-level runtimes of the two networks on the hot path.
+
+`QwenEngine`   — Qwen3 decoder stack (TF:models/qwen3/modeling_qwen3.py:294-427): forward, hand-written backward
+                 (input gradient + LoRA weight gradients written straight into the TrainableArena), KV-cache
+                 prefill and single-token decode.
+`EsmEngine`    — NT-v2 / ESM encoder forward (TF:models/esm/modeling_esm.py:466-555 + NT-v2 SwiGLU FFN), no
+                 backward: the reference always runs the DNA encoder under no_grad (dna_llm.py:121).
+
+Both consume "packed" bf16 weights: q/k/v fused into one [Nq+2Nkv, H] matrix, gate/up fused into [2F, H], plus
+pre-transposed copies of the frozen weights so that every dgrad is the same K-contiguous NT GEMM.  The packed
+buffers are the storage of the nn.Parameters the callers see (they are re-aliased after .to()/.load_state_dict()).
+All arithmetic is libbioreason_hip.so; torch provides memory, streams and autograd bookkeeping only.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .arena import TrainableArena
+
+BF16 = torch.bfloat16
+
+
+def rope_tables(npos: int, hd: int, theta: float, device, round_bf16: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cos/sin [npos, hd/2] exactly as HF builds them (fp32 inv_freq x position, TF:qwen3:126-138, TF:esm:144-159);
+    HF then casts them to the activation dtype (bf16) — `round_bf16` reproduces that."""
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = torch.arange(npos, dtype=torch.float32)[:, None] * inv[None, :]
+    c, s = fr.cos(), fr.sin()
+    if round_bf16:
+        c, s = c.to(BF16).float(), s.to(BF16).float()
+    return c.contiguous().to(device), s.contiguous().to(device)
+
+
+# =============================================================================================== LoRA groups
+class LoraGroup:
+    """Adapters of one fused projection: targets j = 0..n-1 with output row blocks `n_sizes`.
+    Master layout (fp32, in the arena): Acat [r_pad, K] (row block j = A_j), Bcat [N, r_pad] (block (rows_j, cols_j) = B_j).
+    bf16 images: A, AT [K, r_pad], B, BT [r_pad, N]."""
+
+    def __init__(self, arena: TrainableArena, key: str, K: int, n_sizes: List[int], r: int, alpha: float):
+        self.key, self.K, self.n_sizes, self.r = key, K, n_sizes, r
+        self.N = sum(n_sizes)
+        self.r_pad = (len(n_sizes) * r + 63) // 64 * 64
+        self.scaling = alpha / r
+        self.arena = arena
+        arena.add(key + ".A", self.r_pad, K)
+        arena.add(key + ".B", self.N, self.r_pad)
+        self.on_views: List = []          # callbacks of the module shells that alias the per-target views
+        arena.on_rebind(self.materialise)
+
+    def materialise(self):
+        a, dev = self.arena, self.arena.device
+        self.A_master, self.B_master = a.param(self.key + ".A"), a.param(self.key + ".B")
+        self.A_grad, self.B_grad = a.grad(self.key + ".A"), a.grad(self.key + ".B")
+        am, bm = a.mask_view(self.key + ".A"), a.mask_view(self.key + ".B")
+        off = 0
+        active = getattr(self, "active", None)
+        for j, n in enumerate(self.n_sizes):
+            if active is None or active[j]:
+                am[j * self.r:(j + 1) * self.r, :] = 1
+                bm[off:off + n, j * self.r:(j + 1) * self.r] = 1
+            off += n
+        self.A = torch.zeros(self.r_pad, self.K, dtype=BF16, device=dev)
+        self.AT = torch.zeros(self.K, self.r_pad, dtype=BF16, device=dev)
+        self.B = torch.zeros(self.N, self.r_pad, dtype=BF16, device=dev)
+        self.BT = torch.zeros(self.r_pad, self.N, dtype=BF16, device=dev)
+        a.register_pack(self.A_master, self.A, False)
+        a.register_pack(self.A_master, self.AT, True)
+        a.register_pack(self.B_master, self.B, False)
+        a.register_pack(self.B_master, self.BT, True)
+        for fn in self.on_views:
+            fn()
+
+    def target_views(self, j: int):
+        """(A_j param, B_j param, A_j grad, B_j grad) — what lora_A.default.weight / lora_B.default.weight alias"""
+        off = sum(self.n_sizes[:j])
+        n = self.n_sizes[j]
+        rs = slice(j * self.r, (j + 1) * self.r)
+        return (self.A_master[rs, :], self.B_master[off:off + n, rs], self.A_grad[rs, :], self.B_grad[off:off + n, rs])
+
+
+# =============================================================================================== Qwen3
+@dataclass
+class QwenLayerW:
+    ln1: torch.Tensor = None
+    ln2: torch.Tensor = None
+    qn: torch.Tensor = None
+    kn: torch.Tensor = None
+    Wqkv: torch.Tensor = None
+    Wo: torch.Tensor = None
+    Wgu: torch.Tensor = None
+    Wd: torch.Tensor = None
+    WqkvT: torch.Tensor = None
+    WoT: torch.Tensor = None
+    WguT: torch.Tensor = None
+    WdT: torch.Tensor = None
+    lora: Dict[str, Optional[LoraGroup]] = field(default_factory=lambda: {"qkv": None, "o": None, "gu": None, "d": None})
+
+
+@dataclass
+class SeqMeta:
+    B: int
+    S: int
+    pos: torch.Tensor                 # int32 [B*S]
+    kmask: Optional[torch.Tensor]     # uint8 [B, S] or None
+    lora_on: bool = True
+    max_pos: int = 0                  # largest rotary position + 1 (0 -> S)
+
+
+class QwenEngine:
+    def __init__(self, cfg, device):
+        self.cfg = cfg
+        self.device = device
+        self.H = cfg.hidden_size
+        self.Hq, self.Hkv, self.hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self.F = cfg.intermediate_size
+        self.L = cfg.num_hidden_layers
+        self.V = cfg.vocab_size
+        self.eps = cfg.rms_norm_eps
+        self.Nq, self.Nkv = self.Hq * self.hd, self.Hkv * self.hd
+        self.scale = self.hd ** -0.5
+        self.layers: List[QwenLayerW] = [QwenLayerW() for _ in range(self.L)]
+        self.norm_w: torch.Tensor = None
+        self.E: torch.Tensor = None          # [V, H] tied embedding / lm_head
+        self.ET: Optional[torch.Tensor] = None
+        self._rope = None
+        self._rope_len = 0
+
+    # ------------------------------------------------------------------ helpers
+    def rope(self, npos: int):
+        if self._rope is None or self._rope_len < npos:
+            n = max(npos, 512)
+            theta = self.cfg.rope_parameters["rope_theta"] if hasattr(self.cfg, "rope_parameters") else self.cfg.rope_theta
+            self._rope = rope_tables(n, self.hd, theta, self.device)
+            self._rope_len = n
+        return self._rope
+
+    def ensure_transposed(self):
+        for L in self.layers:
+            if L.WqkvT is None:
+                L.WqkvT = ops.transpose2d(L.Wqkv)
+                L.WoT = ops.transpose2d(L.Wo)
+                L.WguT = ops.transpose2d(L.Wgu)
+                L.WdT = ops.transpose2d(L.Wd)
+        if self.ET is None:
+            self.ET = ops.transpose2d(self.E)
+
+    @staticmethod
+    def _lora_fwd(x2d, W, G: Optional[LoraGroup], on: bool, res=None, out=None):
+        """y = x W^T (+ (s x A^T) B^T) (+res); returns (y, t)"""
+        if G is not None and on:
+            t = ops.gemm_nt(x2d, G.A, alpha=G.scaling)
+            return ops.gemm_nt(x2d, W, a2=t, b2=G.B, res=res, out=out), t
+        return ops.gemm_nt(x2d, W, res=res, out=out), None
+
+    @staticmethod
+    def _lora_bwd(dy, WT, G: Optional[LoraGroup], on: bool, x2d, t):
+        """dx = dy W (+ s (dy B) A); accumulates dA, dB into the arena."""
+        if G is not None and on:
+            dts = ops.gemm_nt(dy, G.BT, alpha=G.scaling)                 # [T, r_pad] = s * dy B
+            dx = ops.gemm_nt(dy, WT, a2=dts, b2=G.AT)
+            dyT = ops.transpose2d(dy, pad_to=32)                         # [N, Tp]
+            tT = ops.transpose2d(t, pad_to=32)                           # [r_pad, Tp]
+            ops.gemm_nt_splitk(dyT, tT, G.B_grad)                        # dB += dy^T t      (t already holds s)
+            dtT = ops.transpose2d(dts, pad_to=32)
+            xT = ops.transpose2d(x2d, pad_to=32)                         # [K, Tp]
+            ops.gemm_nt_splitk(dtT, xT, G.A_grad)                        # dA += (s dy B)^T x
+            return dx
+        return ops.gemm_nt(dy, WT)
+
+    # ------------------------------------------------------------------ one decoder layer
+    def layer_fwd(self, li: int, x: torch.Tensor, m: SeqMeta, save: bool, kv_out=None):
+        """x [T, H] bf16 -> y [T, H].  kv_out = (kcache, vcache, s_off): also write K/V rows into a cache
+        [B, Hkv, Smax, hd] (prefill) and attend over the cache view."""
+        L = self.layers[li]
+        B, S, T = m.B, m.S, m.B * m.S
+        cosT, sinT = self.rope(m.max_pos or m.S)
+        xn = ops.rmsnorm_fwd(x, L.ln1, self.eps)
+        qkv, t1 = self._lora_fwd(xn, L.Wqkv, L.lora["qkv"], m.lora_on)
+        q = torch.empty((B, S, self.Hq, self.hd), dtype=BF16, device=x.device)
+        if kv_out is None:
+            k = torch.empty((B, S, self.Hkv, self.hd), dtype=BF16, device=x.device)
+            v = torch.empty((B, S, self.Hkv, self.hd), dtype=BF16, device=x.device)
+            s_off = 0
+        else:
+            kc, vc, s_off = kv_out
+            k, v = kc.permute(0, 2, 1, 3), vc.permute(0, 2, 1, 3)        # [B, Smax, Hkv, hd] views
+        ops.qk_norm_rope_fwd(qkv, L.qn, L.kn, cosT, sinT, m.pos, S, self.Hq, self.Hkv, self.hd, self.eps, 1.0, q, k, v, s_off)
+        if kv_out is not None:
+            k, v = k[:, :s_off + S], v[:, :s_off + S]
+        vt = ops.head_transpose(v)
+        o, lse = ops.attn_fwd(q, k, vt, m.kmask, True, self.scale, need_lse=save)
+        o2 = o.view(T, self.Nq)
+        h, t2 = self._lora_fwd(o2, L.Wo, L.lora["o"], m.lora_on, res=x)
+        hn = ops.rmsnorm_fwd(h, L.ln2, self.eps)
+        gu, t3 = self._lora_fwd(hn, L.Wgu, L.lora["gu"], m.lora_on)
+        act = ops.swiglu_fwd(gu)
+        y, t4 = self._lora_fwd(act, L.Wd, L.lora["d"], m.lora_on, res=h)
+        saved = (x, xn, t1, qkv, q, k, v, o, lse, t2, h, hn, t3, gu, act, t4) if save else None
+        return y, saved
+
+    def layer_bwd(self, li: int, dy: torch.Tensor, saved, m: SeqMeta):
+        L = self.layers[li]
+        (x, xn, t1, qkv, q, k, v, o, lse, t2, h, hn, t3, gu, act, t4) = saved
+        B, S, T = m.B, m.S, m.B * m.S
+        cosT, sinT = self.rope(m.max_pos or m.S)
+        on = m.lora_on
+        dact = self._lora_bwd(dy, L.WdT, L.lora["d"], on, act, t4)
+        dgu = ops.swiglu_bwd(gu, dact)
+        dhn = self._lora_bwd(dgu, L.WguT, L.lora["gu"], on, hn, t3)
+        dh = ops.rmsnorm_bwd(dhn, h, L.ln2, self.eps, dres=dy)             # + residual branch
+        do = self._lora_bwd(dh, L.WoT, L.lora["o"], on, o.view(T, self.Nq), t2)
+        dq, dk, dv = ops.attn_bwd(q, k, v, o, do.view(B, S, self.Hq, self.hd), lse, m.kmask, True, self.scale)
+        dqkv = ops.qk_norm_rope_bwd(qkv, L.qn, L.kn, cosT, sinT, m.pos, S, self.Hq, self.Hkv, self.hd, self.eps, 1.0, dq, dk, dv)
+        dxn = self._lora_bwd(dqkv, L.WqkvT, L.lora["qkv"], on, xn, t1)
+        return ops.rmsnorm_bwd(dxn, x, L.ln1, self.eps, dres=dh)
+
+    # ------------------------------------------------------------------ stack
+    def forward_hidden(self, x: torch.Tensor, m: SeqMeta, save: bool):
+        """x [T,H] -> final-normed hidden [T,H]; returns (hidden, tape)"""
+        tape = []
+        for li in range(self.L):
+            x, saved = self.layer_fwd(li, x, m, save)
+            tape.append(saved)
+        hid = ops.rmsnorm_fwd(x, self.norm_w, self.eps)
+        return hid, (tape, x) if save else None
+
+    def backward_hidden(self, dhid: torch.Tensor, tape_x, m: SeqMeta):
+        tape, xlast = tape_x
+        dx = ops.rmsnorm_bwd(dhid, xlast, self.norm_w, self.eps)
+        for li in reversed(range(self.L)):
+            dx = self.layer_bwd(li, dx, tape[li], m)
+            tape[li] = None
+        return dx
+
+
+# =============================================================================================== NT-v2 / ESM encoder
+@dataclass
+class EsmLayerW:
+    ln1_w: torch.Tensor = None
+    ln1_b: torch.Tensor = None
+    Wqkv: torch.Tensor = None
+    bqkv: torch.Tensor = None
+    Wo: torch.Tensor = None
+    bo: torch.Tensor = None
+    ln2_w: torch.Tensor = None
+    ln2_b: torch.Tensor = None
+    Wup: torch.Tensor = None      # [2F, H]
+    Wdown: torch.Tensor = None    # [H, F]
+
+
+class EsmEngine:
+    def __init__(self, cfg, device):
+        self.cfg, self.device = cfg, device
+        self.H = cfg.hidden_size
+        self.nh = cfg.num_attention_heads
+        self.hd = self.H // self.nh
+        self.F = cfg.intermediate_size
+        self.L = cfg.num_hidden_layers
+        self.eps = cfg.layer_norm_eps
+        self.layers: List[EsmLayerW] = [EsmLayerW() for _ in range(self.L)]
+        self.E: torch.Tensor = None
+        self.lnf_w = self.lnf_b = None
+        self._rope = None
+        self._rope_len = 0
+
+    def rope(self, npos):
+        if self._rope is None or self._rope_len < npos:
+            theta = getattr(self.cfg, "rope_theta", 10000.0) or 10000.0
+            self._rope = rope_tables(max(npos, 64), self.hd, theta, self.device)
+            self._rope_len = max(npos, 64)
+        return self._rope
+
+    @torch.no_grad()
+    def forward(self, ids32: torch.Tensor, mask_u8: torch.Tensor) -> torch.Tensor:
+        """ids32 [n, S] int32, mask_u8 [n, S] -> last hidden state [n*S, H] (after emb_layer_norm_after,
+        = outputs.hidden_states[-1] of EsmForMaskedLM)."""
+        n, S = ids32.shape
+        T = n * S
+        dev = ids32.device
+        cosT, sinT = self.rope(S)
+        pos = torch.arange(S, dtype=torch.int32, device=dev).repeat(n)      # positions ignore padding (TF:esm:733-737)
+        # word embeddings * attention_mask (TF:esm:239,267-268): padded rows are zero vectors
+        # (a token with mask 0 reads row 0 of a one-row zero table instead of its embedding; no host sync)
+        x = torch.empty((T, self.H), dtype=BF16, device=dev)
+        zero_row = torch.zeros((1, self.H), dtype=BF16, device=dev)
+        tok_src = (mask_u8.reshape(-1).to(torch.int32) - 1).clamp_(max=0).neg_().sub_(1)   # mask 1 -> -1, mask 0 -> 0
+        ops.embed_scatter_fwd(ids32.reshape(-1), tok_src, self.E, zero_row, x)
+        for L in self.layers:
+            xn = ops.layernorm_fwd(x, L.ln1_w, L.ln1_b, self.eps)
+            qkv = ops.gemm_nt(xn, L.Wqkv, bias=L.bqkv)
+            q = torch.empty((n, S, self.nh, self.hd), dtype=BF16, device=dev)
+            k = torch.empty_like(q)
+            v = torch.empty_like(q)
+            ops.qk_norm_rope_fwd(qkv, None, None, cosT, sinT, pos, S, self.nh, self.nh, self.hd, 0.0, self.hd ** -0.5, q, k, v, 0)
+            vt = ops.head_transpose(v)
+            o, _ = ops.attn_fwd(q, k, vt, mask_u8, False, 1.0, need_lse=False)     # scaling 1.0: q was pre-scaled (TF:esm:345,374)
+            x = ops.gemm_nt(o.view(T, self.H), L.Wo, bias=L.bo, res=x)
+            xn = ops.layernorm_fwd(x, L.ln2_w, L.ln2_b, self.eps)
+            up = ops.gemm_nt(xn, L.Wup)
+            act = ops.swiglu_fwd(up)
+            x = ops.gemm_nt(act, L.Wdown, res=x)
+        return ops.layernorm_fwd(x, self.lnf_w, self.lnf_b, self.eps)

@@ -1,0 +1,124 @@
+"""KV-cache generation for the HIP Qwen3: prefill + single-token decode + device-side sampling.
+
+Replaces `text_model.generate(inputs_embeds=..., attention_mask=..., use_cache=True, **kw)` as called by
+DNALLMModel.generate (bioreason/models/dna_llm.py:297-304), i.e. HF GenerationMixin.generate/_sample
+(TF:generation/utils.py:2261, 2783-2925) with a DynamicCache:
+  * rotary positions = cumsum(attention_mask) - 1 (TF:generation/utils.py:751-773), continuing +1 per new token;
+  * left-padded prompts are handled by the key-validity mask; new positions are always attendable;
+  * finished rows emit pad_token_id; a row finishes when it emits eos_token_id; generation stops when every row
+    has finished (checked every few steps so the host never blocks the launch queue per token) or at
+    max_new_tokens; with `inputs_embeds` only the NEW tokens are returned (grpo_trainer.py:588-596).
+The whole step is kernel launches on the current stream; the sampler keeps tokens, finished flags and the RNG
+counter on the device.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .engine import BF16, QwenEngine, SeqMeta
+
+
+class KVCache:
+    def __init__(self, eng: QwenEngine, B: int, Smax: int, device):
+        self.k = [torch.zeros((B, eng.Hkv, Smax, eng.hd), dtype=BF16, device=device) for _ in range(eng.L)]
+        self.v = [torch.zeros((B, eng.Hkv, Smax, eng.hd), dtype=BF16, device=device) for _ in range(eng.L)]
+        self.Smax = Smax
+
+
+@torch.no_grad()
+def prefill(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, cache: KVCache, pos: torch.Tensor):
+    """Runs the prompt through the stack writing K/V into the cache; returns the last-position hidden rows [B, H]."""
+    eng = model.ensure_packed()
+    B, S, H = inputs_embeds.shape
+    kmask = attention_mask.to(torch.uint8).contiguous()
+    meta = SeqMeta(B=B, S=S, pos=pos.reshape(-1).contiguous(), kmask=kmask, lora_on=model._lora_enabled,
+                   max_pos=cache.Smax + 1)
+    x = inputs_embeds.reshape(B * S, H).to(BF16).contiguous()
+    for li in range(eng.L):
+        x, _ = eng.layer_fwd(li, x, meta, save=False, kv_out=(cache.k[li], cache.v[li], 0))
+    last = (torch.arange(B, device=x.device, dtype=torch.int32) * S + (S - 1))
+    xl = ops.gather_rows(last, x)
+    return ops.rmsnorm_fwd(xl, eng.norm_w, eng.eps)
+
+
+@torch.no_grad()
+def decode_step(model, tok: torch.Tensor, cache: KVCache, kmask: torch.Tensor, pos: torch.Tensor, cur_len: int):
+    """One new token per sequence: tok int32 [B] -> final hidden [B, H].  `cur_len` = cached positions so far."""
+    eng: QwenEngine = model.engine
+    on = model._lora_enabled
+    B = tok.shape[0]
+    dev = tok.device
+    cosT, sinT = eng.rope(cache.Smax + 1)
+    x = torch.empty((B, eng.H), dtype=BF16, device=dev)
+    ops.embed_scatter_fwd(tok, None, eng.E, None, x)
+    q = torch.empty((B, 1, eng.Hq, eng.hd), dtype=BF16, device=dev)
+    for li, L in enumerate(eng.layers):
+        xn = ops.rmsnorm_fwd(x, L.ln1, eng.eps)
+        qkv, _ = eng._lora_fwd(xn, L.Wqkv, L.lora["qkv"], on)
+        kc, vc = cache.k[li], cache.v[li]
+        ops.qk_norm_rope_fwd(qkv, L.qn, L.kn, cosT, sinT, pos, 1, eng.Hq, eng.Hkv, eng.hd, eng.eps, 1.0, q,
+                             kc.permute(0, 2, 1, 3), vc.permute(0, 2, 1, 3), cur_len)
+        o = ops.attn_decode(q.view(B, eng.Hq, eng.hd), kc, vc, kmask, cur_len + 1, eng.scale)
+        h, _ = eng._lora_fwd(o, L.Wo, L.lora["o"], on, res=x)
+        hn = ops.rmsnorm_fwd(h, L.ln2, eng.eps)
+        gu, _ = eng._lora_fwd(hn, L.Wgu, L.lora["gu"], on)
+        act = ops.swiglu_fwd(gu)
+        x, _ = eng._lora_fwd(act, L.Wd, L.lora["d"], on, res=h)
+    return ops.rmsnorm_fwd(x, eng.norm_w, eng.eps)
+
+
+@torch.no_grad()
+def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int = 20,
+             do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
+             eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None, seed: int = 0,
+             check_every: int = 16, return_full_length: bool = False,
+             force_tokens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`force_tokens` [B, max_new_tokens] (optional): teacher forcing — the model's own choice is still recorded
+    in the output, but the given token is fed back (used to compare decodes position by position)."""
+    eng = model.ensure_packed()
+    B, P, H = inputs_embeds.shape
+    dev = inputs_embeds.device
+    if isinstance(eos_token_id, (list, tuple)):
+        eos_token_id = eos_token_id[0]
+    eos = -1 if eos_token_id is None else int(eos_token_id)
+    pad = int(pad_token_id) if pad_token_id is not None else (eos if eos >= 0 else 0)
+    Smax = P + max_new_tokens
+    cache = KVCache(eng, B, Smax, dev)
+    am = attention_mask.to(torch.long)
+    pos_prompt = (am.cumsum(-1) - 1).masked_fill(am == 0, 0).to(torch.int32)      # TF:generation/utils.py:763-765
+    kmask = torch.ones((B, Smax), dtype=torch.uint8, device=dev)
+    kmask[:, :P] = am.to(torch.uint8)
+    hid = prefill(model, inputs_embeds, attention_mask, cache, pos_prompt)
+    next_pos = (pos_prompt[:, -1] + 1).contiguous()                               # TF:generation/utils.py:979-984
+
+    tokens = torch.full((B, max_new_tokens), pad, dtype=torch.int32, device=dev)
+    finished = torch.zeros((B,), dtype=torch.uint8, device=dev)
+    cur = torch.empty((B,), dtype=torch.int32, device=dev)
+    step_t = torch.zeros((1,), dtype=torch.int32, device=dev)
+    logits = torch.empty((B, eng.V), dtype=torch.float32, device=dev)
+    n_done = max_new_tokens
+    for t in range(max_new_tokens):
+        ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
+        ops.sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished if eos >= 0 else None, pad,
+                   cur, None, eos_id=eos, tokens_out=tokens)
+        if eos >= 0 and force_tokens is None and (t + 1) % check_every == 0 and bool(finished.all().item()):
+            n_done = t + 1
+            break
+        if t + 1 == max_new_tokens:
+            break
+        if force_tokens is not None:
+            cur = force_tokens[:, t].to(torch.int32).contiguous()
+        hid = decode_step(model, cur, cache, kmask, next_pos, P + t)
+        next_pos += 1
+        step_t += 1
+    out = tokens[:, :n_done]
+    if eos >= 0 and not return_full_length and force_tokens is None:
+        # HF stops right after the step in which the last row finished: trim the all-pad tail we may have produced
+        is_eos = out == eos
+        has = is_eos.any(dim=1)
+        first = torch.where(has, is_eos.int().argmax(dim=1), torch.full_like(has, out.shape[1] - 1, dtype=torch.long))
+        out = out[:, : int(first.max().item()) + 1]
+    return out.to(torch.long)

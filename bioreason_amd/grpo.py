@@ -1,0 +1,88 @@
+"""GRPO arithmetic and the training step on top of the HIP DNA-LLM (mirror of
+bioreason/trainer/grpo_trainer.py: `_get_per_token_logps` :510-520, `_generate_and_score_completions` :535-749,
+`compute_loss` :751-814).  The HF-Trainer scaffolding of the reference (logging, callbacks, checkpoints) is not
+re-created; the numerics, the data-parallel partitioning and the two collectives are.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------- tensor math
+def completion_mask(completion_ids: torch.Tensor, eos_token_id: int) -> torch.Tensor:
+    """1 up to and including the first EOS (grpo_trainer.py:605-609); int32 [B, C]."""
+    mask, _ = ops.eos_mask(completion_ids.to(torch.int32).contiguous(), int(eos_token_id))
+    return mask
+
+
+def per_token_logps(model, prompt_ids: torch.Tensor, prompt_mask: torch.Tensor, completion_ids: torch.Tensor,
+                    completion_mask_: torch.Tensor, **multimodal) -> torch.Tensor:
+    """log pi(completion token | prefix) for every completion position -> fp32 [B, C].
+
+    Same quantity as `_get_per_token_logps(model, cat(prompt, completion), cat(masks))[:, P-1:]`
+    (grpo_trainer.py:510-520 with the slice of :624/:640/:779), but the tied lm_head, the log-softmax and the
+    gather run fused over the C kept rows only instead of materialising [B, P+C, V] logits."""
+    B, P = prompt_ids.shape
+    C = completion_ids.shape[1]
+    ids = torch.cat([prompt_ids, completion_ids.to(prompt_ids.dtype)], dim=1)
+    mask = torch.cat([prompt_mask, completion_mask_.to(prompt_mask.dtype)], dim=1)
+    embeds = model._inputs_embeds(ids, multimodal.get("dna_tokenized"), multimodal.get("batch_idx_map"),
+                                  multimodal.get("dna_alias"))
+    hid = model.text_model.hidden_states(embeds, mask)                     # [B*(P+C), H]
+    S = P + C
+    dev = ids.device
+    rows = (torch.arange(B, device=dev, dtype=torch.int32)[:, None] * S
+            + torch.arange(P - 1, S - 1, device=dev, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
+    tgt = completion_ids.to(torch.int32).reshape(-1).contiguous()
+    return model.text_model.token_logprobs(hid, rows, tgt).view(B, C)
+
+
+class _GrpoLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logp, old_logp, ref_logp, adv, mask, eps_lo, eps_hi, beta):
+        out3, dlogp = ops.grpo_loss(logp.contiguous(), old_logp, ref_logp, adv.contiguous().float(), mask.contiguous(),
+                                    eps_lo, eps_hi, beta, need_grad=True)
+        ctx.save_for_backward(dlogp)
+        ctx.mark_non_differentiable(out3)
+        return out3[0].clone(), out3
+
+    @staticmethod
+    def backward(ctx, g, _g3):
+        (dlogp,) = ctx.saved_tensors
+        return dlogp * g, None, None, None, None, None, None, None
+
+
+def grpo_loss(logp, old_logp, ref_logp, advantages, mask, epsilon_low=0.2, epsilon_high=0.2, beta=0.04):
+    """-> (loss, stats[3] = {loss, mean_kl, clip_ratio}); old_logp=None <=> num_iterations == 1 (:786)."""
+    rl = ref_logp.contiguous() if (ref_logp is not None and beta != 0.0) else None
+    ol = old_logp.contiguous() if old_logp is not None else None
+    return _GrpoLossFn.apply(logp, ol, rl, advantages, mask.to(torch.int32), epsilon_low, epsilon_high, beta)
+
+
+def group_advantages(rewards_per_func: torch.Tensor, num_generations: int, rank: int = 0, local_n: Optional[int] = None):
+    """rewards_per_func: ALL-GATHERED [N, F] fp32 -> (advantages [local slice], group mean, group std) (:682-699)."""
+    adv, gm, gs = ops.group_advantage(rewards_per_func.contiguous().float(), num_generations)
+    if local_n is not None:
+        adv = adv[rank * local_n:(rank + 1) * local_n]
+    return adv, gm, gs
+
+
+def repeat_sampler_indices(num_samples: int, mini_repeat_count: int, batch_size: int = 1, repeat_count: int = 1, seed: int = 0) -> List[int]:
+    """RepeatRandomSampler (grpo_trainer.py:72-119): every rank draws the same permutation, each prompt index is
+    emitted `mini_repeat_count` (= G) times consecutively; the launcher then shards the stream across ranks."""
+    g = torch.Generator().manual_seed(seed)
+    perm = torch.randperm(num_samples, generator=g).tolist()
+    chunks = [perm[i:i + batch_size] for i in range(0, len(perm), batch_size)]
+    out: List[int] = []
+    for chunk in chunks:
+        if len(chunk) != batch_size:
+            continue
+        for _ in range(repeat_count):
+            for index in chunk:
+                out.extend([index] * mini_repeat_count)
+    return out

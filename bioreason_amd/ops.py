@@ -282,10 +282,12 @@ def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- GRPO / optimiser
-def sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished, pad_id, out_ids, out_logp=None):
+def sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished, pad_id, out_ids, out_logp=None,
+           eos_id=-1, tokens_out=None):
     B, V = logits.shape
     get_lib().call("bra_sample", logits, _ld(logits), B, V, temperature, top_k, top_p, int(do_sample), seed & 0xFFFFFFFF,
-                   step_t, finished, pad_id, out_ids, out_logp, current_stream(logits))
+                   step_t, finished, pad_id, eos_id, out_ids, out_logp, tokens_out,
+                   tokens_out.stride(0) if tokens_out is not None else 0, current_stream(logits))
     return out_ids
 
 
@@ -314,9 +316,19 @@ def grpo_loss(logp, old_logp, ref_logp, adv, mask, eps_lo, eps_hi, beta, need_gr
     return out3, dlogp
 
 
-def sumsq(g: torch.Tensor, out: torch.Tensor):
-    get_lib().call("bra_sumsq", g, g.numel(), out, current_stream(g))
+def vec_sum(x: torch.Tensor, scale: float) -> torch.Tensor:
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    get_lib().call("bra_vec_sum", x, x.numel(), scale, out, current_stream(x))
+    return out
 
 
-def adamw(p, g, m, v, lr, b1, b2, eps, wd, step, sumsq_t=None, max_norm=0.0, grad_scale=1.0):
-    get_lib().call("bra_adamw", p, g, m, v, p.numel(), lr, b1, b2, eps, wd, step, sumsq_t, max_norm, grad_scale, current_stream(p))
+def sumsq(g: torch.Tensor, out: torch.Tensor, mask=None):
+    get_lib().call("bra_sumsq", g, mask, g.numel(), out, current_stream(g))
+
+
+def adamw(p, g, m, v, lr, b1, b2, eps, wd, step, sumsq_t=None, max_norm=0.0, grad_scale=1.0, mask=None):
+    get_lib().call("bra_adamw", p, g, m, v, mask, p.numel(), lr, b1, b2, eps, wd, step, sumsq_t, max_norm, grad_scale, current_stream(p))
+
+
+def pack_params(desc_table: torch.Tensor, ndesc: int, max_elems: int):
+    get_lib().call("bra_pack_params", desc_table, ndesc, max_elems, current_stream(desc_table))

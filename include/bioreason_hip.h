@@ -134,16 +134,22 @@ int bra_colsum(const void* x, long ldx, float* out, int rows, int cols, void* st
 int bra_pack_desc_size(void);
 int bra_pack_params(const void* descs_dev, int ndesc, long max_elems, void* stream);
 /* AdamW over one flat arena with device-side global-norm clip (train_dna_qwen.py:393-411, :1003 clip 1.0) */
-int bra_sumsq(const float* g, long n, float* out, void* stream);
-int bra_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-              float wd, int step, const float* sumsq, float max_norm, float grad_scale, void* stream);
+/* out[0] = scale * sum(x): the `mean` of F.cross_entropy (TF:loss/loss_utils.py:32-46) */
+int bra_vec_sum(const float* x, long n, float scale, float* out, void* stream);
+/* mask (bytes, optional): 0 = structural zero of the packed LoRA layout, excluded from norm and update */
+int bra_sumsq(const float* g, const void* mask, long n, float* out, void* stream);
+int bra_adamw(float* p, const float* g, float* m, float* v, const void* mask, long n, float lr, float b1, float b2,
+              float eps, float wd, int step, const float* sumsq, float max_norm, float grad_scale, void* stream);
 
 /* ---- GRPO arithmetic (k_grpo.hip) --------------------------------------------- */
 /* temperature -> top-k -> top-p -> multinomial, or argmax when do_sample == 0
  * (TF:generation/logits_process.py:238,473,542; TF:generation/utils.py:2897-2925; grpo_trainer.py:384-391) */
+/* finished[B] (bytes, in/out): a finished row emits pad_id; a row that emits eos_id becomes finished
+ * (HF: next = next*unfinished + pad*(1-unfinished); unfinished &= next != eos).  tokens_out[row*ldt + *step_ptr]
+ * receives the token (the [B, C] completion matrix), step_ptr is a device int so a replayed launch advances. */
 int bra_sample(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p,
-               int do_sample, unsigned seed, const int* step_ptr, const void* finished, int pad_id, int* out_ids,
-               float* out_logp, void* stream);
+               int do_sample, unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id,
+               int* out_ids, float* out_logp, int* tokens_out, long ldt, void* stream);
 /* completion mask up to and including the first EOS (grpo_trainer.py:605-609) */
 int bra_eos_mask(const int* ids, int B, int C, int eos_id, int* mask, int* lengths, void* stream);
 /* rewards [N,F] -> sum over F -> (r - mean_group) / (std_group + 1e-4), groups of G (grpo_trainer.py:682-691) */
