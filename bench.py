@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py — GRPO training-step throughput of the HIP DNA-LLM path (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full GRPO step on one batch of synthetic DNA+prompt input per GPU (cfg-3 of SURVEY §8d):
+NT-500M encoder + Qwen3-1.7B, 1 unique prompt x G=8 rollouts per GPU, prompt P = 2180 (2 DNA sequences x 1024 NT
+tokens + 128 text tokens), 256 sampled tokens per rollout (EOS suppressed so every rollout has the full length),
+reference log-probs (adapters off), policy forward/backward (LoRA r=32 on all 7 projections + dna_projection),
+reward all-gather + group advantages, gradient all-reduce, AdamW with grad clip 1.0.  Inputs are resident in HBM
+before the timed region.  value = samples (prompt, completion pairs) per second over all ranks.
+
+The JSON line also carries
+  roofline     — the dominant kernel (bra gemm_nt_kernel<64, bf16>, every linear layer of encoder / prefill /
+                 log-prob / backward): algorithmic FLOPs (2*M*N*K of each large-M launch) / its duration measured
+                 with HIP events on the launch stream inside the timed steps, against 2.5 PFLOP/s dense bf16 MFMA;
+  cpu_baseline — the oracle (reference glue + installed HF Qwen3 / ESM modules, bf16) timed on the host cores for a
+                 bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: 2.5 PF dense; 5 PF is 2:1 sparse)
+SD, TEXT_LEN, NDNA, G, C = 1024, 128, 2, 8, 256
+
+
+def flops_per_sample():
+    """BASELINE.md §3 (algorithmic, encoder counted once per sample as in the reference's own accounting)"""
+    return 34.1e12
+
+
+def cpu_baseline(max_seconds: float = 60.0):
+    """The oracle on the host cores, bounded: ONE sample of the cfg-3 workload at full model size —
+    encoder fwd (2 x 1024), prefill P=2180, 2 of the 256 decode steps (extrapolated x128), reference log-probs
+    forward and policy forward+backward over P+C.  bf16, sdpa, all cores."""
+    from oracle import dna_llm_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    t_build = time.time()
+    tc = dict(vocab_size=151936, hidden_size=2048, intermediate_size=6144, num_hidden_layers=28, num_attention_heads=16,
+              num_key_value_heads=8, head_dim=128, rope_theta=1e6, max_position_embeddings=40960)
+    dc = dict(vocab_size=4107, hidden_size=1024, intermediate_size=4096, num_hidden_layers=29, num_attention_heads=16,
+              max_position_embeddings=2050)
+    from transformers.initialization import no_init_weights
+    with no_init_weights():
+        text = O.make_qwen3(tc, "sdpa").to(torch.bfloat16)
+        dna = O.make_nt_v2(dc, "sdpa").to(torch.bfloat16)
+    g = torch.Generator().manual_seed(0)
+    for mdl in (text, dna):
+        for p in mdl.parameters():
+            p.data.uniform_(-0.03, 0.03, generator=g) if p.dim() >= 2 else p.data.fill_(1.0)
+    O.apply_lora(text, r=32, alpha=64.0)
+    for n, p in text.named_parameters():
+        if "lora_" in n:
+            p.data = p.data.to(torch.bfloat16)
+    model = O.OracleDNALLM(text, dna, 151670).to(torch.bfloat16)
+    from bioreason_amd.synth import synth_prompt_batch
+    b = synth_prompt_batch(B=1, n_unique=1, Sd=SD, text_len=TEXT_LEN, n_dna=NDNA, seed=42)
+    mm = {"dna_tokenized": b["dna_tokenized"], "batch_idx_map": b["batch_idx_map"]}
+    build_s = time.time() - t_build
+    from oracle import grpo_math as GM
+    t0 = time.time()
+    nd = 2
+    gen = model.generate(input_ids=b["input_ids"], attention_mask=b["attention_mask"], **mm, max_new_tokens=nd + 1,
+                         do_sample=True, temperature=0.6, top_k=20, top_p=0.95, pad_token_id=0)
+    t_roll_short = time.time() - t0
+    # time one extra decode step pair to extrapolate: second call with 2*nd+1 tokens
+    t0 = time.time()
+    model.generate(input_ids=b["input_ids"], attention_mask=b["attention_mask"], **mm, max_new_tokens=2 * nd + 1,
+                   do_sample=True, temperature=0.6, top_k=20, top_p=0.95, pad_token_id=0)
+    t_roll_long = time.time() - t0
+    per_step = max((t_roll_long - t_roll_short) / nd, 0.0)
+    t_rollout = t_roll_short + per_step * (C - 1 - nd)
+    comp = torch.randint(0, 151643, (1, C), generator=g)
+    ids = torch.cat([b["input_ids"], comp], 1)
+    mask = torch.ones_like(ids)
+    t0 = time.time()
+    O.set_adapters(text, False)
+    with torch.no_grad():
+        ref_lp = GM.per_token_logps(model, ids, mask, **mm)[:, -C:]
+    O.set_adapters(text, True)
+    t_ref = time.time() - t0
+    t0 = time.time()
+    lp = GM.per_token_logps(model, ids, mask, **mm)[:, -C:]
+    loss, _, _ = GM.grpo_loss(lp.float(), None, ref_lp.float(), torch.ones(1), torch.ones(1, C), 0.2, 0.2, 0.04)
+    loss.backward()
+    t_pol = time.time() - t0
+    total = t_rollout + t_ref + t_pol
+    return {"value": 1.0 / total, "unit": "samples/s", "cores": ncores, "kind": "port",
+            "sample": f"1 sample of the cfg-3 workload at full model size (bf16, sdpa): rollout {t_rollout:.1f}s "
+                      f"(prefill + {nd} measured decode steps, extrapolated to {C}), ref logps {t_ref:.1f}s, "
+                      f"policy fwd+bwd {t_pol:.1f}s; model build {build_s:.0f}s not counted"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--completion-len", type=int, default=C)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from bioreason_amd import configs, ops
+    from bioreason_amd.dna_llm import DNALLMModel
+    from bioreason_amd.synth import synth_prompt_batch
+    from bioreason_amd.trainer import GRPOConfig, GRPOStepRunner
+
+    model = DNALLMModel(configs.qwen3_config(), configs.nt_v2_config(), device=dev)
+    model.text_model.init_weights(0.02, seed=1)          # random-init weights of the real architectures (same on every rank)
+    model.dna_model.init_weights(0.02, seed=2)
+    model.text_model.apply_lora(r=32, alpha=64.0, dropout=0.0, arena=model.arena)
+    gen = torch.Generator().manual_seed(7)
+    for n, p in model.text_model.named_parameters():     # non-zero LoRA B so the adapter path carries signal
+        if "lora_B" in n:
+            p.data.copy_((torch.randn(p.shape, generator=gen) * 0.01).to(dev))
+    model.arena.pack()
+    cfg = GRPOConfig(num_generations=G, max_completion_length=args.completion_len, eos_token_id=None, seed=42)
+    runner = GRPOStepRunner(model, cfg)
+    batch = synth_prompt_batch(B=G, n_unique=1, Sd=SD, text_len=TEXT_LEN, n_dna=NDNA, dna_token_id=model.dna_token_id,
+                               device=dev, seed=42 + rank)
+
+    for _ in range(args.warmup):
+        runner.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ops.GEMM_PROFILE = ops.GemmProfile(min_m=1024)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = runner.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ops.GEMM_PROFILE.summary()
+    ops.GEMM_PROFILE = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # phase breakdown (one extra, untimed, instrumented step)
+    runner.step(batch, timing=True)
+    loss = float(out["loss_t"].item())
+
+    if rank == 0:
+        samples = world * G * args.steps
+        value = samples / elapsed
+        line = {
+            "metric": "GRPO samples/sec (NT-500M+Qwen3-1.7B, DNA 2x1024, prompt 2180, gen 256)",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "GRPO step cfg-3: NT-v2-500M encoder + Qwen3-1.7B (LoRA r=32 all linears + dna_projection), "
+                                   "1 prompt x G=8 per GPU, P=2180, C=%d sampled tokens (T=0.6, top-k 20, top-p 0.95), "
+                                   "ref logps + policy fwd/bwd + AdamW; random-init weights" % args.completion_len,
+                       "global_batch": world * G, "prompt_len": 2180, "completion_len": args.completion_len, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": prof["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": prof["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "gemm_nt_kernel<64,EPI_BF16> (launches with M>=1024)", "launches": prof["launches"],
+                         "avg_launch_ms": prof["avg_launch_ms"]},
+            "step_tflops": value / world * flops_per_sample() / 1e12,
+            "step_frac_of_mfma_peak": value / world * flops_per_sample() / 1e12 / PEAK_BF16_TFLOPS,
+            "phases_ms": {k: round(v, 2) for k, v in runner.timers.items()},
+            "loss": loss,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the GPU number must still be reported
+                line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+// k_decode.hip — host-side orchestration of ONE Qwen3 decode step (all layers) in native code.
+// The per-token loop of HF generate (TF:generation/utils.py:2876-2925 -> Qwen3Model.forward TF:qwen3:367-427
+// with a DynamicCache) is ~400 small launches; issuing them from Python costs more than they take to run, so
+// the step is one C-ABI call that enqueues every kernel on the caller's stream.  No device code here.
+#include "bra_device.h"
+#include "bra_api_internal.h"
+#include "../../include/bioreason_hip.h"
+
+namespace {
+
+struct Layer {
+    const void *ln1, *ln2, *qn, *kn, *Wqkv, *Wo, *Wgu, *Wd;
+    const void *A_qkv, *B_qkv, *A_o, *B_o, *A_gu, *B_gu, *A_d, *B_d;   // LoRA images (null = no adapter)
+    int r_qkv, r_o, r_gu, r_d;                                         // padded ranks
+    float s_qkv, s_o, s_gu, s_d;                                       // alpha / r
+    void *kc, *vc;                                                     // KV cache [B, Hkv, Smax, hd]
+};
+
+}  // namespace
+
+extern "C" int bra_qwen_layer_desc_size(void) { return (int)sizeof(Layer); }
+
+// x, xn, h, hn: [B,H]; qkv: [B,Nq+2Nkv]; q, o: [B,Nq]; gu: [B,2F]; act: [B,F]; t: [B,128]; hid: [B,H]
+extern "C" int bra_qwen_decode_step(const void* layers_host, int L, int B, int H, int Hq, int Hkv, int hd, int F,
+                                    int Smax, float eps, float scale, const void* E, const void* norm_w,
+                                    const float* cosT, const float* sinT, const int* tok, const int* pos,
+                                    const void* kmask, int cur_len, int lora_on, void* x, void* xn, void* qkv, void* q,
+                                    void* o, void* h, void* hn, void* gu, void* act, void* t, float* part_o,
+                                    float* part_ml, void* hid, void* stream) {
+    const Layer* ls = (const Layer*)layers_host;
+    const int Nq = Hq * hd, Nkv = Hkv * hd, Nqkv = Nq + 2 * Nkv;
+    int rc;
+#define CK(call) do { rc = (call); if (rc) return rc; } while (0)
+    CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));
+    // lin: y = in W^T (+ LoRA) (+res)
+    auto lin = [&](const void* in, int K, const void* W, int N, const void* A, const void* Bm, int r, float s,
+                   const void* res, void* out) -> int {
+        if (A && lora_on) {
+            int e = bra_gemm_bf16_nt(in, K, A, K, nullptr, 0, nullptr, 0, 0, t, r, B, r, K, s, nullptr, nullptr, 0, 0, 0, stream);
+            if (e) return e;
+            return bra_gemm_bf16_nt(in, K, W, K, t, r, Bm, r, r, out, N, B, N, K, 1.f, nullptr, res, N, 0, 0, stream);
+        }
+        return bra_gemm_bf16_nt(in, K, W, K, nullptr, 0, nullptr, 0, 0, out, N, B, N, K, 1.f, nullptr, res, N, 0, 0, stream);
+    };
+    for (int li = 0; li < L; ++li) {
+        const Layer& l = ls[li];
+        CK(bra_rmsnorm_fwd(x, H, l.ln1, xn, H, nullptr, B, H, eps, stream));
+        CK(lin(xn, H, l.Wqkv, Nqkv, l.A_qkv, l.B_qkv, l.r_qkv, l.s_qkv, nullptr, qkv));
+        // q -> [B,1,Hq,hd]; k,v appended to the cache at sequence index cur_len
+        CK(bra_qk_norm_rope_fwd(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, B, 1, Hq, Hkv, hd, eps, 1.f, q, (long)Nq, (long)Nq,
+                                (long)hd, l.kc, (long)Hkv * Smax * hd, (long)hd, (long)Smax * hd, l.vc, (long)Hkv * Smax * hd,
+                                (long)hd, (long)Smax * hd, cur_len, stream));
+        CK(bra_attn_decode(q, l.kc, l.vc, kmask, part_o, part_ml, o, B, Hq, Hkv, hd, Smax, cur_len + 1, scale, stream));
+        CK(lin(o, Nq, l.Wo, H, l.A_o, l.B_o, l.r_o, l.s_o, x, h));
+        CK(bra_rmsnorm_fwd(h, H, l.ln2, hn, H, nullptr, B, H, eps, stream));
+        CK(lin(hn, H, l.Wgu, 2 * F, l.A_gu, l.B_gu, l.r_gu, l.s_gu, nullptr, gu));
+        CK(bra_swiglu_fwd(gu, 2 * F, act, F, B, F, stream));
+        CK(lin(act, F, l.Wd, H, l.A_d, l.B_d, l.r_d, l.s_d, h, x));
+    }
+    CK(bra_rmsnorm_fwd(x, H, norm_w, hid, H, nullptr, B, H, eps, stream));
+#undef CK
+    return 0;
+}

@@ -267,6 +267,78 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Skinny GEMM for decode (M <= 16 rows): y[M,N] = alpha*(x W^T + x2 W2^T) (+bias)(+res).
+// HBM-bound weight streaming: a workgroup owns 16 output columns; its 4 waves interleave over K in
+// 32-deep steps (wave w takes steps w, w+4, ...: one round of the 4 waves reads 256 contiguous bytes of
+// each of the 16 weight rows), every lane issues one 16-byte weight load per step straight into the
+// MFMA A-fragment (no LDS round trip for data that is used once) with 8 steps in flight; x (M x K, a few
+// KB, L2-resident) is read the same way as the B-fragment with rows clamped to M-1.  The four partial
+// 16x16 tiles are combined through LDS.
+template <int OUTF32>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+    __shared__ float red[4][64][4];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = (int)blockIdx.x * 16;
+    int rn = n0 + fr; rn = rn < g.N ? rn : g.N - 1;
+    int rm = fr < g.M ? fr : g.M - 1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+        const bf16_t* wp = g.B + (long)rn * g.ldb + fq * 8;
+        const bf16_t* xp = g.A + (long)rm * g.lda + fq * 8;
+        const int nk = g.K / 32;
+        int kt = wave;
+        for (; kt + 28 < nk; kt += 32) {            // 8 steps of this wave in flight
+            u32x4 w[8], x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { w[u] = ld16(wp + (long)(kt + 4 * u) * 32); x[u] = ld16(xp + (long)(kt + 4 * u) * 32); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = mfma_16x16x32(w[u], x[u], acc);
+        }
+        for (; kt < nk; kt += 4) acc = mfma_16x16x32(ld16(wp + (long)kt * 32), ld16(xp + (long)kt * 32), acc);
+    }
+    if (g.K2 > 0) {
+        const bf16_t* wp = g.B2 + (long)rn * g.ldb2 + fq * 8;
+        const bf16_t* xp = g.A2 + (long)rm * g.lda2 + fq * 8;
+        const int nk = g.K2 / 32;
+        for (int kt = wave; kt < nk; kt += 4) acc = mfma_16x16x32(ld16(wp + (long)kt * 32), ld16(xp + (long)kt * 32), acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
+    __syncthreads();
+    if (wave != 0) return;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (red[0][lane][r] + red[1][lane][r] + red[2][lane][r] + red[3][lane][r]) * g.alpha;
+    // lane holds D[n = n0 + 4*fq + r][m = fr]
+    const int m = fr, n = n0 + 4 * fq;
+    if (m >= g.M || n >= g.N) return;
+    if (g.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += bf2f(g.bias[n + r]);
+    }
+    if (OUTF32) {
+        float* cp = (float*)g.C + (long)m * g.ldc + n;
+        for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = g.accumulate ? cp[r] + v[r] : v[r];
+    } else {
+        if (g.res) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] = round_bf(v[r]) + bf2f(g.res[(long)m * g.ldres + n + r]);
+        }
+        bf16_t* cp = (bf16_t*)g.C + (long)m * g.ldc + n;
+        if (n + 3 < g.N) { u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); st8(cp, o); }
+        else for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = f2bf(v[r]);
+    }
+}
+
+static int launch_skinny(const GemmArgs& g, int out_f32, bra_stream_t stream) {
+    const int grid = (g.N + 15) / 16;
+    if (out_f32) BRA_LAUNCH((gemm_skinny_kernel<1>), dim3(grid), dim3(256), 0, stream, g);
+    else BRA_LAUNCH((gemm_skinny_kernel<0>), dim3(grid), dim3(256), 0, stream, g);
+    return BRA_LAUNCH_STATUS();
+}
+
 template <int BK, int EPI>
 static int launch_gemm(const GemmArgs& g, bra_stream_t stream) {
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
@@ -309,10 +381,9 @@ extern "C" int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb
     int e = check_common(g);
     if (e) return e;
     if (!C || ldc % 4) return BRA_ERR_ARG;
-    if (out_f32) {
-        if (res) return BRA_ERR_ARG;
-        return dispatch_bk<EPI_F32>(g, (bra_stream_t)stream);
-    }
+    if (out_f32 && res) return BRA_ERR_ARG;
+    if (M <= 16) return launch_skinny(g, out_f32, (bra_stream_t)stream);   // decode: weight-streaming kernel
+    if (out_f32) return dispatch_bk<EPI_F32>(g, (bra_stream_t)stream);
     return dispatch_bk<EPI_BF16>(g, (bra_stream_t)stream);
 }
 

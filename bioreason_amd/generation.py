@@ -13,11 +13,13 @@ counter on the device.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional
 
 import torch
 
 from . import ops
+from ._lib import current_stream, get_lib
 from .engine import BF16, QwenEngine, SeqMeta
 
 
@@ -44,9 +46,59 @@ def prefill(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, ca
     return ops.rmsnorm_fwd(xl, eng.norm_w, eng.eps)
 
 
+class _LayerDesc(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("ln1", "ln2", "qn", "kn", "Wqkv", "Wo", "Wgu", "Wd", "A_qkv", "B_qkv", "A_o",
+                                                "B_o", "A_gu", "B_gu", "A_d", "B_d")]
+                + [(n, ctypes.c_int) for n in ("r_qkv", "r_o", "r_gu", "r_d")]
+                + [(n, ctypes.c_float) for n in ("s_qkv", "s_o", "s_gu", "s_d")]
+                + [("kc", ctypes.c_void_p), ("vc", ctypes.c_void_p)])
+
+
+class DecodeState:
+    """Host descriptor table + device workspaces for `bra_qwen_decode_step` (one native call per token)."""
+
+    def __init__(self, model, cache: KVCache, B: int):
+        eng: QwenEngine = model.engine
+        dev = eng.device
+        self.eng, self.cache, self.B = eng, cache, B
+        arr = (_LayerDesc * eng.L)()
+        for i, L in enumerate(eng.layers):
+            d = arr[i]
+            d.ln1, d.ln2, d.qn, d.kn = L.ln1.data_ptr(), L.ln2.data_ptr(), L.qn.data_ptr(), L.kn.data_ptr()
+            d.Wqkv, d.Wo, d.Wgu, d.Wd = L.Wqkv.data_ptr(), L.Wo.data_ptr(), L.Wgu.data_ptr(), L.Wd.data_ptr()
+            for g in ("qkv", "o", "gu", "d"):
+                G = L.lora[g]
+                setattr(d, "A_" + g, G.A.data_ptr() if G is not None else None)
+                setattr(d, "B_" + g, G.B.data_ptr() if G is not None else None)
+                setattr(d, "r_" + g, G.r_pad if G is not None else 0)
+                setattr(d, "s_" + g, G.scaling if G is not None else 0.0)
+            d.kc, d.vc = cache.k[i].data_ptr(), cache.v[i].data_ptr()
+        self.arr = arr
+        nq, nqkv = eng.Nq, eng.Nq + 2 * eng.Nkv
+
+        def buf(n):
+            return torch.empty((B, n), dtype=BF16, device=dev)
+
+        self.x, self.xn, self.h, self.hn, self.hid = buf(eng.H), buf(eng.H), buf(eng.H), buf(eng.H), buf(eng.H)
+        self.qkv, self.q, self.o = buf(nqkv), buf(nq), buf(nq)
+        self.gu, self.act, self.t = buf(2 * eng.F), buf(eng.F), buf(128)
+        nch = (cache.Smax + 127) // 128
+        self.part_o = torch.empty((B, eng.Hq, nch, eng.hd), dtype=torch.float32, device=dev)
+        self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
+        self.cosT, self.sinT = eng.rope(cache.Smax + 1)
+
+    def step(self, tok, pos, kmask, cur_len: int, lora_on: bool):
+        e = self.eng
+        get_lib().call("bra_qwen_decode_step", ctypes.addressof(self.arr), e.L, self.B, e.H, e.Hq, e.Hkv, e.hd, e.F,
+                       self.cache.Smax, e.eps, e.scale, e.E, e.norm_w, self.cosT, self.sinT, tok, pos, kmask, cur_len,
+                       int(lora_on), self.x, self.xn, self.qkv, self.q, self.o, self.h, self.hn, self.gu, self.act, self.t,
+                       self.part_o, self.part_ml, self.hid, current_stream(self.x))
+        return self.hid
+
+
 @torch.no_grad()
 def decode_step(model, tok: torch.Tensor, cache: KVCache, kmask: torch.Tensor, pos: torch.Tensor, cur_len: int):
-    """One new token per sequence: tok int32 [B] -> final hidden [B, H].  `cur_len` = cached positions so far."""
+    """(Python-orchestrated variant, kept for tests) tok int32 [B] -> final hidden [B, H]."""
     eng: QwenEngine = model.engine
     on = model._lora_enabled
     B = tok.shape[0]
@@ -75,7 +127,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
              do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
              eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None, seed: int = 0,
              check_every: int = 16, return_full_length: bool = False,
-             force_tokens: Optional[torch.Tensor] = None) -> torch.Tensor:
+             force_tokens: Optional[torch.Tensor] = None, native_step: bool = True) -> torch.Tensor:
     """`force_tokens` [B, max_new_tokens] (optional): teacher forcing — the model's own choice is still recorded
     in the output, but the given token is fed back (used to compare decodes position by position)."""
     eng = model.ensure_packed()
@@ -100,6 +152,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     step_t = torch.zeros((1,), dtype=torch.int32, device=dev)
     logits = torch.empty((B, eng.V), dtype=torch.float32, device=dev)
     n_done = max_new_tokens
+    state = DecodeState(model, cache, B) if native_step else None
     for t in range(max_new_tokens):
         ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
         ops.sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished if eos >= 0 else None, pad,
@@ -111,7 +164,10 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             break
         if force_tokens is not None:
             cur = force_tokens[:, t].to(torch.int32).contiguous()
-        hid = decode_step(model, cur, cache, kmask, next_pos, P + t)
+        if state is not None:
+            hid = state.step(cur, next_pos, kmask, P + t, model._lora_enabled)
+        else:
+            hid = decode_step(model, cur, cache, kmask, next_pos, P + t)
         next_pos += 1
         step_t += 1
     out = tokens[:, :n_done]

@@ -60,12 +60,39 @@ def gemm_nt(
     if res is not None:
         res = _as2d(res)
         assert res.shape == (M, N) and res.dtype == BF16
+    prof = GEMM_PROFILE
+    timed = prof is not None and M >= prof.min_m and a.is_cuda
+    if timed:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     get_lib().call(
         "bra_gemm_bf16_nt", a, _ld(a), b, _ld(b), a2, _ld(a2) if a2 is not None else 0, b2,
         _ld(b2) if b2 is not None else 0, K2, out, _ld(out), M, N, K, alpha, bias, res,
         _ld(res) if res is not None else 0, int(out_f32), int(accumulate), current_stream(a),
     )
+    if timed:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.records.append((2.0 * M * N * K, e0, e1))
     return out
+
+
+class GemmProfile:
+    """bench.py hook: HIP events (on the launch stream) around every large-M launch of the dominant kernel."""
+
+    def __init__(self, min_m: int = 1024):
+        self.min_m = min_m
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        fl = sum(r[0] for r in self.records)
+        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
+        n = len(self.records)
+        return {"launches": n, "flops": fl, "ms": ms, "avg_launch_ms": ms / max(n, 1), "tflops": fl / max(ms, 1e-9) / 1e9}
+
+
+GEMM_PROFILE: Optional[GemmProfile] = None
 
 
 def gemm_nt_splitk(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, split_k: int = 0) -> torch.Tensor:

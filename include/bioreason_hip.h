@@ -110,6 +110,20 @@ int bra_attn_decode_nchunk(int len);
 int bra_attn_decode(const void* q, const void* kc, const void* vc, const void* kmask, float* part_o, float* part_ml,
                     void* o, int B, int Hq, int Hkv, int hd, int Smax, int len, float scale, void* stream);
 
+/* ---- native decode step (k_decode.hip) -------------------------------------------
+ * One token per sequence through all L Qwen3 layers (the body of HF's `_sample` loop,
+ * TF:generation/utils.py:2876-2925 -> TF:qwen3:367-427 with a KV cache), enqueued by native code so the
+ * ~400 launches of a step are not paced by the Python interpreter.  `layers_host` is a HOST array of L
+ * records {ln1, ln2, qn, kn, Wqkv, Wo, Wgu, Wd, A_qkv, B_qkv, A_o, B_o, A_gu, B_gu, A_d, B_d (device ptrs, LoRA
+ * ones may be null); int r_qkv, r_o, r_gu, r_d; float s_qkv, s_o, s_gu, s_d; kc, vc}; the rest are device
+ * pointers to caller-owned workspaces.  Writes the final-normed hidden rows [B, H] to `hid`. */
+int bra_qwen_layer_desc_size(void);
+int bra_qwen_decode_step(const void* layers_host, int L, int B, int H, int Hq, int Hkv, int hd, int F, int Smax,
+                         float eps, float scale, const void* E, const void* norm_w, const float* cosT,
+                         const float* sinT, const int* tok, const int* pos, const void* kmask, int cur_len,
+                         int lora_on, void* x, void* xn, void* qkv, void* q, void* o, void* h, void* hn, void* gu,
+                         void* act, void* t, float* part_o, float* part_ml, void* hid, void* stream);
+
 /* ---- data movement around the kernels (k_misc.hip) ---------------------------- */
 int bra_head_transpose(const void* x, long sb, long ss, long sh, void* xt, long t_sb, long t_sh, long pitch, int B,
                        int S, int H, int hd, void* stream);

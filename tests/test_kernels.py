@@ -25,7 +25,7 @@ def rnd(*shape, dev, scale=1.0, seed=None):
 
 
 # ----------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("M,N,K,K2", [(128, 128, 64, 0), (200, 96, 128, 64), (130, 260, 32, 32), (1, 8, 64, 0), (257, 136, 192, 0)])
+@pytest.mark.parametrize("M,N,K,K2", [(128, 128, 64, 0), (200, 96, 128, 64), (130, 260, 32, 32), (1, 8, 64, 0), (257, 136, 192, 0), (8, 144, 2560, 64), (16, 40, 96, 0)])
 def test_gemm_nt(backend, M, N, K, K2):
     a, b = rnd(M, K, dev=backend), rnd(N, K, dev=backend)
     a2 = rnd(M, K2, dev=backend) if K2 else None

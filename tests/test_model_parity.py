@@ -154,3 +154,20 @@ def test_greedy_decode_and_logps(backend, name):
     assert rel(l0.self_attn.q_proj.lora_B["default"].weight.grad, ref["grpo_grad_l0_q_B"]) < 0.1
     assert rel(l0.self_attn.q_proj.lora_A["default"].weight.grad, ref["grpo_grad_l0_q_A"]) < 0.1
     assert rel(m.dna_projection.weight.grad, ref["grpo_grad_proj_w"]) < 0.1
+
+
+def test_native_decode_step_equals_python_orchestration(backend):
+    """bra_qwen_decode_step (native launch loop) vs the Python-orchestrated step: same kernels, same tokens."""
+    fix = torch.load(os.path.join(GOLD, "tiny_a.pt"), weights_only=False)
+    cfg = fix["config"]
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    b.pop("labels")
+    kw = dict(max_new_tokens=6, do_sample=True, temperature=0.6, top_k=20, top_p=0.95, eos_token_id=None, seed=3)
+    g1 = m.generate(**b, native_step=True, **kw)
+    g2 = m.generate(**b, native_step=False, **kw)
+    assert torch.equal(g1.cpu(), g2.cpu())
+    with m.text_model.disable_adapter():
+        g3 = m.generate(**b, native_step=True, **kw)
+        g4 = m.generate(**b, native_step=False, **kw)
+    assert torch.equal(g3.cpu(), g4.cpu())
