@@ -581,12 +581,22 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(DecodeArgs a) 
     float m[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) m[g] = kNeg;
+    // validity of the chunk's 128 positions as two wave ballots (no per-key branch: a conditional byte load
+    // inside the unrolled loop serialises the 32 K-row loads behind each other)
+    uint64_t vbits[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int key = s_begin + hh * 64 + lane;
+        bool okk = key < s_end;
+        const uint8_t mb = a.kmask ? a.kmask[(long)b * a.Smax + (okk ? key : s_end - 1)] : (uint8_t)1;
+        vbits[hh] = wave_ballot(okk && mb != 0);
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int key = s_begin + it * KPI + kg;
-        bool ok = key < s_end;
-        const int kc_ = ok ? key : s_end - 1;
-        if (ok && a.kmask) ok = a.kmask[(long)b * a.Smax + key] != 0;
+        const int rel_ = it * KPI + kg;
+        const bool ok = (vbits[rel_ >> 6] >> (rel_ & 63)) & 1ull;
+        const int kc_ = key < s_end ? key : s_end - 1;
         float f[8];
         unpack8(ld16(kb_ + (long)kc_ * HD), f);
 #pragma unroll

@@ -23,8 +23,58 @@ __device__ __forceinline__ float uniform01(uint32_t seed, uint32_t step, uint32_
 
 // One workgroup per sequence.  logits: fp32 [B, V].  Top-k by k rounds of a block-wide arg-max
 // under the strict total order (value desc, index asc) — k <= 64.
+// stage 1 of the sampler: per (row, vocabulary slice) top-k under the order (value desc, index asc); the slice
+// lives in registers, k rounds of a block-wide arg-max.  64 slices per row keep the whole chip busy instead of
+// one workgroup per sequence scanning 152k logits k times.
+constexpr int kSlices = 64;
+__global__ __launch_bounds__(256) void topk_slices_kernel(const float* logits, long ldl, int V, int k, float* cand_v,
+                                                          int* cand_i) {
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    __shared__ int s_win;
+    const int row = (int)blockIdx.y, sl = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (V + kSlices - 1) / kSlices;
+    const int lo = sl * per, hi = (lo + per) < V ? (lo + per) : V;
+    const float* lr = logits + (long)row * ldl;
+    constexpr int EPT = 16;                       // slice <= 4096 elements
+    float v[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = lo + tid + 256 * e;
+        v[e] = i < hi ? lr[i] : -3.0e38f;
+    }
+    for (int round = 0; round < k; ++round) {
+        float bv = -3.0e38f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = lo + tid + 256 * e;
+            if (v[e] > bv) { bv = v[e]; bi = i; }   // e ascending => lowest index among equal values
+        }
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = wave_shfl_xor(bv, m);
+            const int oi = wave_shfl_xor_i(bi, m);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+            const long o = ((long)row * kSlices + sl) * k + round;
+            cand_v[o] = bv;
+            cand_i[o] = bv > -1.0e38f ? bi : 0x7fffffff;
+            s_win = bi;
+        }
+        __syncthreads();
+        const int win = s_win;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) if (lo + tid + 256 * e == win) v[e] = -3.0e38f;
+    }
+}
+
 template <int NT>
-__global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ldl, int V, float temperature,
+__global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ldl, int V, const int* cand_idx, float temperature,
                                                     int top_k, float top_p, int do_sample, uint32_t seed,
                                                     const int* step_ptr, uint8_t* finished, int pad_id,
                                                     int eos_id, int* out_ids, float* out_logp, int* tokens_out,
@@ -41,8 +91,9 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ld
     for (int round = 0; round < k; ++round) {
         float bv = -3.0e38f;
         int bi = 0x7fffffff;
-        for (int i = tid; i < V; i += NT) {
-            const float v = lr[i];
+        for (int j = tid; j < V; j += NT) {
+            const float v = lr[j];
+            const int i = cand_idx ? cand_idx[(long)row * ldl + j] : j;     // original vocabulary index
             // candidates strictly after (last_v, last_i) in the order (value desc, index asc)
             const bool after = (v < last_v) || (v == last_v && i > last_i);
             if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
@@ -186,12 +237,29 @@ __global__ __launch_bounds__(256) void grpo_loss_kernel(const float* logp, const
 
 using namespace bra;
 
+extern "C" int bra_sample_ws_floats(int B, int top_k) {     // workspace size in 4-byte words (values + indices)
+    const int k = top_k > 0 ? (top_k < 64 ? top_k : 64) : 64;
+    return 2 * B * kSlices * k;
+}
+
 extern "C" int bra_sample(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p,
                           int do_sample, unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id,
-                          int* out_ids, float* out_logp, int* tokens_out, long ldt, void* stream) {
+                          int* out_ids, float* out_logp, int* tokens_out, long ldt, void* ws, void* stream) {
     if (B == 0) return 0;
     if (!logits || !out_ids || V <= 0 || (do_sample && temperature <= 0.f)) return BRA_ERR_ARG;
-    BRA_LAUNCH((sample_kernel<1024>), dim3(B), dim3(1024), 0, stream, logits, ldl, V, temperature, top_k, top_p,
+    if (ws && V <= kSlices * 4096 && V >= 4096) {
+        const int k = do_sample ? (top_k > 0 ? (top_k < 64 ? top_k : 64) : 64) : 1;
+        float* cv = (float*)ws;
+        int* ci = (int*)ws + (long)B * kSlices * k;
+        BRA_LAUNCH(topk_slices_kernel, dim3(kSlices, B), dim3(256), 0, stream, logits, ldl, V, k, cv, ci);
+        int r = BRA_LAUNCH_STATUS();
+        if (r) return r;
+        BRA_LAUNCH((sample_kernel<1024>), dim3(B), dim3(1024), 0, stream, (const float*)cv, (long)kSlices * k, kSlices * k,
+                   (const int*)ci, temperature, top_k, top_p, do_sample, (uint32_t)seed, step_ptr, (uint8_t*)finished, pad_id,
+                   eos_id, out_ids, out_logp, tokens_out, ldt);
+        return BRA_LAUNCH_STATUS();
+    }
+    BRA_LAUNCH((sample_kernel<1024>), dim3(B), dim3(1024), 0, stream, logits, ldl, V, (const int*)nullptr, temperature, top_k, top_p,
                do_sample, (uint32_t)seed, step_ptr, (uint8_t*)finished, pad_id, eos_id, out_ids, out_logp, tokens_out, ldt);
     return BRA_LAUNCH_STATUS();
 }

@@ -152,11 +152,13 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     step_t = torch.zeros((1,), dtype=torch.int32, device=dev)
     logits = torch.empty((B, eng.V), dtype=torch.float32, device=dev)
     n_done = max_new_tokens
+    kk = (min(top_k, 64) if top_k > 0 else 64) if do_sample else 1
+    sample_ws = torch.empty((2 * B * 64 * kk,), dtype=torch.float32, device=dev) if eng.V >= 4096 else None
     state = DecodeState(model, cache, B) if native_step else None
     for t in range(max_new_tokens):
         ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
         ops.sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished if eos >= 0 else None, pad,
-                   cur, None, eos_id=eos, tokens_out=tokens)
+                   cur, None, eos_id=eos, tokens_out=tokens, ws=sample_ws)
         if eos >= 0 and force_tokens is None and (t + 1) % check_every == 0 and bool(finished.all().item()):
             n_done = t + 1
             break

@@ -310,11 +310,14 @@ def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- GRPO / optimiser
 def sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished, pad_id, out_ids, out_logp=None,
-           eos_id=-1, tokens_out=None):
+           eos_id=-1, tokens_out=None, ws=None):
     B, V = logits.shape
+    if ws is None and V >= 4096:
+        k = min(top_k, 64) if top_k > 0 else 64
+        ws = torch.empty((2 * B * 64 * k,), dtype=torch.float32, device=logits.device)
     get_lib().call("bra_sample", logits, _ld(logits), B, V, temperature, top_k, top_p, int(do_sample), seed & 0xFFFFFFFF,
                    step_t, finished, pad_id, eos_id, out_ids, out_logp, tokens_out,
-                   tokens_out.stride(0) if tokens_out is not None else 0, current_stream(logits))
+                   tokens_out.stride(0) if tokens_out is not None else 0, ws, current_stream(logits))
     return out_ids
 
 

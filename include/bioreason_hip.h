@@ -163,7 +163,10 @@ int bra_adamw(float* p, const float* g, float* m, float* v, const void* mask, lo
  * receives the token (the [B, C] completion matrix), step_ptr is a device int so a replayed launch advances. */
 int bra_sample(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p,
                int do_sample, unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id,
-               int* out_ids, float* out_logp, int* tokens_out, long ldt, void* stream);
+               int* out_ids, float* out_logp, int* tokens_out, long ldt, void* ws, void* stream);
+/* ws (optional, bra_sample_ws_floats(B, top_k) 4-byte words): enables the two-stage top-k (64 vocabulary slices
+ * per row in parallel, then a merge) instead of one workgroup per row scanning the vocabulary k times */
+int bra_sample_ws_floats(int B, int top_k);
 /* completion mask up to and including the first EOS (grpo_trainer.py:605-609) */
 int bra_eos_mask(const int* ids, int B, int C, int eos_id, int* mask, int* lengths, void* stream);
 /* rewards [N,F] -> sum over F -> (r - mean_group) / (std_group + 1e-4), groups of G (grpo_trainer.py:682-691) */

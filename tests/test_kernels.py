@@ -391,7 +391,7 @@ def test_sampler_greedy_and_topk(backend):
     step = torch.zeros(1, dtype=torch.int32, device=backend)
     T, k, p = 0.6, 20, 0.95
     draws = []
-    for s in range(200):
+    for s in range(200 if backend.type == "cuda" else 80):
         step.fill_(s)
         ops.sample(logits, T, k, p, True, 1234, step, None, 0, out)
         draws.append(out.clone().cpu())
