@@ -790,3 +790,17 @@ extern "C" int bra_attn_decode(const void* q, const void* kc, const void* vc, co
 #undef BRA_DEC
     return BRA_ERR_UNSUPPORTED;
 }
+
+extern "C" int bra_attn_decode_merge(const float* part_o, const float* part_ml, void* o, int B, int Hq, int hd, int nchunk,
+                                     void* stream) {
+    if (B <= 0 || Hq <= 0 || nchunk <= 0 || !part_o || !part_ml || !o) return BRA_ERR_ARG;
+    DecodeArgs a = {};
+    a.part_o = const_cast<float*>(part_o); a.part_ml = const_cast<float*>(part_ml); a.o = (bf16_t*)o;
+    a.B = B; a.Hq = Hq; a.hd = hd; a.nchunk = nchunk;
+    bra_stream_t st = (bra_stream_t)stream;
+    if (hd == 128) BRA_LAUNCH((attn_decode_merge_kernel<128>), dim3(Hq, B), dim3(64), 0, st, a);
+    else if (hd == 64) BRA_LAUNCH((attn_decode_merge_kernel<64>), dim3(Hq, B), dim3(64), 0, st, a);
+    else if (hd == 32) BRA_LAUNCH((attn_decode_merge_kernel<32>), dim3(Hq, B), dim3(64), 0, st, a);
+    else return BRA_ERR_UNSUPPORTED;
+    return BRA_LAUNCH_STATUS();
+}

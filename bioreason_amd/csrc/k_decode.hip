@@ -61,3 +61,33 @@ extern "C" int bra_qwen_decode_step(const void* layers_host, int L, int B, int H
 #undef CK
     return 0;
 }
+
+// Fused variant (k_decfused.hip): 6 launches per layer.  The layer records carry ROLLOUT weights in
+// Wqkv / Wo / Wgu / Wd: LoRA already merged (W + s B A, the same merge PEFT's merge_and_unload performs,
+// reason.py:428-446) and gate/up rows interleaved in blocks of 8 for the SwiGLU epilogue; the LoRA fields are unused.
+// Ends with the final RMSNorm + tied lm_head into fp32 logits [B, V] when `logits` is non-null.
+extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B, int H, int Hq, int Hkv, int hd, int F,
+                                          int Smax, int V, float eps, float scale, const void* E, const void* norm_w,
+                                          const float* cosT, const float* sinT, const int* tok, const int* pos,
+                                          const void* kmask, int cur_len, void* x, void* qkv, void* o, void* h, void* act,
+                                          float* part_o, float* part_ml, float* logits, void* stream) {
+    const Layer* ls = (const Layer*)layers_host;
+    const int Nq = Hq * hd, Nkv = Hkv * hd, Nqkv = Nq + 2 * Nkv;
+    const int nchunk = (cur_len + 1 + 127) / 128;
+    int rc;
+#define CK(call) do { rc = (call); if (rc) return rc; } while (0)
+    CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));
+    for (int li = 0; li < L; ++li) {
+        const Layer& l = ls[li];
+        CK(bra_dec_gemm(x, H, l.ln1, eps, l.Wqkv, H, nullptr, 0, qkv, Nqkv, B, Nqkv, H, 0, 0, stream));
+        CK(bra_dec_attn_partial(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, l.kc, l.vc, kmask, part_o, part_ml, B, Hq, Hkv, hd,
+                                Smax, cur_len, eps, scale, stream));
+        CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, nchunk, stream));
+        CK(bra_dec_gemm(o, Nq, nullptr, 0.f, l.Wo, Nq, x, H, h, H, B, H, Nq, 0, 0, stream));
+        CK(bra_dec_gemm(h, H, l.ln2, eps, l.Wgu, H, nullptr, 0, act, F, B, 2 * F, H, 1, 0, stream));
+        CK(bra_dec_gemm(act, F, nullptr, 0.f, l.Wd, F, h, H, x, H, B, H, F, 0, 0, stream));
+    }
+    if (logits) CK(bra_dec_gemm(x, H, norm_w, eps, E, H, nullptr, 0, logits, V, B, V, H, 0, 1, stream));
+#undef CK
+    return 0;
+}

@@ -97,6 +97,65 @@ class DecodeState:
 
 
 @torch.no_grad()
+def rollout_weights(model):
+    """Per-layer weight set of the fused decode step: LoRA merged into the base weight (W + s B A, rounded to bf16 —
+    the merge PEFT's merge_and_unload performs, reason.py:428-446) when adapters are enabled, and gate/up rows
+    interleaved in blocks of 8 for the SwiGLU epilogue.  Rebuilt when the adapters or base weights changed."""
+    eng: QwenEngine = model.ensure_packed()
+    arena = model.arena
+    key = (model._packed_sig, model._lora_enabled, None if arena is None or arena.params is None else (arena.step_count, arena.params._version))
+    cached = getattr(eng, "_rollout", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    on = model._lora_enabled
+    out = []
+    F = eng.F
+    for L in eng.layers:
+        def merged(W, G):
+            if G is None or not on:
+                return W
+            return ops.gemm_nt(G.B, G.AT, alpha=G.scaling, res=W)
+        wgu = merged(L.Wgu, L.lora["gu"])
+        wgu_il = wgu.view(2, F // 8, 8, wgu.shape[1]).permute(1, 0, 2, 3).reshape(2 * F, wgu.shape[1]).contiguous()
+        out.append({"Wqkv": merged(L.Wqkv, L.lora["qkv"]), "Wo": merged(L.Wo, L.lora["o"]), "Wgu": wgu_il,
+                    "Wd": merged(L.Wd, L.lora["d"])})
+    eng._rollout = (key, out)
+    return out
+
+
+class FusedDecodeState:
+    """Descriptor table + workspaces for `bra_qwen_decode_step_fused` (6 launches per layer, logits included)."""
+
+    def __init__(self, model, cache: KVCache, B: int):
+        eng: QwenEngine = model.engine
+        dev = eng.device
+        self.eng, self.cache, self.B = eng, cache, B
+        self.rw = rollout_weights(model)
+        arr = (_LayerDesc * eng.L)()
+        for i, (L, R) in enumerate(zip(eng.layers, self.rw)):
+            d = arr[i]
+            d.ln1, d.ln2, d.qn, d.kn = L.ln1.data_ptr(), L.ln2.data_ptr(), L.qn.data_ptr(), L.kn.data_ptr()
+            d.Wqkv, d.Wo, d.Wgu, d.Wd = R["Wqkv"].data_ptr(), R["Wo"].data_ptr(), R["Wgu"].data_ptr(), R["Wd"].data_ptr()
+            d.kc, d.vc = cache.k[i].data_ptr(), cache.v[i].data_ptr()
+        self.arr = arr
+
+        def buf(n):
+            return torch.empty((B, n), dtype=BF16, device=dev)
+
+        self.x, self.h, self.qkv, self.o, self.act = buf(eng.H), buf(eng.H), buf(eng.Nq + 2 * eng.Nkv), buf(eng.Nq), buf(eng.F)
+        nch = (cache.Smax + 127) // 128
+        self.part_o = torch.empty((B, eng.Hq, nch, eng.hd), dtype=torch.float32, device=dev)
+        self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
+        self.cosT, self.sinT = eng.rope(cache.Smax + 1)
+
+    def step(self, tok, pos, kmask, cur_len: int, logits: torch.Tensor):
+        e = self.eng
+        get_lib().call("bra_qwen_decode_step_fused", ctypes.addressof(self.arr), e.L, self.B, e.H, e.Hq, e.Hkv, e.hd, e.F,
+                       self.cache.Smax, e.V, e.eps, e.scale, e.E, e.norm_w, self.cosT, self.sinT, tok, pos, kmask, cur_len,
+                       self.x, self.qkv, self.o, self.h, self.act, self.part_o, self.part_ml, logits, current_stream(self.x))
+
+
+@torch.no_grad()
 def decode_step(model, tok: torch.Tensor, cache: KVCache, kmask: torch.Tensor, pos: torch.Tensor, cur_len: int):
     """(Python-orchestrated variant, kept for tests) tok int32 [B] -> final hidden [B, H]."""
     eng: QwenEngine = model.engine
@@ -127,7 +186,8 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
              do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
              eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None, seed: int = 0,
              check_every: int = 16, return_full_length: bool = False,
-             force_tokens: Optional[torch.Tensor] = None, native_step: bool = True) -> torch.Tensor:
+             force_tokens: Optional[torch.Tensor] = None, native_step: bool = True,
+             decode_impl: str = "fused") -> torch.Tensor:
     """`force_tokens` [B, max_new_tokens] (optional): teacher forcing — the model's own choice is still recorded
     in the output, but the given token is fed back (used to compare decodes position by position)."""
     eng = model.ensure_packed()
@@ -154,9 +214,10 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     n_done = max_new_tokens
     kk = (min(top_k, 64) if top_k > 0 else 64) if do_sample else 1
     sample_ws = torch.empty((2 * B * 64 * kk,), dtype=torch.float32, device=dev) if eng.V >= 4096 else None
-    state = DecodeState(model, cache, B) if native_step else None
+    fused = native_step and decode_impl == "fused"
+    state = (FusedDecodeState(model, cache, B) if fused else DecodeState(model, cache, B)) if native_step else None
+    ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
     for t in range(max_new_tokens):
-        ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
         ops.sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished if eos >= 0 else None, pad,
                    cur, None, eos_id=eos, tokens_out=tokens, ws=sample_ws)
         if eos >= 0 and force_tokens is None and (t + 1) % check_every == 0 and bool(finished.all().item()):
@@ -166,10 +227,14 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             break
         if force_tokens is not None:
             cur = force_tokens[:, t].to(torch.int32).contiguous()
-        if state is not None:
-            hid = state.step(cur, next_pos, kmask, P + t, model._lora_enabled)
+        if fused:
+            state.step(cur, next_pos, kmask, P + t, logits)
         else:
-            hid = decode_step(model, cur, cache, kmask, next_pos, P + t)
+            if state is not None:
+                hid = state.step(cur, next_pos, kmask, P + t, model._lora_enabled)
+            else:
+                hid = decode_step(model, cur, cache, kmask, next_pos, P + t)
+            ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
         next_pos += 1
         step_t += 1
     out = tokens[:, :n_done]

@@ -124,6 +124,27 @@ int bra_qwen_decode_step(const void* layers_host, int L, int B, int H, int Hq, i
                          int lora_on, void* x, void* xn, void* qkv, void* q, void* o, void* h, void* hn, void* gu,
                          void* act, void* t, float* part_o, float* part_ml, void* hid, void* stream);
 
+/* Fused decode kernels (k_decfused.hip) and the 6-launch-per-layer step built from them.
+ * bra_dec_gemm: out[M<=16, N] = rmsnorm(x; norm_w, eps) W^T (+res); act=1: W rows are [8 gate | 8 up] blocks and the
+ *   output is silu(gate)*up [M, N/2] (Qwen3MLP TF:qwen3:81-83); out_f32: fp32 logits (tied lm_head TF:qwen3:495).
+ * bra_dec_attn_partial: per-head q/k RMSNorm + RoPE of the new token (TF:qwen3:252-256), append of its K/V row at
+ *   index cur_len, chunked attention over [0, cur_len]; bra_attn_decode_merge combines the chunk partials.
+ * bra_qwen_decode_step_fused: layer records carry rollout weights (LoRA merged as PEFT merge_and_unload does,
+ *   reason.py:428-446; gate/up row-interleaved); writes fp32 logits [B, V] if `logits` is non-null. */
+int bra_dec_gemm(const void* x, long ldx, const void* norm_w, float eps, const void* W, long ldw, const void* res,
+                 long ldres, void* out, long ldo, int M, int N, int K, int act, int out_f32, void* stream);
+int bra_dec_attn_partial(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT,
+                         const float* sinT, const int* pos, void* kc, void* vc, const void* kmask, float* part_o,
+                         float* part_ml, int B, int Hq, int Hkv, int hd, int Smax, int cur_len, float eps, float scale,
+                         void* stream);
+int bra_attn_decode_merge(const float* part_o, const float* part_ml, void* o, int B, int Hq, int hd, int nchunk,
+                          void* stream);
+int bra_qwen_decode_step_fused(const void* layers_host, int L, int B, int H, int Hq, int Hkv, int hd, int F, int Smax,
+                               int V, float eps, float scale, const void* E, const void* norm_w, const float* cosT,
+                               const float* sinT, const int* tok, const int* pos, const void* kmask, int cur_len,
+                               void* x, void* qkv, void* o, void* h, void* act, float* part_o, float* part_ml,
+                               float* logits, void* stream);
+
 /* ---- data movement around the kernels (k_misc.hip) ---------------------------- */
 int bra_head_transpose(const void* x, long sb, long ss, long sh, void* xt, long t_sb, long t_sh, long pitch, int B,
                        int S, int H, int hd, void* stream);

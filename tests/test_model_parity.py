@@ -171,3 +171,27 @@ def test_native_decode_step_equals_python_orchestration(backend):
         g3 = m.generate(**b, native_step=True, **kw)
         g4 = m.generate(**b, native_step=False, **kw)
     assert torch.equal(g3.cpu(), g4.cpu())
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b"])
+@pytest.mark.parametrize("lora", [False, True])
+def test_fused_decode_step_matches_unfused(backend, name, lora):
+    """The 6-launch fused decode step (RMSNorm / RoPE / KV-append / SwiGLU folded into the GEMM and attention kernels,
+    LoRA merged into rollout weights) against the op-by-op step: same tokens under teacher forcing, except where the
+    unfused path's own logit margin is inside bf16 noise; logits within bf16 tolerance."""
+    from bioreason_amd import generation
+    fix = torch.load(os.path.join(GOLD, f"{name}.pt"), weights_only=False)
+    cfg = fix["config"]
+    m = build(fix, backend, lora)
+    b = to_dev(fix["batch"], backend)
+    b.pop("labels")
+    want = fix["fp32_lora" if lora else "fp32"]["greedy_ids"].to(backend)
+    kw = dict(max_new_tokens=cfg["gen_tokens"], do_sample=False, eos_token_id=None, force_tokens=want)
+    g_f = m.generate(**b, decode_impl="fused", **kw)
+    g_u = m.generate(**b, decode_impl="unfused", **kw)
+    scores = fix["fp32_lora" if lora else "fp32"]["greedy_scores"]
+    diff = (g_f != g_u).nonzero().tolist()
+    for bi, t in diff:
+        a, c = int(g_f[bi, t]), int(g_u[bi, t])
+        assert abs((scores[bi, t, a] - scores[bi, t, c]).item()) < 0.02 * scores[bi, t].abs().max().item() + 0.05
+    assert len(diff) <= 2
