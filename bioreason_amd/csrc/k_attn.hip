@@ -659,19 +659,41 @@ __global__ __launch_bounds__(64) void attn_decode_merge_kernel(DecodeArgs a) {
     const int lane = lane_id();
     const int hq = (int)blockIdx.x, b = (int)blockIdx.y;
     const long base = ((long)b * a.Hq + hq) * a.nchunk;
+    // lane c holds the (max, sum) pair of chunk c (+64, ...): one round of loads, then wave reductions
+    float mc[4], lc[4];
     float m = kNeg;
-    for (int c = 0; c < a.nchunk; ++c) m = fmaxf(m, a.part_ml[(base + c) * 2]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = lane + 64 * r;
+        mc[r] = c < a.nchunk ? a.part_ml[(base + c) * 2] : kNeg;
+        lc[r] = c < a.nchunk ? a.part_ml[(base + c) * 2 + 1] : 0.f;
+        m = fmaxf(m, mc[r]);
+    }
+    m = wave_max<64>(m);
     float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mc[r] = exp2f(mc[r] - m); l += lc[r] * mc[r]; }     // mc now holds the chunk weight
+    l = wave_sum<64>(l);
     constexpr int EPL = HD / 64 > 0 ? HD / 64 : 1;
     float acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    for (int c = 0; c < a.nchunk; ++c) {
-        const float w = exp2f(a.part_ml[(base + c) * 2] - m);
-        l += a.part_ml[(base + c) * 2 + 1] * w;
-        if (lane * EPL < HD)
+    const int nc = a.nchunk < 256 ? a.nchunk : 256;
+    for (int c0 = 0; c0 < nc; c0 += 8) {
+        float v[8][EPL], w[8];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[e] += a.part_o[(base + c) * HD + lane * EPL + e] * w;
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            const int cc = c < nc ? c : nc - 1;
+            const float wsel = (cc >> 6) == 0 ? mc[0] : ((cc >> 6) == 1 ? mc[1] : ((cc >> 6) == 2 ? mc[2] : mc[3]));
+            w[u] = c < nc ? wave_shfl(wsel, cc & 63) : 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[u][e] = (lane * EPL < HD) ? a.part_o[(base + cc) * HD + lane * EPL + e] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] += v[u][e] * w[u];
     }
     const float inv = l > 0.f ? 1.f / l : 0.f;
     if (lane * EPL < HD)

@@ -29,44 +29,66 @@ struct DecGemmArgs {
 
 __device__ __forceinline__ float silu_d(float x) { return x / (1.f + __expf(-x)); }
 
-template <int NORM, int ACT, int OUTF32>
+// NCOL = output columns per workgroup: 16, or 8 (upper half of the MFMA tile idle) so that N = 2048 projections
+// still put a workgroup on every one of the 256 CUs (HBM streaming is per-CU latency bound at this size)
+template <int NORM, int ACT, int OUTF32, int NCOL>
 __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs g) {
     BRA_DYN_SMEM(smem);                       // NORM: normalised x rows, bf16 [M][K + 8]
     __shared__ float red[4][64][4];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = (int)blockIdx.x * 16;
+    const int n0 = (int)blockIdx.x * NCOL;
     const int rm = fr < g.M ? fr : g.M - 1;
     const long xpitch = g.K + 8;
+    const bool wlive = fr < NCOL;                 // lanes that stream a weight row
     if (NORM) {
-        // 16 threads per row: sum of squares, then the normalised row into LDS
-        const int r = tid >> 4, sub = tid & 15;
-        const bool live = r < g.M;
-        const bf16_t* xr = g.x + (long)(live ? r : 0) * g.ldx;
-        float ss = 0.f;
-        for (int c = sub * 8; c < g.K; c += 128) {
-            float f[8];
-            unpack8(ld16(xr + c), f);
+        // thread t owns 16-byte column chunk j = t, t+256, .. of EVERY row: all row loads of a chunk are issued
+        // together (one memory latency), the per-row sums of squares are combined across the block through LDS
+        __shared__ float ssq[4][16];
+        float ss[16];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
+        for (int r = 0; r < 16; ++r) ss[r] = 0.f;
+        const int nch = g.K / 8;
+        for (int j = tid; j < nch; j += 256) {
+            u32x4 xr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (r < g.M) xr[r] = ld16(g.x + (long)r * g.ldx + j * 8);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (r < g.M) {
+                float f[8];
+                unpack8(xr[r], f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ss[r] += f[i] * f[i];
+            }
         }
-        ss += wave_shfl_xor(ss, 8); ss += wave_shfl_xor(ss, 4); ss += wave_shfl_xor(ss, 2); ss += wave_shfl_xor(ss, 1);
-        const float rstd = rsqrtf(ss / (float)g.K + g.eps);
-        if (live) {
-            bf16_t* dst = reinterpret_cast<bf16_t*>(smem) + (long)r * xpitch;
-            for (int c = sub * 8; c < g.K; c += 128) {
-                float f[8], w[8];
-                unpack8(ld16(xr + c), f);
-                unpack8(ld16(g.nw + c), w);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) if (r < g.M) ss[r] = wave_sum<64>(ss[r]);      // g.M is wave-uniform
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ssq[wave][r] = ss[r];
+        }
+        __syncthreads();
+        for (int j = tid; j < nch; j += 256) {
+            float w[8];
+            unpack8(ld16(g.nw + j * 8), w);
+            u32x4 xr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (r < g.M) xr[r] = ld16(g.x + (long)r * g.ldx + j * 8);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (r < g.M) {
+                const float rstd = rsqrtf((ssq[0][r] + ssq[1][r] + ssq[2][r] + ssq[3][r]) / (float)g.K + g.eps);
+                float f[8];
+                unpack8(xr[r], f);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) f[i] = w[i] * round_bf(f[i] * rstd);
-                st16(dst + c, pack8(f));
+                st16(reinterpret_cast<bf16_t*>(smem) + (long)r * xpitch + j * 8, pack8(f));
             }
         }
         __syncthreads();
     }
-    int rn = n0 + fr; rn = rn < g.N ? rn : g.N - 1;
+    int rn = n0 + (wlive ? fr : 0); rn = rn < g.N ? rn : g.N - 1;
     const bf16_t* wp = g.W + (long)rn * g.ldw + fq * 8;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const bf16_t* xg = g.x + (long)rm * g.ldx + fq * 8;
     const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem) + (long)rm * xpitch + fq * 8;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -75,7 +97,7 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs g) {
     for (; kt + 28 < nk; kt += 32) {
         u32x4 w[8], x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = ld16(wp + (long)(kt + 4 * u) * 32);
+        for (int u = 0; u < 8; ++u) w[u] = (NCOL == 16 || wlive) ? ld16(wp + (long)(kt + 4 * u) * 32) : zero4;
         if (!NORM) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) x[u] = ld16(xg + (long)(kt + 4 * u) * 32);
@@ -89,7 +111,7 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs g) {
         for (int u = 0; u < 8; ++u) acc = mfma_16x16x32(w[u], x[u], acc);
     }
     for (; kt < nk; kt += 4) {
-        const u32x4 w = ld16(wp + (long)kt * 32);
+        const u32x4 w = (NCOL == 16 || wlive) ? ld16(wp + (long)kt * 32) : zero4;
         const u32x4 x = NORM ? ld16(xs + (long)kt * 32) : ld16(xg + (long)kt * 32);
         acc = mfma_16x16x32(w, x, acc);
     }
@@ -118,7 +140,7 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs g) {
         return;
     }
     const int n = n0 + 4 * fq;
-    if (m >= g.M || n >= g.N) return;
+    if (m >= g.M || n >= g.N || 4 * fq >= NCOL) return;
     if (OUTF32) {
         float* cp = (float*)g.out + (long)m * g.ldo + n;
         for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = v[r];
@@ -185,6 +207,15 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
     s_end = s_end < len ? s_end : len;
     const int kg = lane / LPK, dl = lane % LPK;
     const int Nq = a.Hq * HD, Nkv = a.Hkv * HD;
+    // the first half of the chunk's K rows is requested before anything else: its latency hides the q/k prologue
+    bf16_t* kb_ = a.kc + ((long)b * a.Hkv + hkv) * a.Smax * HD + dl * 8;
+    bf16_t* vb_ = a.vc + ((long)b * a.Hkv + hkv) * a.Smax * HD + dl * 8;
+    u32x4 ra[GRP], rb[GRP];
+#pragma unroll
+    for (int i = 0; i < GRP; ++i) {
+        const int key = s_begin + i * KPI + kg;
+        ra[i] = ld16(kb_ + (long)(key < s_end ? key : s_end - 1) * HD);
+    }
     const bf16_t* row = a.qkv + (long)b * a.ldqkv;
     const int p = a.pos[b];
     const float* cosr = a.cosT + (long)p * (HD / 2);
@@ -204,8 +235,6 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
     unpack8(ld16(row + Nq + (long)hkv * HD + dl * 8), kn);
     norm_rope_slice<HD>(kn, a.kw, cosr, sinr, dl, a.eps);
     unpack8(ld16(row + Nq + Nkv + (long)hkv * HD + dl * 8), vn);
-    bf16_t* kb_ = a.kc + ((long)b * a.Hkv + hkv) * a.Smax * HD + dl * 8;
-    bf16_t* vb_ = a.vc + ((long)b * a.Hkv + hkv) * a.Smax * HD + dl * 8;
     const bool owns_new = a.cur_len >= s_begin && a.cur_len < s_begin + CK;
     if (owns_new && kg == 0) {
         st16(kb_ + (long)a.cur_len * HD, pack8(kn));
@@ -225,22 +254,22 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
     float m[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) m[g] = kNegD;
+    // software pipeline over the two halves: K1 is requested before K0 is consumed, V0 before K1 is consumed, ...
+#pragma unroll
+    for (int i = 0; i < GRP; ++i) {
+        const int key = s_begin + (GRP + i) * KPI + kg;
+        rb[i] = ld16(kb_ + (long)(key < s_end ? key : s_end - 1) * HD);
+    }
+    sched_fence();
 #pragma unroll
     for (int grp = 0; grp < 2; ++grp) {
-        u32x4 kr[GRP];
-#pragma unroll
-        for (int i = 0; i < GRP; ++i) {
-            const int key = s_begin + (grp * GRP + i) * KPI + kg;
-            kr[i] = ld16(kb_ + (long)(key < s_end ? key : s_end - 1) * HD);
-        }
-        sched_fence();
 #pragma unroll
         for (int i = 0; i < GRP; ++i) {
             const int it = grp * GRP + i;
             const int rel_ = it * KPI + kg;
             const bool ok = (vbits[rel_ >> 6] >> (rel_ & 63)) & 1ull;
             float f[8];
-            unpack8(kr[i], f);
+            unpack8(grp == 0 ? ra[i] : rb[i], f);
             if (rel_ == new_rel) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = kn[e];
@@ -257,6 +286,15 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
                 m[g] = fmaxf(m[g], d);
             }
         }
+        sched_fence();
+        // the registers this half's K rows just vacated receive its V rows
+#pragma unroll
+        for (int i = 0; i < GRP; ++i) {
+            const int key = s_begin + (grp * GRP + i) * KPI + kg;
+            const u32x4 vv = ld16(vb_ + (long)(key < s_end ? key : s_end - 1) * HD);
+            if (grp == 0) ra[i] = vv; else rb[i] = vv;
+        }
+        sched_fence();
     }
     float l[G], acc[G][8];
 #pragma unroll
@@ -269,19 +307,12 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
     }
 #pragma unroll
     for (int grp = 0; grp < 2; ++grp) {
-        u32x4 vr[GRP];
-#pragma unroll
-        for (int i = 0; i < GRP; ++i) {
-            const int key = s_begin + (grp * GRP + i) * KPI + kg;
-            vr[i] = ld16(vb_ + (long)(key < s_end ? key : s_end - 1) * HD);
-        }
-        sched_fence();
 #pragma unroll
         for (int i = 0; i < GRP; ++i) {
             const int it = grp * GRP + i;
             const int rel_ = it * KPI + kg;
             float f[8];
-            unpack8(vr[i], f);
+            unpack8(grp == 0 ? ra[i] : rb[i], f);
             if (rel_ == new_rel) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = round_bf(vn[e]);
@@ -327,17 +358,25 @@ extern "C" int bra_dec_gemm(const void* x, long ldx, const void* norm_w, float e
     if (out_f32 && res) return BRA_ERR_ARG;
     DecGemmArgs g = {(const bf16_t*)x, ldx, (const bf16_t*)norm_w, eps, (const bf16_t*)W, ldw, (const bf16_t*)res, ldres, out, ldo, M, N, K};
     bra_stream_t st = (bra_stream_t)stream;
-    const dim3 grid((N + 15) / 16), blk(256);
+    const dim3 blk(256);
+    const bool narrow = !act && (N + 15) / 16 < 256 && N % 8 == 0;        // fewer than one workgroup per CU: 8-column tiles
+    const dim3 grid(narrow ? (N + 7) / 8 : (N + 15) / 16);
+#define BRA_DG(NORM_, ACT_, F32_, NCOL_, SMEM_)                                                        \
+    do {                                                                                               \
+        BRA_ALLOW_SMEM((dec_gemm_kernel<NORM_, ACT_, F32_, NCOL_>), SMEM_);                            \
+        BRA_LAUNCH((dec_gemm_kernel<NORM_, ACT_, F32_, NCOL_>), grid, blk, SMEM_, st, g);              \
+    } while (0)
+    const size_t smem = norm_w ? (size_t)M * (K + 8) * 2 : 0;
     if (norm_w) {
-        const size_t smem = (size_t)M * (K + 8) * 2;
-        if (act) { BRA_ALLOW_SMEM((dec_gemm_kernel<1, 1, 0>), smem); BRA_LAUNCH((dec_gemm_kernel<1, 1, 0>), grid, blk, smem, st, g); }
-        else if (out_f32) { BRA_ALLOW_SMEM((dec_gemm_kernel<1, 0, 1>), smem); BRA_LAUNCH((dec_gemm_kernel<1, 0, 1>), grid, blk, smem, st, g); }
-        else { BRA_ALLOW_SMEM((dec_gemm_kernel<1, 0, 0>), smem); BRA_LAUNCH((dec_gemm_kernel<1, 0, 0>), grid, blk, smem, st, g); }
+        if (act) BRA_DG(1, 1, 0, 16, smem);
+        else if (out_f32) { if (narrow) BRA_DG(1, 0, 1, 8, smem); else BRA_DG(1, 0, 1, 16, smem); }
+        else { if (narrow) BRA_DG(1, 0, 0, 8, smem); else BRA_DG(1, 0, 0, 16, smem); }
     } else {
-        if (act) BRA_LAUNCH((dec_gemm_kernel<0, 1, 0>), grid, blk, 0, st, g);
-        else if (out_f32) BRA_LAUNCH((dec_gemm_kernel<0, 0, 1>), grid, blk, 0, st, g);
-        else BRA_LAUNCH((dec_gemm_kernel<0, 0, 0>), grid, blk, 0, st, g);
+        if (act) BRA_DG(0, 1, 0, 16, smem);
+        else if (out_f32) { if (narrow) BRA_DG(0, 0, 1, 8, smem); else BRA_DG(0, 0, 1, 16, smem); }
+        else { if (narrow) BRA_DG(0, 0, 0, 8, smem); else BRA_DG(0, 0, 0, 16, smem); }
     }
+#undef BRA_DG
     return BRA_LAUNCH_STATUS();
 }
 
