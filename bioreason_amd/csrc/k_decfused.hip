@@ -31,7 +31,8 @@ __device__ __forceinline__ float silu_d(float x) { return x / (1.f + __expf(-x))
 
 // NCOL = output columns per workgroup: 16, or 8 (upper half of the MFMA tile idle) so that N = 2048 projections
 // still put a workgroup on every one of the 256 CUs (HBM streaming is per-CU latency bound at this size)
-template <int NORM, int ACT, int OUTF32, int NCOL>
+// MP = rows handled by the RMSNorm prologue (8 or 16, compile-time so that its loads carry no run-time branch)
+template <int NORM, int ACT, int OUTF32, int NCOL, int MP>
 __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs g) {
     BRA_DYN_SMEM(smem);                       // NORM: normalised x rows, bf16 [M][K + 8]
     __shared__ float red[4][64][4];
@@ -44,17 +45,20 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs g) {
     if (NORM) {
         // thread t owns 16-byte column chunk j = t, t+256, .. of EVERY row: all row loads of a chunk are issued
         // together (one memory latency), the per-row sums of squares are combined across the block through LDS
-        __shared__ float ssq[4][16];
-        float ss[16];
+        __shared__ float ssq[4][MP];
+        float ss[MP];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ss[r] = 0.f;
+        for (int r = 0; r < MP; ++r) ss[r] = 0.f;
         const int nch = g.K / 8;
+        long roff[MP];
+#pragma unroll
+        for (int r = 0; r < MP; ++r) roff[r] = (long)(r < g.M ? r : g.M - 1) * g.ldx;      // clamped: no branch around a load
         for (int j = tid; j < nch; j += 256) {
-            u32x4 xr[16];
+            u32x4 xr[MP];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) if (r < g.M) xr[r] = ld16(g.x + (long)r * g.ldx + j * 8);
+            for (int r = 0; r < MP; ++r) xr[r] = ld16(g.x + roff[r] + j * 8);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) if (r < g.M) {
+            for (int r = 0; r < MP; ++r) {
                 float f[8];
                 unpack8(xr[r], f);
 #pragma unroll
@@ -62,25 +66,27 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs g) {
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) if (r < g.M) ss[r] = wave_sum<64>(ss[r]);      // g.M is wave-uniform
+        for (int r = 0; r < MP; ++r) ss[r] = wave_sum<64>(ss[r]);
         if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ssq[wave][r] = ss[r];
+            for (int r = 0; r < MP; ++r) ssq[wave][r] = ss[r];
         }
         __syncthreads();
+        float rstd[MP];
+#pragma unroll
+        for (int r = 0; r < MP; ++r) rstd[r] = rsqrtf((ssq[0][r] + ssq[1][r] + ssq[2][r] + ssq[3][r]) / (float)g.K + g.eps);
         for (int j = tid; j < nch; j += 256) {
             float w[8];
             unpack8(ld16(g.nw + j * 8), w);
-            u32x4 xr[16];
+            u32x4 xr[MP];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) if (r < g.M) xr[r] = ld16(g.x + (long)r * g.ldx + j * 8);
+            for (int r = 0; r < MP; ++r) xr[r] = ld16(g.x + roff[r] + j * 8);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) if (r < g.M) {
-                const float rstd = rsqrtf((ssq[0][r] + ssq[1][r] + ssq[2][r] + ssq[3][r]) / (float)g.K + g.eps);
+            for (int r = 0; r < MP; ++r) {
                 float f[8];
                 unpack8(xr[r], f);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) f[i] = w[i] * round_bf(f[i] * rstd);
+                for (int i = 0; i < 8; ++i) f[i] = w[i] * round_bf(f[i] * rstd[r]);
                 st16(reinterpret_cast<bf16_t*>(smem) + (long)r * xpitch + j * 8, pack8(f));
             }
         }
@@ -196,7 +202,7 @@ __device__ __forceinline__ void norm_rope_slice(float (&x)[8], const bf16_t* nw,
 
 template <int HD, int G>
 __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
-    constexpr int CK = 128, LPK = HD / 8, KPI = 64 / LPK, NIT = CK / KPI, GRP = NIT / 2;
+    constexpr int CK = 64, LPK = HD / 8, KPI = 64 / LPK, NIT = CK / KPI, GRP = NIT / 2;   // 64 positions per wave
     const int lane = lane_id();
     const int c = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     const int hkv = (int)blockIdx.y, b = (int)blockIdx.z;
@@ -242,13 +248,12 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
     }
     const int new_rel = owns_new ? a.cur_len - s_begin : -1;
     // ---- validity bits of the 128 positions
-    uint64_t vbits[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        const int key = s_begin + hh * 64 + lane;
+    uint64_t vbits;
+    {
+        const int key = s_begin + lane;
         const bool okk = key < s_end;
-        const uint8_t mb = (a.kmask && key != a.cur_len) ? a.kmask[(long)b * a.Smax + (okk ? key : s_end - 1)] : (uint8_t)1;
-        vbits[hh] = wave_ballot(okk && mb != 0);
+        const uint8_t mraw = a.kmask ? a.kmask[(long)b * a.Smax + (okk ? key : s_end - 1)] : (uint8_t)1;
+        vbits = wave_ballot(okk && (mraw != 0 || key == a.cur_len));
     }
     float sco[NIT][G];
     float m[G];
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
         for (int i = 0; i < GRP; ++i) {
             const int it = grp * GRP + i;
             const int rel_ = it * KPI + kg;
-            const bool ok = (vbits[rel_ >> 6] >> (rel_ & 63)) & 1ull;
+            const bool ok = (vbits >> rel_) & 1ull;
             float f[8];
             unpack8(grp == 0 ? ra[i] : rb[i], f);
             if (rel_ == new_rel) {
@@ -361,12 +366,17 @@ extern "C" int bra_dec_gemm(const void* x, long ldx, const void* norm_w, float e
     const dim3 blk(256);
     const bool narrow = !act && (N + 15) / 16 < 256 && N % 8 == 0;        // fewer than one workgroup per CU: 8-column tiles
     const dim3 grid(narrow ? (N + 7) / 8 : (N + 15) / 16);
-#define BRA_DG(NORM_, ACT_, F32_, NCOL_, SMEM_)                                                        \
-    do {                                                                                               \
-        BRA_ALLOW_SMEM((dec_gemm_kernel<NORM_, ACT_, F32_, NCOL_>), SMEM_);                            \
-        BRA_LAUNCH((dec_gemm_kernel<NORM_, ACT_, F32_, NCOL_>), grid, blk, SMEM_, st, g);              \
+#define BRA_DG(NORM_, ACT_, F32_, NCOL_, SMEM_)                                                            \
+    do {                                                                                                   \
+        if (M <= 8) {                                                                                      \
+            BRA_ALLOW_SMEM((dec_gemm_kernel<NORM_, ACT_, F32_, NCOL_, 8>), SMEM_);                         \
+            BRA_LAUNCH((dec_gemm_kernel<NORM_, ACT_, F32_, NCOL_, 8>), grid, blk, SMEM_, st, g);           \
+        } else {                                                                                           \
+            BRA_ALLOW_SMEM((dec_gemm_kernel<NORM_, ACT_, F32_, NCOL_, 16>), SMEM_);                        \
+            BRA_LAUNCH((dec_gemm_kernel<NORM_, ACT_, F32_, NCOL_, 16>), grid, blk, SMEM_, st, g);          \
+        }                                                                                                  \
     } while (0)
-    const size_t smem = norm_w ? (size_t)M * (K + 8) * 2 : 0;
+    const size_t smem = norm_w ? (size_t)(M <= 8 ? 8 : 16) * (K + 8) * 2 : 0;
     if (norm_w) {
         if (act) BRA_DG(1, 1, 0, 16, smem);
         else if (out_f32) { if (narrow) BRA_DG(1, 0, 1, 8, smem); else BRA_DG(1, 0, 1, 16, smem); }
@@ -388,7 +398,7 @@ extern "C" int bra_dec_attn_partial(const void* qkv, long ldqkv, const void* qw,
     if (!qkv || !qw || !kw || !cosT || !sinT || !pos || !kc || !vc || !part_o || !part_ml) return BRA_ERR_ARG;
     const int G = Hq / Hkv;
     DecAttnArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, (bf16_t*)kc, (bf16_t*)vc,
-                     (const uint8_t*)kmask, part_o, part_ml, B, Hq, Hkv, Smax, cur_len, (cur_len + 1 + 127) / 128, eps, scale};
+                     (const uint8_t*)kmask, part_o, part_ml, B, Hq, Hkv, Smax, cur_len, (cur_len + 1 + 63) / 64, eps, scale};
     bra_stream_t st = (bra_stream_t)stream;
     dim3 grid((a.nchunk + 3) / 4, Hkv, B);
 #define BRA_DA(HD_, G_)                                                                         \

@@ -73,7 +73,7 @@ extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B,
                                           float* part_o, float* part_ml, float* logits, void* stream) {
     const Layer* ls = (const Layer*)layers_host;
     const int Nq = Hq * hd, Nkv = Hkv * hd, Nqkv = Nq + 2 * Nkv;
-    const int nchunk = (cur_len + 1 + 127) / 128;
+    const int nchunk = (cur_len + 1 + 63) / 64;
     int rc;
 #define CK(call) do { rc = (call); if (rc) return rc; } while (0)
     CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));

@@ -143,7 +143,7 @@ class FusedDecodeState:
             return torch.empty((B, n), dtype=BF16, device=dev)
 
         self.x, self.h, self.qkv, self.o, self.act = buf(eng.H), buf(eng.H), buf(eng.Nq + 2 * eng.Nkv), buf(eng.Nq), buf(eng.F)
-        nch = (cache.Smax + 127) // 128
+        nch = (cache.Smax + 63) // 64
         self.part_o = torch.empty((B, eng.Hq, nch, eng.hd), dtype=torch.float32, device=dev)
         self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
         self.cosT, self.sinT = eng.rope(cache.Smax + 1)
