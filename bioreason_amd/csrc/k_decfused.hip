@@ -42,6 +42,17 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs g) {
     const int rm = fr < g.M ? fr : g.M - 1;
     const long xpitch = g.K + 8;
     const bool wlive = fr < NCOL;                 // lanes that stream a weight row
+    int rn = n0 + (wlive ? fr : 0); rn = rn < g.N ? rn : g.N - 1;
+    const bf16_t* wp = g.W + (long)rn * g.ldw + fq * 8;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const int nk = g.K / 32;
+    const int nbatch = (nk - wave + 31) / 32 > 0 ? (nk - wave + 31) / 32 : 0;
+    u32x4 wc[8];                                  // first weight batch: requested before the prologue (independent of x)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        int kk = wave + 4 * u; kk = kk < nk ? kk : nk - 1;
+        wc[u] = (NCOL == 16 || wlive) ? ld16(wp + (long)kk * 32) : zero4;
+    }
     if (NORM) {
         // thread t owns 16-byte column chunk j = t, t+256, .. of EVERY row: all row loads of a chunk are issued
         // together (one memory latency), the per-row sums of squares are combined across the block through LDS
@@ -92,34 +103,35 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs g) {
         }
         __syncthreads();
     }
-    int rn = n0 + (wlive ? fr : 0); rn = rn < g.N ? rn : g.N - 1;
-    const bf16_t* wp = g.W + (long)rn * g.ldw + fq * 8;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const bf16_t* xg = g.x + (long)rm * g.ldx + fq * 8;
     const bf16_t* xs = reinterpret_cast<const bf16_t*>(smem) + (long)rm * xpitch + fq * 8;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int nk = g.K / 32;
-    int kt = wave;
-    for (; kt + 28 < nk; kt += 32) {
-        u32x4 w[8], x[8];
+    // batches of 8 k-steps, double-buffered in registers: batch i+1 is requested before batch i is consumed
+    for (int kb = 0; kb < nbatch; ++kb) {
+        const int kt = wave + 32 * kb;
+        u32x4 wn[8], x[8];
+        const int ktn = kt + 32;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = (NCOL == 16 || wlive) ? ld16(wp + (long)(kt + 4 * u) * 32) : zero4;
+        for (int u = 0; u < 8; ++u) {
+            int kk = ktn + 4 * u; kk = kk < nk ? kk : nk - 1;
+            wn[u] = (NCOL == 16 || wlive) ? ld16(wp + (long)kk * 32) : zero4;
+        }
         if (!NORM) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = ld16(xg + (long)(kt + 4 * u) * 32);
+            for (int u = 0; u < 8; ++u) { int kk = kt + 4 * u; kk = kk < nk ? kk : nk - 1; x[u] = ld16(xg + (long)kk * 32); }
         }
         sched_fence();
         if (NORM) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = ld16(xs + (long)(kt + 4 * u) * 32);
+            for (int u = 0; u < 8; ++u) { int kk = kt + 4 * u; kk = kk < nk ? kk : nk - 1; x[u] = ld16(xs + (long)kk * 32); }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = mfma_16x16x32(w[u], x[u], acc);
-    }
-    for (; kt < nk; kt += 4) {
-        const u32x4 w = (NCOL == 16 || wlive) ? ld16(wp + (long)kt * 32) : zero4;
-        const u32x4 x = NORM ? ld16(xs + (long)kt * 32) : ld16(xg + (long)kt * 32);
-        acc = mfma_16x16x32(w, x, acc);
+        for (int u = 0; u < 8; ++u) {
+            const u32x4 wu = (kt + 4 * u < nk) ? wc[u] : zero4;        // steps past K contribute zero
+            acc = mfma_16x16x32(wu, x[u], acc);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wc[u] = wn[u];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
@@ -216,11 +228,18 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
     // the first half of the chunk's K rows is requested before anything else: its latency hides the q/k prologue
     bf16_t* kb_ = a.kc + ((long)b * a.Hkv + hkv) * a.Smax * HD + dl * 8;
     bf16_t* vb_ = a.vc + ((long)b * a.Hkv + hkv) * a.Smax * HD + dl * 8;
-    u32x4 ra[GRP], rb[GRP];
+    u32x4 ra[GRP], rb[GRP], va[GRP], vb[GRP];     // all K and V rows of the chunk: one memory round trip
 #pragma unroll
     for (int i = 0; i < GRP; ++i) {
-        const int key = s_begin + i * KPI + kg;
-        ra[i] = ld16(kb_ + (long)(key < s_end ? key : s_end - 1) * HD);
+        const int k0 = s_begin + i * KPI + kg, k1 = s_begin + (GRP + i) * KPI + kg;
+        ra[i] = ld16(kb_ + (long)(k0 < s_end ? k0 : s_end - 1) * HD);
+        rb[i] = ld16(kb_ + (long)(k1 < s_end ? k1 : s_end - 1) * HD);
+    }
+#pragma unroll
+    for (int i = 0; i < GRP; ++i) {
+        const int k0 = s_begin + i * KPI + kg, k1 = s_begin + (GRP + i) * KPI + kg;
+        va[i] = ld16(vb_ + (long)(k0 < s_end ? k0 : s_end - 1) * HD);
+        vb[i] = ld16(vb_ + (long)(k1 < s_end ? k1 : s_end - 1) * HD);
     }
     const bf16_t* row = a.qkv + (long)b * a.ldqkv;
     const int p = a.pos[b];
@@ -259,13 +278,6 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
     float m[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) m[g] = kNegD;
-    // software pipeline over the two halves: K1 is requested before K0 is consumed, V0 before K1 is consumed, ...
-#pragma unroll
-    for (int i = 0; i < GRP; ++i) {
-        const int key = s_begin + (GRP + i) * KPI + kg;
-        rb[i] = ld16(kb_ + (long)(key < s_end ? key : s_end - 1) * HD);
-    }
-    sched_fence();
 #pragma unroll
     for (int grp = 0; grp < 2; ++grp) {
 #pragma unroll
@@ -291,15 +303,6 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
                 m[g] = fmaxf(m[g], d);
             }
         }
-        sched_fence();
-        // the registers this half's K rows just vacated receive its V rows
-#pragma unroll
-        for (int i = 0; i < GRP; ++i) {
-            const int key = s_begin + (grp * GRP + i) * KPI + kg;
-            const u32x4 vv = ld16(vb_ + (long)(key < s_end ? key : s_end - 1) * HD);
-            if (grp == 0) ra[i] = vv; else rb[i] = vv;
-        }
-        sched_fence();
     }
     float l[G], acc[G][8];
 #pragma unroll
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
             const int it = grp * GRP + i;
             const int rel_ = it * KPI + kg;
             float f[8];
-            unpack8(grp == 0 ? ra[i] : rb[i], f);
+            unpack8(grp == 0 ? va[i] : vb[i], f);
             if (rel_ == new_rel) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = round_bf(vn[e]);

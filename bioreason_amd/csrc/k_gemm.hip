@@ -15,6 +15,8 @@
 // ds_read_b128), register-staged global->LDS pipeline with one barrier per
 // K-step, XCD-aware grouped tile order.  Operand roles are swapped
 // (D[n][m]) so every lane owns 4 consecutive output columns of one row.
+#include <type_traits>
+
 #include "bra_device.h"
 #include "bra_api_internal.h"
 
@@ -56,17 +58,20 @@ __device__ __forceinline__ int swz_chunk(int row, int c) {
     return BK == 64 ? (c ^ (row & 7)) : (c ^ ((row >> 2) & 3));
 }
 
-template <int BK, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
-    constexpr int BM = 128, BN = 128;
+// BM x 128 output tile, BM/64 x 2 waves of 64x64; PF = register prefetch depth in K-tiles (the global loads of
+// tile t+PF are in flight while tile t is multiplied; LDS stays double-buffered).
+template <int BM, int BK, int EPI, int PF>
+__global__ __launch_bounds__(BM * 2) void gemm_nt_kernel(GemmArgs g) {
+    constexpr int BN = 128, NT = BM * 2;
     constexpr int CH = BK / 8;              // 16-byte chunks per tile row
-    constexpr int LPT = (BM * CH) / 256;    // 16-byte loads per thread per operand per K-step
-    constexpr int TILE_BYTES = BM * BK * 2;
+    constexpr int LPTA = (BM * CH) / NT;    // 16-byte loads per thread per K-step, A operand
+    constexpr int LPTB = (BN * CH) / NT;    // ... B operand
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     BRA_DYN_SMEM(smem);                     // [2 buffers][A tile | B tile]
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;   // wave position in the 2x2 grid
+    const int wm = wave >> 1, wn = wave & 1;   // wave position in the (BM/64) x 2 grid
 
     // ---- tile order: XCD-aware, grouped along M so a group re-uses B panels from L2
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
@@ -95,35 +100,41 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     }
 
     // ---- per-thread global->LDS staging slots
-    int ld_row[LPT], ld_c[LPT];
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) {
-        int q = tid + 256 * i;
-        ld_row[i] = q / CH;
-        ld_c[i] = q % CH;
-    }
-    u32x4 ra[LPT], rb[LPT];
+    // register sets are named statically (S is a compile-time constant at every call site): a run-time index
+    // into a register array would send it to scratch
+    u32x4 ra[PF][LPTA], rb[PF][LPTB];
 
-    auto issue_loads = [&](int kt) {
+    auto issue_loads = [&](auto S, int kt) {
+        constexpr int s = decltype(S)::value;
         const bf16_t* Ap; const bf16_t* Bp; long la, lb; int k0;
         if (kt < nk1) { Ap = g.A; Bp = g.B; la = g.lda; lb = g.ldb; k0 = kt * BK; }
         else { Ap = g.A2; Bp = g.B2; la = g.lda2; lb = g.ldb2; k0 = (kt - nk1) * BK; }
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            int rm = m0 + ld_row[i]; rm = rm < g.M ? rm : g.M - 1;   // clamp: rows past M are never stored
-            int rn = n0 + ld_row[i]; rn = rn < g.N ? rn : g.N - 1;
-            ra[i] = ld16(Ap + (long)rm * la + k0 + ld_c[i] * 8);
-            rb[i] = ld16(Bp + (long)rn * lb + k0 + ld_c[i] * 8);
+        for (int i = 0; i < LPTA; ++i) {
+            const int q = tid + NT * i;
+            int rm = m0 + q / CH; rm = rm < g.M ? rm : g.M - 1;      // clamp: rows past M are never stored
+            ra[s][i] = ld16(Ap + (long)rm * la + k0 + (q % CH) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < LPTB; ++i) {
+            const int q = tid + NT * i;
+            int rn = n0 + q / CH; rn = rn < g.N ? rn : g.N - 1;
+            rb[s][i] = ld16(Bp + (long)rn * lb + k0 + (q % CH) * 8);
         }
     };
-    auto write_lds = [&](int buf) {
-        char* sa = smem + buf * 2 * TILE_BYTES;
-        char* sb = sa + TILE_BYTES;
+    auto write_lds = [&](auto S, int buf) {
+        constexpr int s = decltype(S)::value;
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            int off = ld_row[i] * (BK * 2) + swz_chunk<BK>(ld_row[i], ld_c[i]) * 16;
-            st16(sa + off, ra[i]);
-            st16(sb + off, rb[i]);
+        for (int i = 0; i < LPTA; ++i) {
+            const int q = tid + NT * i;
+            st16(sa + (q / CH) * (BK * 2) + swz_chunk<BK>(q / CH, q % CH) * 16, ra[s][i]);
+        }
+#pragma unroll
+        for (int i = 0; i < LPTB; ++i) {
+            const int q = tid + NT * i;
+            st16(sb + (q / CH) * (BK * 2) + swz_chunk<BK>(q / CH, q % CH) * 16, rb[s][i]);
         }
     };
 
@@ -133,17 +144,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue_loads(kt_begin);
-    write_lds(0);
-    __syncthreads();
-
     const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
-        const bool more = (kt + 1 < kt_end);
-        if (more) issue_loads(kt + 1);
-        const char* sa = smem + buf * 2 * TILE_BYTES;
-        const char* sb = sa + TILE_BYTES;
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * STAGE;
+        const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             u32x4 fa[4], fb[4];
@@ -160,8 +164,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma_16x16x32(fb[ni], fa[mi], acc[ni][mi]);
         }
-        if (more) write_lds(buf ^ 1);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, PF - 1>;
+    if (PF == 1) {
+        issue_loads(S0{}, kt_begin);
+        write_lds(S0{}, 0);
         __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int buf = (kt - kt_begin) & 1;
+            const bool more = (kt + 1 < kt_end);
+            if (more) issue_loads(S0{}, kt + 1);
+            compute(buf);
+            if (more) write_lds(S0{}, buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // tile kt_begin + j lives in register set j & 1 until it is written to LDS buffer j & 1
+        issue_loads(S0{}, kt_begin);
+        if (kt_begin + 1 < kt_end) issue_loads(S1{}, kt_begin + 1);
+        write_lds(S0{}, 0);
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+            if (kt + 2 < kt_end) issue_loads(S0{}, kt + 2);      // set 0 is free: tile kt already sits in LDS buffer 0
+            compute(0);
+            if (kt + 1 < kt_end) write_lds(S1{}, 1);
+            __syncthreads();
+            if (kt + 1 < kt_end) {
+                if (kt + 3 < kt_end) issue_loads(S1{}, kt + 3);
+                compute(1);
+                if (kt + 2 < kt_end) write_lds(S0{}, 0);
+                __syncthreads();
+            }
+        }
     }
 
     // ---- epilogue: lane owns C[m][n..n+3], m = m0 + wm*64 + 16*mi + fr, n = n0 + wn*64 + 16*ni + 4*fq
@@ -339,14 +374,35 @@ static int launch_skinny(const GemmArgs& g, int out_f32, bra_stream_t stream) {
     return BRA_LAUNCH_STATUS();
 }
 
-template <int BK, int EPI>
-static int launch_gemm(const GemmArgs& g, bra_stream_t stream) {
-    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+// tile variant: bit 0 = register prefetch depth 2, bit 1 = 256-row tiles (8 waves).  Chosen per call by
+// pick_variant(); bra_gemm_set_variant(v >= 0) pins it (tuning / A-B measurements only).
+static int g_forced_variant = -1;
+
+static int pick_variant(const GemmArgs& g) {
+    if (g_forced_variant >= 0) return g_forced_variant;
+    const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+    return (tiles256 >= 512 ? 2 : 0) | 1;
+}
+
+template <int BM, int BK, int EPI, int PF>
+static int launch_gemm_v(const GemmArgs& g, bra_stream_t stream) {
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + 127) / 128);
     int grid = tiles;
     if (EPI == EPI_ATOMIC) grid = tiles * (g.split_k > 0 ? g.split_k : 1);
-    const size_t smem = 2 * 2 * 128 * BK * 2;
-    BRA_LAUNCH((gemm_nt_kernel<BK, EPI>), dim3(grid), dim3(256), smem, stream, g);
+    const size_t smem = 2 * (size_t)(BM + 128) * BK * 2;
+    BRA_ALLOW_SMEM((gemm_nt_kernel<BM, BK, EPI, PF>), smem);
+    BRA_LAUNCH((gemm_nt_kernel<BM, BK, EPI, PF>), dim3(grid), dim3(BM * 2), smem, stream, g);
     return BRA_LAUNCH_STATUS();
+}
+
+template <int BK, int EPI>
+static int launch_gemm(const GemmArgs& g, bra_stream_t stream) {
+    switch (pick_variant(g)) {
+        case 1: return launch_gemm_v<128, BK, EPI, 2>(g, stream);
+        case 2: return launch_gemm_v<256, BK, EPI, 1>(g, stream);
+        case 3: return launch_gemm_v<256, BK, EPI, 2>(g, stream);
+        default: return launch_gemm_v<128, BK, EPI, 1>(g, stream);
+    }
 }
 
 template <int EPI>
@@ -367,6 +423,8 @@ static int check_common(const GemmArgs& g) {
 }  // namespace bra
 
 using namespace bra;
+
+extern "C" int bra_gemm_set_variant(int v) { bra::g_forced_variant = v; return 0; }
 
 extern "C" int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2,
                                 const void* B2, long ldb2, int K2, void* C, long ldc, int M, int N, int K,

@@ -40,6 +40,10 @@ int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, const voi
                      long ldb2, int K2, void* C, long ldc, int M, int N, int K, float alpha, const void* bias,
                      const void* res, long ldres, int out_f32, int accumulate, void* stream);
 
+/* tuning knob for A/B measurements: pins the tile variant of bra_gemm_* (bit 0 = register prefetch depth 2,
+ * bit 1 = 256-row tiles); v < 0 restores the built-in per-shape choice */
+int bra_gemm_set_variant(int v);
+
 /* C[M,N] (f32, pre-zeroed or holding a running gradient) += alpha * A[M,K] B[N,K]^T with the K range cut
  * into `split_k` slices and combined by atomics: weight gradients of LoRA A/B and dna_projection, where
  * K is the token count (autograd of PEFT's lora_A / lora_B, and of dna_llm.py:159-160). */

@@ -414,3 +414,28 @@ def test_sampler_greedy_and_topk(backend):
     fin = torch.tensor([0, 1, 0], dtype=torch.uint8, device=backend)
     ops.sample(logits, T, k, p, True, 1, step, fin, 42, out)
     assert out[1].item() == 42
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_gemm_tile_variants(backend, variant):
+    """every tile variant (128/256-row tiles x register prefetch depth 1/2) against the fp32 statement"""
+    from bioreason_amd._lib import get_lib
+    get_lib().call("bra_gemm_set_variant", variant)
+    try:
+        for (M, N, K, K2) in [(300, 200, 256, 64), (520, 136, 64, 0), (100, 128, 192, 0)]:
+            a, b = rnd(M, K, dev=backend), rnd(N, K, dev=backend)
+            a2 = rnd(M, K2, dev=backend) if K2 else None
+            b2 = rnd(N, K2, dev=backend) if K2 else None
+            ref = a.float() @ b.float().T + (a2.float() @ b2.float().T if K2 else 0)
+            c = ops.gemm_nt(a, b, a2=a2, b2=b2, out_f32=True)
+            assert rel(c, ref) < 1e-5
+            sk = torch.zeros(M, N, device=backend)
+            ops.gemm_nt_splitk(a, b, sk, split_k=3)
+            assert rel(sk, a.float() @ b.float().T) < 1e-5
+            h, e = rnd(M, K, dev=backend, scale=0.3), rnd(N, K, dev=backend, scale=0.3)
+            tgt = (torch.arange(M) % N).to(torch.int32).to(backend)
+            logp, lse = ops.lmhead_logprob(h, e, tgt)
+            lg = (h.float() @ e.float().T).to(BF).float()
+            assert (lse.cpu() - torch.logsumexp(lg, -1).cpu()).abs().max() < 2e-3
+    finally:
+        get_lib().call("bra_gemm_set_variant", -1)

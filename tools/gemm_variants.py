@@ -1,0 +1,26 @@
+import sys, os, json, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bioreason_amd import ops
+from bioreason_amd._lib import get_lib
+dev = torch.device("cuda:0"); BF = torch.bfloat16
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / iters
+T = 8 * 2436
+shapes = [("qkv", T, 4096, 2048, 128), ("o", T, 2048, 2048, 64), ("gate_up", T, 12288, 2048, 64), ("down", T, 2048, 6144, 64),
+          ("enc_qkv", 16384, 3072, 1024, 0), ("enc_ffn_dn", 16384, 1024, 4096, 0), ("lm_head", 2048, 151936, 2048, 0), ("sq8192", 8192, 8192, 8192, 0)]
+for name, M, N, K, K2 in shapes:
+    a = torch.randn(M, K, device=dev).to(BF); b = torch.randn(N, K, device=dev).to(BF)
+    a2 = torch.randn(M, K2, device=dev).to(BF) if K2 else None; b2 = torch.randn(N, K2, device=dev).to(BF) if K2 else None
+    c = torch.empty(M, N, dtype=BF, device=dev)
+    res = {}
+    for v in range(4):
+        get_lib().call("bra_gemm_set_variant", v)
+        ms = timeit(lambda: ops.gemm_nt(a, b, a2=a2, b2=b2, out=c))
+        res[v] = round(2.0 * M * N * (K + K2) / ms / 1e9)
+    get_lib().call("bra_gemm_set_variant", -1)
+    ms = timeit(lambda: torch.matmul(a, b.T))
+    print(name, "TF by variant", res, "torch", round(2.0 * M * N * K / ms / 1e9), flush=True)
