@@ -199,6 +199,31 @@ __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0
 #define setprio(p) __builtin_amdgcn_s_setprio(p)
 #endif
 
+// ---- asynchronous global -> LDS copy (LDS-DMA, `global_load_lds_dwordx4`) -----------------------------
+// One wave-instruction moves 64 x 16 B: lane l's 16 bytes from its OWN global address to
+// (wave-uniform LDS base) + 16*l.  It is a VMEM operation: completion is observed with s_waitcnt vmcnt(N)
+// followed by a barrier, never by __syncthreads() alone.
+#ifdef BRA_EMU
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    memcpy(lds_wave_base + bra_emu::lane_id() * 16, gsrc, 16);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {}
+__device__ __forceinline__ void raw_barrier() { bra_emu::block_sync(); }
+__device__ __forceinline__ int uniform_i(int v) { return v; }
+#else
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// barrier that does NOT drain the VMEM queue (a __syncthreads() would wait for every LDS-DMA in flight)
+__device__ __forceinline__ void raw_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 __device__ __forceinline__ u32x2 ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }

@@ -58,6 +58,113 @@ __device__ __forceinline__ int swz_chunk(int row, int c) {
     return BK == 64 ? (c ^ (row & 7)) : (c ^ ((row >> 2) & 3));
 }
 
+// ---- epilogue: lane owns C[m][n..n+3], m = m0 + wm*64 + 16*mi + fr, n = n0 + wn*64 + 16*ni + 4*fq
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn,
+                                              int lane, int tile_n) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const float alpha = g.alpha;
+    if (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_ATOMIC || EPI == EPI_DLOGIT) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + fr;
+            if (m >= g.M) continue;
+            float lse_m = 0.f, coef_m = 0.f; int tgt_m = -1;
+            if (EPI == EPI_DLOGIT) { lse_m = g.lse[m]; coef_m = g.coef[m]; tgt_m = g.tgt[m]; }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+                if (n >= g.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] * alpha;
+                const bool full = (n + 3 < g.N);
+                if (EPI == EPI_BF16) {
+                    if (g.bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += bf2f(g.bias[n + r]);
+                    }
+                    if (g.res) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < g.N) v[r] = round_bf(v[r]) + bf2f(g.res[(long)m * g.ldres + n + r]);
+                    }
+                    bf16_t* cp = (bf16_t*)g.C + (long)m * g.ldc + n;
+                    if (full) {
+                        u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                        st8(cp, o);
+                    } else {
+                        for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = f2bf(v[r]);
+                    }
+                } else if (EPI == EPI_DLOGIT) {
+                    bf16_t* cp = (bf16_t*)g.C + (long)m * g.ldc + n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p = __expf(round_bf(v[r]) - lse_m);
+                        v[r] = coef_m * (((n + r) == tgt_m ? 1.f : 0.f) - p);
+                    }
+                    if (full) {
+                        u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                        st8(cp, o);
+                    } else {
+                        for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = f2bf(v[r]);
+                    }
+                } else if (EPI == EPI_F32) {
+                    float* cp = (float*)g.C + (long)m * g.ldc + n;
+                    if (g.bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += bf2f(g.bias[n + r]);
+                    }
+                    if (full) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        if (g.accumulate) o += *reinterpret_cast<const f32x4*>(cp);
+                        *reinterpret_cast<f32x4*>(cp) = o;
+                    } else {
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < g.N) cp[r] = g.accumulate ? cp[r] + v[r] : v[r];
+                    }
+                } else {  // EPI_ATOMIC
+                    float* cp = (float*)g.C + (long)m * g.ldc + n;
+                    for (int r = 0; r < 4; ++r) if (n + r < g.N) atomicAdd(cp + r, v[r]);
+                }
+            }
+        }
+    } else {  // EPI_LSE: each wave reduces its 64 columns per row
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + fr;
+            const int tgt_m = (m < g.M) ? g.tgt[m] : -1;
+            float vmax = -3.0e38f;
+            float vals[16];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = round_bf(acc[ni][mi][r] * alpha);
+                    bool ok = (n + r) < g.N;
+                    vals[ni * 4 + r] = ok ? x : -3.0e38f;
+                    if (ok) vmax = fmaxf(vmax, x);
+                    if (ok && (n + r) == tgt_m) g.tgt_logit[m] = x;
+                }
+            }
+            // lanes fr, fr+16, fr+32, fr+48 hold the same row: reduce over fq
+            vmax = fmaxf(vmax, wave_shfl_xor(vmax, 16));
+            vmax = fmaxf(vmax, wave_shfl_xor(vmax, 32));
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += (vals[i] > -1.0e38f) ? __expf(vals[i] - vmax) : 0.f;
+            s += wave_shfl_xor(s, 16);
+            s += wave_shfl_xor(s, 32);
+            const int chunk = tile_n * 2 + wn;
+            if (fq == 0 && m < g.M && chunk < g.nchunk) {
+                g.part_max[(long)m * g.nchunk + chunk] = vmax;
+                g.part_sum[(long)m * g.nchunk + chunk] = s;
+            }
+        }
+    }
+}
+
 // BM x 128 output tile, BM/64 x 2 waves of 64x64; PF = register prefetch depth in K-tiles (the global loads of
 // tile t+PF are in flight while tile t is multiplied; LDS stays double-buffered).
 template <int BM, int BK, int EPI, int PF>
@@ -199,107 +306,112 @@ __global__ __launch_bounds__(BM * 2) void gemm_nt_kernel(GemmArgs g) {
         }
     }
 
-    // ---- epilogue: lane owns C[m][n..n+3], m = m0 + wm*64 + 16*mi + fr, n = n0 + wn*64 + 16*ni + 4*fq
-    const float alpha = g.alpha;
-    if (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_ATOMIC || EPI == EPI_DLOGIT) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wm * 64 + mi * 16 + fr;
-            if (m >= g.M) continue;
-            float lse_m = 0.f, coef_m = 0.f; int tgt_m = -1;
-            if (EPI == EPI_DLOGIT) { lse_m = g.lse[m]; coef_m = g.coef[m]; tgt_m = g.tgt[m]; }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n = n0 + wn * 64 + ni * 16 + fq * 4;
-                if (n >= g.N) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] * alpha;
-                const bool full = (n + 3 < g.N);
-                if (EPI == EPI_BF16) {
-                    if (g.bias) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += bf2f(g.bias[n + r]);
-                    }
-                    if (g.res) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (n + r < g.N) v[r] = round_bf(v[r]) + bf2f(g.res[(long)m * g.ldres + n + r]);
-                    }
-                    bf16_t* cp = (bf16_t*)g.C + (long)m * g.ldc + n;
-                    if (full) {
-                        u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                        st8(cp, o);
-                    } else {
-                        for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = f2bf(v[r]);
-                    }
-                } else if (EPI == EPI_DLOGIT) {
-                    bf16_t* cp = (bf16_t*)g.C + (long)m * g.ldc + n;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float p = __expf(round_bf(v[r]) - lse_m);
-                        v[r] = coef_m * (((n + r) == tgt_m ? 1.f : 0.f) - p);
-                    }
-                    if (full) {
-                        u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                        st8(cp, o);
-                    } else {
-                        for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = f2bf(v[r]);
-                    }
-                } else if (EPI == EPI_F32) {
-                    float* cp = (float*)g.C + (long)m * g.ldc + n;
-                    if (g.bias) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += bf2f(g.bias[n + r]);
-                    }
-                    if (full) {
-                        f32x4 o = {v[0], v[1], v[2], v[3]};
-                        if (g.accumulate) o += *reinterpret_cast<const f32x4*>(cp);
-                        *reinterpret_cast<f32x4*>(cp) = o;
-                    } else {
-                        for (int r = 0; r < 4; ++r)
-                            if (n + r < g.N) cp[r] = g.accumulate ? cp[r] + v[r] : v[r];
-                    }
-                } else {  // EPI_ATOMIC
-                    float* cp = (float*)g.C + (long)m * g.ldc + n;
-                    for (int r = 0; r < 4; ++r) if (n + r < g.N) atomicAdd(cp + r, v[r]);
-                }
-            }
-        }
-    } else {  // EPI_LSE: each wave reduces its 64 columns per row
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wm * 64 + mi * 16 + fr;
-            const int tgt_m = (m < g.M) ? g.tgt[m] : -1;
-            float vmax = -3.0e38f;
-            float vals[16];
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n = n0 + wn * 64 + ni * 16 + fq * 4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = round_bf(acc[ni][mi][r] * alpha);
-                    bool ok = (n + r) < g.N;
-                    vals[ni * 4 + r] = ok ? x : -3.0e38f;
-                    if (ok) vmax = fmaxf(vmax, x);
-                    if (ok && (n + r) == tgt_m) g.tgt_logit[m] = x;
-                }
-            }
-            // lanes fr, fr+16, fr+32, fr+48 hold the same row: reduce over fq
-            vmax = fmaxf(vmax, wave_shfl_xor(vmax, 16));
-            vmax = fmaxf(vmax, wave_shfl_xor(vmax, 32));
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s += (vals[i] > -1.0e38f) ? __expf(vals[i] - vmax) : 0.f;
-            s += wave_shfl_xor(s, 16);
-            s += wave_shfl_xor(s, 32);
-            const int chunk = tile_n * 2 + wn;
-            if (fq == 0 && m < g.M && chunk < g.nchunk) {
-                g.part_max[(long)m * g.nchunk + chunk] = vmax;
-                g.part_sum[(long)m * g.nchunk + chunk] = s;
-            }
-        }
+    gemm_epilogue<EPI>(g, acc, m0, n0, wm, wn, lane, tile_n);
+}
+
+// ---------------------------------------------------------------------------
+// LDS-DMA variant for the large-M GEMMs: 256 x 128 output tile, 8 waves (4 x 2, 64 x 64 each), BK = 64, three
+// 48 KiB LDS stages filled by `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass: the ds_write
+// path tops out at ~80 B/clk/CU and made the register-staged kernel LDS-bound), counted vmcnt so that the
+// copy of tile t+2 stays in flight across the barrier of tile t, one raw s_barrier per K-step.
+// LDS image per stage: A rows [256][128 B] then B rows [128][128 B]; a DMA piece = 8 rows = 1 KiB written
+// linearly by the 64 lanes, so the conflict-free XOR swizzle (chunk ^= row & 7) is applied on the SOURCE side:
+// lane l lands at (row l>>3, physical chunk l&7) and therefore fetches logical chunk (l&7) ^ (l>>3).
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 128, BK = 64;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    BRA_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = (int)blockIdx.x;
+    int kslice = 0;
+    if (EPI == EPI_ATOMIC) { kslice = bid / ntiles; bid -= kslice * ntiles; }
+    bid = (int)xcd_remap((unsigned)bid, (unsigned)ntiles);
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int gid = bid / per_group;
+    const int first_m = gid * GROUP;
+    const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int tile_m = first_m + (bid % per_group) % gsize;
+    const int tile_n = (bid % per_group) / gsize;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int nk1 = g.K / BK, nk2 = g.K2 / BK;
+    int kt_begin = 0, kt_end = nk1 + nk2;
+    if (EPI == EPI_ATOMIC && g.split_k > 1) {
+        int per = (kt_end + g.split_k - 1) / g.split_k;
+        kt_begin = kslice * per;
+        kt_end = kt_begin + per < kt_end ? kt_begin + per : kt_end;
+        if (kt_begin >= kt_end) return;
     }
+    const int nt = kt_end - kt_begin;
+
+    // per-lane source rows of this wave's 4 A pieces and 2 B pieces (clamped: rows past M / N are never stored)
+    const int prow = lane >> 3, lchunk = ((lane & 7) ^ (lane >> 3)) * 8;
+    int rowA[4], rowB[2];          // rows only (6 VGPRs): nothing here may spill — a scratch reload in the K loop
+#pragma unroll                     // carries a vmcnt(0) that would drain the DMA queue
+    for (int j = 0; j < 4; ++j) { int r = m0 + wave * 32 + j * 8 + prow; rowA[j] = r < g.M ? r : g.M - 1; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { int r = n0 + wave * 16 + j * 8 + prow; rowB[j] = r < g.N ? r : g.N - 1; }
+    auto issue = [&](int kt, int stage) {
+        char* sa = smem + stage * STAGE + wave * (32 * 128);
+        char* sb = smem + stage * STAGE + A_BYTES + wave * (16 * 128);
+        const bool main = kt < nk1;
+        const bf16_t* Ap = (main ? g.A : g.A2) + (long)(main ? kt : kt - nk1) * BK + lchunk;
+        const bf16_t* Bp = (main ? g.B : g.B2) + (long)(main ? kt : kt - nk1) * BK + lchunk;
+        const long la = main ? g.lda : g.lda2, lb = main ? g.ldb : g.ldb2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(Ap + (long)rowA[j] * la, sa + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(Bp + (long)rowB[j] * lb, sb + j * 1024);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    auto compute = [&](int stage) {
+        const char* sa = smem + stage * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            u32x4 fa[4], fb[4];
+            const int c = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int rowa = wm * 64 + i * 16 + fr;
+                int rowb = wn * 64 + i * 16 + fr;
+                fa[i] = ld16(sa + rowa * 128 + swz_chunk<64>(rowa, c) * 16);
+                fb[i] = ld16(sb + rowb * 128 + swz_chunk<64>(rowb, c) * 16);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma_16x16x32(fb[ni], fa[mi], acc[ni][mi]);
+        }
+    };
+
+    issue(kt_begin, 0);
+    if (nt > 1) { issue(kt_begin + 1, 1); wait_vmcnt<6>(); } else { wait_vmcnt<0>(); }
+    raw_barrier();
+    int stage = 0;
+    for (int t = 0; t < nt; ++t) {
+        int s2 = stage + 2; s2 = s2 >= 3 ? s2 - 3 : s2;
+        const bool ahead = t + 2 < nt;
+        if (ahead) issue(kt_begin + t + 2, s2);        // stage s2 was last read during step t-1: every wave is past that barrier
+        compute(stage);
+        if (ahead) wait_vmcnt<6>(); else wait_vmcnt<0>();   // tile t+1 has landed; tile t+2 may still be in flight
+        raw_barrier();
+        stage = stage + 1 == 3 ? 0 : stage + 1;
+    }
+    gemm_epilogue<EPI>(g, acc, m0, n0, wm, wn, lane, tile_n);
 }
 
 // ---------------------------------------------------------------------------
@@ -395,8 +507,20 @@ static int launch_gemm_v(const GemmArgs& g, bra_stream_t stream) {
     return BRA_LAUNCH_STATUS();
 }
 
+template <int EPI>
+static int launch_glds(const GemmArgs& g, bra_stream_t stream) {
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
+    int grid = tiles;
+    if (EPI == EPI_ATOMIC) grid = tiles * (g.split_k > 0 ? g.split_k : 1);
+    const size_t smem = 3 * (size_t)(256 + 128) * 64 * 2;
+    BRA_ALLOW_SMEM((gemm_glds_kernel<EPI>), smem);
+    BRA_LAUNCH((gemm_glds_kernel<EPI>), dim3(grid), dim3(512), smem, stream, g);
+    return BRA_LAUNCH_STATUS();
+}
+
 template <int BK, int EPI>
 static int launch_gemm(const GemmArgs& g, bra_stream_t stream) {
+    if (BK == 64 && pick_variant(g) == 4) return launch_glds<EPI>(g, stream);
     switch (pick_variant(g)) {
         case 1: return launch_gemm_v<128, BK, EPI, 2>(g, stream);
         case 2: return launch_gemm_v<256, BK, EPI, 1>(g, stream);
