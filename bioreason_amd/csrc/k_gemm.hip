@@ -317,7 +317,9 @@ __global__ __launch_bounds__(BM * 2) void gemm_nt_kernel(GemmArgs g) {
 // LDS image per stage: A rows [256][128 B] then B rows [128][128 B]; a DMA piece = 8 rows = 1 KiB written
 // linearly by the 64 lanes, so the conflict-free XOR swizzle (chunk ^= row & 7) is applied on the SOURCE side:
 // lane l lands at (row l>>3, physical chunk l&7) and therefore fetches logical chunk (l&7) ^ (l>>3).
-template <int EPI>
+// SKEW: fragment reads of the next half K-step are issued before the MFMAs of the current one (the barrier sits
+// between the two halves), so LDS latency hides behind matrix work instead of stalling both waves of a SIMD at once.
+template <int EPI, int SKEW>
 __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 128, BK = 64;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -402,14 +404,52 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmArgs g) {
     if (nt > 1) { issue(kt_begin + 1, 1); wait_vmcnt<6>(); } else { wait_vmcnt<0>(); }
     raw_barrier();
     int stage = 0;
-    for (int t = 0; t < nt; ++t) {
-        int s2 = stage + 2; s2 = s2 >= 3 ? s2 - 3 : s2;
-        const bool ahead = t + 2 < nt;
-        if (ahead) issue(kt_begin + t + 2, s2);        // stage s2 was last read during step t-1: every wave is past that barrier
-        compute(stage);
-        if (ahead) wait_vmcnt<6>(); else wait_vmcnt<0>();   // tile t+1 has landed; tile t+2 may still be in flight
-        raw_barrier();
-        stage = stage + 1 == 3 ? 0 : stage + 1;
+    if (!SKEW) {
+        for (int t = 0; t < nt; ++t) {
+            int s2 = stage + 2; s2 = s2 >= 3 ? s2 - 3 : s2;
+            const bool ahead = t + 2 < nt;
+            if (ahead) issue(kt_begin + t + 2, s2);        // stage s2 was last read during step t-1: every wave is past that barrier
+            compute(stage);
+            if (ahead) wait_vmcnt<6>(); else wait_vmcnt<0>();   // tile t+1 has landed; tile t+2 may still be in flight
+            raw_barrier();
+            stage = stage + 1 == 3 ? 0 : stage + 1;
+        }
+    } else {
+        auto read_frags = [&](int stg, int kk, u32x4 (&fa)[4], u32x4 (&fb)[4]) {
+            const char* sa = smem + stg * STAGE;
+            const char* sb = sa + A_BYTES;
+            const int c = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int rowa = wm * 64 + i * 16 + fr;
+                int rowb = wn * 64 + i * 16 + fr;
+                fa[i] = ld16(sa + rowa * 128 + swz_chunk<64>(rowa, c) * 16);
+                fb[i] = ld16(sb + rowb * 128 + swz_chunk<64>(rowb, c) * 16);
+            }
+        };
+        auto mma = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[4]) {
+            setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma_16x16x32(fb[ni], fa[mi], acc[ni][mi]);
+            setprio(0);
+        };
+        u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+        read_frags(0, 0, fa0, fb0);
+        for (int t = 0; t < nt; ++t) {
+            int s2 = stage + 2; s2 = s2 >= 3 ? s2 - 3 : s2;
+            const int s1 = stage + 1 == 3 ? 0 : stage + 1;
+            const bool ahead = t + 2 < nt;
+            if (ahead) issue(kt_begin + t + 2, s2);
+            read_frags(stage, 1, fa1, fb1);
+            mma(fa0, fb0);
+            if (ahead) wait_vmcnt<6>(); else wait_vmcnt<0>();
+            raw_barrier();                                   // all reads of `stage` are done, tile t+1 has landed
+            if (t + 1 < nt) read_frags(s1, 0, fa0, fb0);
+            mma(fa1, fb1);
+            stage = s1;
+        }
     }
     gemm_epilogue<EPI>(g, acc, m0, n0, wm, wn, lane, tile_n);
 }
@@ -513,14 +553,19 @@ static int launch_glds(const GemmArgs& g, bra_stream_t stream) {
     int grid = tiles;
     if (EPI == EPI_ATOMIC) grid = tiles * (g.split_k > 0 ? g.split_k : 1);
     const size_t smem = 3 * (size_t)(256 + 128) * 64 * 2;
-    BRA_ALLOW_SMEM((gemm_glds_kernel<EPI>), smem);
-    BRA_LAUNCH((gemm_glds_kernel<EPI>), dim3(grid), dim3(512), smem, stream, g);
+    if (pick_variant(g) == 5) {
+        BRA_ALLOW_SMEM((gemm_glds_kernel<EPI, 1>), smem);
+        BRA_LAUNCH((gemm_glds_kernel<EPI, 1>), dim3(grid), dim3(512), smem, stream, g);
+    } else {
+        BRA_ALLOW_SMEM((gemm_glds_kernel<EPI, 0>), smem);
+        BRA_LAUNCH((gemm_glds_kernel<EPI, 0>), dim3(grid), dim3(512), smem, stream, g);
+    }
     return BRA_LAUNCH_STATUS();
 }
 
 template <int BK, int EPI>
 static int launch_gemm(const GemmArgs& g, bra_stream_t stream) {
-    if (BK == 64 && pick_variant(g) == 4) return launch_glds<EPI>(g, stream);
+    if (BK == 64 && pick_variant(g) >= 4) return launch_glds<EPI>(g, stream);
     switch (pick_variant(g)) {
         case 1: return launch_gemm_v<128, BK, EPI, 2>(g, stream);
         case 2: return launch_gemm_v<256, BK, EPI, 1>(g, stream);

@@ -416,7 +416,7 @@ def test_sampler_greedy_and_topk(backend):
     assert out[1].item() == 42
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 def test_gemm_tile_variants(backend, variant):
     """every tile variant (128/256-row tiles x register prefetch depth 1/2) against the fp32 statement"""
     from bioreason_amd._lib import get_lib

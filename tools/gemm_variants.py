@@ -17,7 +17,7 @@ for name, M, N, K, K2 in shapes:
     a2 = torch.randn(M, K2, device=dev).to(BF) if K2 else None; b2 = torch.randn(N, K2, device=dev).to(BF) if K2 else None
     c = torch.empty(M, N, dtype=BF, device=dev)
     res = {}
-    for v in range(5):
+    for v in range(6):
         get_lib().call("bra_gemm_set_variant", v)
         ms = timeit(lambda: ops.gemm_nt(a, b, a2=a2, b2=b2, out=c))
         res[v] = round(2.0 * M * N * (K + K2) / ms / 1e9)
