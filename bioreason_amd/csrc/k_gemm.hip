@@ -532,8 +532,12 @@ static int g_forced_variant = -1;
 
 static int pick_variant(const GemmArgs& g) {
     if (g_forced_variant >= 0) return g_forced_variant;
-    const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
-    return (tiles256 >= 512 ? 2 : 0) | 1;
+    // measured on MI355X (profiles/r1_gemm_variants.txt): the LDS-DMA kernel with skewed fragment reads wins on every
+    // large-M shape of the path (850-1130 TFLOP/s vs 640-870 for the register-staged 128x128 kernel); it needs
+    // K % 64 == 0 and enough 256x128 tiles to fill the chip, otherwise the 128x128 kernel keeps more CUs busy
+    const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
+    if (g.K % 64 == 0 && g.K2 % 64 == 0 && tiles256 >= 192) return 5;
+    return 0;
 }
 
 template <int BM, int BK, int EPI, int PF>

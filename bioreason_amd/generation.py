@@ -187,7 +187,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
              eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None, seed: int = 0,
              check_every: int = 16, return_full_length: bool = False,
              force_tokens: Optional[torch.Tensor] = None, native_step: bool = True,
-             decode_impl: str = "fused") -> torch.Tensor:
+             decode_impl: str = "fused", prompt_alias=None) -> torch.Tensor:
     """`force_tokens` [B, max_new_tokens] (optional): teacher forcing — the model's own choice is still recorded
     in the output, but the given token is fed back (used to compare decodes position by position)."""
     eng = model.ensure_packed()
@@ -198,12 +198,28 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     eos = -1 if eos_token_id is None else int(eos_token_id)
     pad = int(pad_token_id) if pad_token_id is not None else (eos if eos >= 0 else 0)
     Smax = P + max_new_tokens
-    cache = KVCache(eng, B, Smax, dev)
     am = attention_mask.to(torch.long)
     pos_prompt = (am.cumsum(-1) - 1).masked_fill(am == 0, 0).to(torch.int32)      # TF:generation/utils.py:763-765
     kmask = torch.ones((B, Smax), dtype=torch.uint8, device=dev)
     kmask[:, :P] = am.to(torch.uint8)
-    hid = prefill(model, inputs_embeds, attention_mask, cache, pos_prompt)
+    if prompt_alias is None:
+        cache = KVCache(eng, B, Smax, dev)
+        hid = prefill(model, inputs_embeds, attention_mask, cache, pos_prompt)
+    else:
+        # identical prompts (GRPO: the G copies of a prompt, grpo_trainer.py:107-116) are prefetched once: the rows of a
+        # batched forward are independent, so the K/V rows and the last hidden state of a copy equal its representative's
+        reps = sorted(set(prompt_alias))
+        where = {r: i for i, r in enumerate(reps)}
+        sel = torch.tensor(reps, device=dev)
+        gmap = torch.tensor([where[a] for a in prompt_alias], device=dev)
+        cache_r = KVCache(eng, len(reps), Smax, dev)
+        hid_r = prefill(model, inputs_embeds[sel], attention_mask[sel], cache_r, pos_prompt[sel])
+        cache = KVCache.__new__(KVCache)
+        cache.Smax = Smax
+        cache.k = [t.index_select(0, gmap) for t in cache_r.k]
+        cache.v = [t.index_select(0, gmap) for t in cache_r.v]
+        hid = hid_r.index_select(0, gmap).contiguous()
+        del cache_r
     next_pos = (pos_prompt[:, -1] + 1).contiguous()                               # TF:generation/utils.py:979-984
 
     tokens = torch.full((B, max_new_tokens), pad, dtype=torch.int32, device=dev)

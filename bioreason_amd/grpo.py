@@ -86,3 +86,53 @@ def repeat_sampler_indices(num_samples: int, mini_repeat_count: int, batch_size:
             for index in chunk:
                 out.extend([index] * mini_repeat_count)
     return out
+
+
+@torch.no_grad()
+def per_token_logps_shared_prefix(model, prompt_ids: torch.Tensor, prompt_mask: torch.Tensor, completion_ids: torch.Tensor,
+                                  completion_mask_: torch.Tensor, prompt_alias: Sequence[int], **multimodal) -> torch.Tensor:
+    """`per_token_logps` for a no-grad pass (the reference policy, grpo_trainer.py:628-640) when several rows share a
+    prompt (GRPO's G copies): the prompt is run ONCE per distinct prompt with its K/V kept, then only the C completion
+    tokens of every row are run against [shared prompt K/V | own completion K/V].  Rows of a batched forward are
+    independent and causal attention never lets a prompt position see a completion, so the result equals the
+    full-sequence pass; ~7/8 of the prompt work of a group of 8 is not repeated."""
+    from . import ops
+    from .engine import BF16, SeqMeta
+    from .generation import KVCache
+
+    tm = model.text_model
+    eng = tm.ensure_packed()
+    B, P = prompt_ids.shape
+    C = completion_ids.shape[1]
+    S = P + C
+    dev = prompt_ids.device
+    reps = sorted(set(prompt_alias))
+    where = {r: i for i, r in enumerate(reps)}
+    sel = torch.tensor(reps, device=dev)
+    gmap = torch.tensor([where[a] for a in prompt_alias], device=dev)
+    R = len(reps)
+    embeds = model._inputs_embeds(prompt_ids, multimodal.get("dna_tokenized"), multimodal.get("batch_idx_map"), multimodal.get("dna_alias"))
+    # (1) distinct prompts, K/V captured (positions = arange, as Qwen3Model.forward assigns them, TF:qwen3:391-394)
+    cache_r = KVCache(eng, R, S, dev)
+    meta = SeqMeta(B=R, S=P, pos=torch.arange(P, dtype=torch.int32, device=dev).repeat(R),
+                   kmask=prompt_mask[sel].to(torch.uint8).contiguous(), lora_on=tm._lora_enabled, max_pos=S)
+    x = embeds[sel].reshape(R * P, -1).to(BF16).contiguous()
+    for li in range(eng.L):
+        x, _ = eng.layer_fwd(li, x, meta, save=False, kv_out=(cache_r.k[li], cache_r.v[li], 0))
+    last = torch.arange(R, device=dev, dtype=torch.int32) * P + (P - 1)
+    hid_last = ops.rmsnorm_fwd(ops.gather_rows(last, x), eng.norm_w, eng.eps).index_select(0, gmap)      # [B, H]
+    # (2) every row gets its prompt's K/V, (3) completion tokens only
+    kfull = torch.cat([prompt_mask, completion_mask_.to(prompt_mask.dtype)], dim=1).to(torch.uint8).contiguous()
+    meta2 = SeqMeta(B=B, S=C, pos=(torch.arange(C, dtype=torch.int32, device=dev) + P).repeat(B), kmask=kfull,
+                    lora_on=tm._lora_enabled, max_pos=S)
+    ids32 = completion_ids.to(torch.int32).reshape(-1).contiguous()
+    x2 = torch.empty((B * C, eng.H), dtype=BF16, device=dev)
+    ops.embed_scatter_fwd(ids32, None, eng.E, None, x2)
+    for li in range(eng.L):
+        kc = cache_r.k[li].index_select(0, gmap)
+        vc = cache_r.v[li].index_select(0, gmap)
+        x2, _ = eng.layer_fwd(li, x2, meta2, save=False, kv_out=(kc, vc, P))
+    hid2 = ops.rmsnorm_fwd(x2, eng.norm_w, eng.eps).view(B, C, -1)
+    hsel = torch.cat([hid_last[:, None, :], hid2[:, : C - 1, :]], dim=1).reshape(B * C, -1).contiguous()
+    logp, _ = ops.lmhead_logprob(hsel, eng.E, ids32)
+    return logp.view(B, C)

@@ -35,4 +35,4 @@ def synth_prompt_batch(B: int, n_unique: int, Sd: int = 1024, text_len: int = 12
     dna = torch.stack(dna_rows)
     return {"input_ids": ids.to(device), "attention_mask": torch.ones_like(ids).to(device),
             "dna_tokenized": {"input_ids": dna.to(device), "attention_mask": torch.ones_like(dna).to(device)},
-            "batch_idx_map": bmap, "dna_alias": alias}
+            "batch_idx_map": bmap, "dna_alias": alias, "prompt_alias": [(b // rep) * rep for b in range(B)]}

@@ -82,7 +82,8 @@ class GRPOStepRunner:
         completion_ids = m.generate(input_ids=prompt_ids, attention_mask=prompt_mask, **mm,
                                     max_new_tokens=c.max_completion_length, do_sample=True, temperature=c.temperature,
                                     top_k=c.top_k, top_p=c.top_p, eos_token_id=c.eos_token_id, pad_token_id=c.pad_token_id,
-                                    seed=c.seed + 1000003 * self.step_idx + self.rank, return_full_length=True)
+                                    seed=c.seed + 1000003 * self.step_idx + self.rank, return_full_length=True,
+                                    prompt_alias=batch.get("prompt_alias"))
         mark("rollout")
         if c.eos_token_id is not None:
             cmask = grpo.completion_mask(completion_ids, c.eos_token_id)
@@ -92,7 +93,11 @@ class GRPOStepRunner:
         ref_lp = None
         if c.beta != 0.0:
             with torch.no_grad(), m.text_model.disable_adapter():
-                ref_lp = grpo.per_token_logps(m, prompt_ids, prompt_mask, completion_ids, cmask, **mm)
+                if batch.get("prompt_alias") is not None:
+                    ref_lp = grpo.per_token_logps_shared_prefix(m, prompt_ids, prompt_mask, completion_ids, cmask,
+                                                                batch["prompt_alias"], **mm)
+                else:
+                    ref_lp = grpo.per_token_logps(m, prompt_ids, prompt_mask, completion_ids, cmask, **mm)
         mark("ref_logps")
         # ---- rewards, all-gather over ranks, group statistics, local slice (:651-699)
         rewards = self.reward_fn(completion_ids, cmask).float().contiguous()

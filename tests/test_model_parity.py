@@ -195,3 +195,33 @@ def test_fused_decode_step_matches_unfused(backend, name, lora):
         a, c = int(g_f[bi, t]), int(g_u[bi, t])
         assert abs((scores[bi, t, a] - scores[bi, t, c]).item()) < 0.02 * scores[bi, t].abs().max().item() + 0.05
     assert len(diff) <= 2
+
+
+def test_shared_prefix_paths_equal_full_paths(backend):
+    """prompt_alias (GRPO's repeated prompts): prefill-once rollouts and the shared-prefix reference log-prob pass must
+    reproduce the per-row computations they replace."""
+    from bioreason_amd import grpo
+    fix = torch.load(os.path.join(GOLD, "tiny_a.pt"), weights_only=False)
+    cfg = fix["config"]
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    b.pop("labels")
+    # a batch of 4 = 2 distinct prompts x 2 copies
+    rep = lambda t: t.repeat_interleave(2, dim=0)
+    ids, mask = rep(b["input_ids"]), rep(b["attention_mask"])
+    dna = {k: torch.cat([v[0:2], v[0:2], v[2:4], v[2:4]], 0) for k, v in b["dna_tokenized"].items()}
+    bmap = [0, 0, 1, 1, 2, 2, 3, 3]
+    alias = [0, 0, 2, 2]
+    mm = {"dna_tokenized": dna, "batch_idx_map": bmap}
+    kw = dict(max_new_tokens=6, do_sample=True, temperature=0.6, top_k=20, top_p=0.95, eos_token_id=None, seed=5)
+    g_full = m.generate(input_ids=ids, attention_mask=mask, **mm, **kw)
+    g_shared = m.generate(input_ids=ids, attention_mask=mask, **mm, prompt_alias=alias, **kw)
+    assert torch.equal(g_full.cpu(), g_shared.cpu())
+    comp = g_full
+    cmask = torch.ones_like(comp, dtype=torch.int32)
+    cmask[1, 4:] = 0
+    with torch.no_grad(), m.text_model.disable_adapter():
+        full = grpo.per_token_logps(m, ids, mask, comp, cmask, **mm)
+        shared = grpo.per_token_logps_shared_prefix(m, ids, mask, comp, cmask, alias, **mm)
+    w = cmask.bool().cpu()
+    assert (full.cpu()[w] - shared.cpu()[w]).abs().max() < 0.05
