@@ -35,7 +35,7 @@ def run_smoke(device) -> None:
     text = O.make_qwen3(t, "eager")
     dna = O.make_nt_v2(d, "eager")
     text.load_state_dict({k: v.float() for k, v in fix["state"]["text"].items()}, strict=False)
-    dna.load_state_dict({k: v.float() for k, v in fix["state"]["dna"].items()}, strict=False)
+    dna.load_state_dict({k: v.float() for k, v in fix["state"]["dna"].items() if "inv_freq" not in k}, strict=False)   # (the bf16 fixture would round the rotary buffer)
     text.tie_weights()
     O.apply_lora(text, r=32, alpha=64.0)
     text.load_state_dict({k: v.float() for k, v in fix["state"]["lora"].items()}, strict=False)

@@ -216,6 +216,9 @@ def main():
         fix["bf16_lora"] = {"logits": fw.logits.float().clone(), "loss": fw.loss.float().clone()}
         ref.to(torch.float32)
         path = os.path.join(ROOT, "tests", "golden", f"{name}.pt")
+        if "--check-only" in sys.argv:      # tests/test_oracle.py: restatement == reference, nothing written
+            print(name, "restatement equals the reference class bit for bit")
+            continue
         torch.save(fix, path)
         print(name, "ok ->", path, f"{os.path.getsize(path) / 1e6:.2f} MB", "loss", float(r0["loss"]), float(r1["loss"]),
               "greedy", r1["greedy_ids"].tolist())
