@@ -184,6 +184,7 @@ struct DecAttnArgs {
     float* part_o; float* part_ml;        // [B, Hq, nchunk, hd], [B, Hq, nchunk, 2]
     int B, Hq, Hkv, Smax, cur_len, nchunk;
     float eps, scale;
+    int chunk_off, nchunk_tot;             // slot of this call's chunks inside the partial buffers (shared-prefix split)
 };
 
 // per-head RMSNorm (optional weight) + rotate-half RoPE of the 8-dim slice this lane owns (dims 8*dl .. 8*dl+7);
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
             for (int e = 0; e < 8; ++e) acc[g][e] += wave_shfl_xor(acc[g][e], mk);
         }
         const int hq = hkv * G + g;
-        const long base = ((long)b * a.Hq + hq) * a.nchunk + c;
+        const long base = ((long)b * a.Hq + hq) * a.nchunk_tot + a.chunk_off + c;
         if (kg == 0) {
             f32x4 lo = {acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
             f32x4 hi = {acc[g][4], acc[g][5], acc[g][6], acc[g][7]};
@@ -396,12 +397,13 @@ extern "C" int bra_dec_gemm(const void* x, long ldx, const void* norm_w, float e
 extern "C" int bra_dec_attn_partial(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT,
                                     const float* sinT, const int* pos, void* kc, void* vc, const void* kmask,
                                     float* part_o, float* part_ml, int B, int Hq, int Hkv, int hd, int Smax, int cur_len,
-                                    float eps, float scale, void* stream) {
+                                    float eps, float scale, int chunk_off, int nchunk_tot, void* stream) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || cur_len < 0 || cur_len >= Smax) return BRA_ERR_ARG;
     if (!qkv || !qw || !kw || !cosT || !sinT || !pos || !kc || !vc || !part_o || !part_ml) return BRA_ERR_ARG;
     const int G = Hq / Hkv;
     DecAttnArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, (bf16_t*)kc, (bf16_t*)vc,
-                     (const uint8_t*)kmask, part_o, part_ml, B, Hq, Hkv, Smax, cur_len, (cur_len + 1 + 63) / 64, eps, scale};
+                     (const uint8_t*)kmask, part_o, part_ml, B, Hq, Hkv, Smax, cur_len, (cur_len + 1 + 63) / 64, eps, scale, chunk_off,
+                     nchunk_tot > 0 ? nchunk_tot : (cur_len + 1 + 63) / 64};
     bra_stream_t st = (bra_stream_t)stream;
     dim3 grid((a.nchunk + 3) / 4, Hkv, B);
 #define BRA_DA(HD_, G_)                                                                         \
@@ -411,5 +413,184 @@ extern "C" int bra_dec_attn_partial(const void* qkv, long ldqkv, const void* qw,
     }
     BRA_DA(128, 1) BRA_DA(128, 2) BRA_DA(128, 4) BRA_DA(64, 1) BRA_DA(64, 2) BRA_DA(64, 4) BRA_DA(32, 1) BRA_DA(32, 2) BRA_DA(32, 4)
 #undef BRA_DA
+    return BRA_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------
+// Shared-prefix decode attention.  GRPO decodes G copies of ONE prompt together (grpo_trainer.py:107-116): their
+// prompt K/V rows are identical, so the prompt part of the attention of all copies is one small matrix product per
+// kv-head instead of G passes over the same cache:  S[key][row] = K_p[key][:] . Q[row][:]  with
+// row = (copy, q-head of the group) <= 16 rows  ->  v_mfma_f32_16x16x32_bf16 with the K rows streamed straight into
+// the A fragment;  O^T[d][row] += V_p^T[d][key] . P[key][row]  with the prompt's V^T image (kept from the prefill).
+// One wave per (prompt, kv-head, 64-key chunk); the per-copy completion keys go through dec_attn_partial_kernel on the
+// completion cache; both write (max, sum, O) partials that attn_decode_merge_kernel combines.
+namespace bra {
+
+struct DecSharedArgs {
+    const bf16_t* qkv; long ldqkv;        // [B, (Hq + 2 Hkv) * hd] raw projections of the new token, B = R * copies
+    const bf16_t* qw;                     // q_norm weight [hd]
+    const float* cosT; const float* sinT; // [npos, hd/2]
+    const int* pos;                       // [B]
+    const bf16_t* kp; long kp_sr, kp_sh, kp_ss;     // prompt K: element strides over (prompt, kv-head, position)
+    const bf16_t* vtp; long vt_sr, vt_sh, vt_sd;    // prompt V^T [R, Hkv, hd, pitch]
+    const uint8_t* pmask;                 // [R, P] validity of prompt positions (left padding) or null
+    float* part_o; float* part_ml;
+    int R, copies, Hq, Hkv, P, nchunk_tot;
+    float eps, scale;
+};
+
+template <int HD, int G>
+__global__ __launch_bounds__(64) void dec_attn_shared_kernel(DecSharedArgs a) {
+    constexpr int DS = HD / 32;           // 32-deep contraction steps over the head dim
+    constexpr int DB = HD / 16;           // 16-wide output blocks over the head dim
+    const int lane = lane_id();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int c = (int)blockIdx.x, hkv = (int)blockIdx.y, r = (int)blockIdx.z;
+    const int s0 = c * 64;
+    const int rows = a.copies * G;                         // live query rows (<= 16)
+    const int qrow = fr < rows ? fr : rows - 1;
+    const int copy = qrow / G, g = qrow % G;
+    const int b = r * a.copies + copy, hq = hkv * G + g;
+    // ---- K rows of the chunk, straight into MFMA A fragments: lane (fr, fq) holds K[key][32 s + 8 fq .. +8]
+    const bf16_t* kbase = a.kp + r * a.kp_sr + hkv * a.kp_sh;
+    u32x4 kf[4][DS];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        int key = s0 + kb * 16 + fr; key = key < a.P ? key : a.P - 1;
+#pragma unroll
+        for (int s = 0; s < DS; ++s) kf[kb][s] = ld16(kbase + (long)key * a.kp_ss + s * 32 + fq * 8);
+    }
+    // ---- V^T fragments: lane (fr = d within block, fq) holds the 4+4 keys {32 kk + 4 fq + j, 32 kk + 16 + 4 fq + j}
+    const bf16_t* vbase = a.vtp + r * a.vt_sr + hkv * a.vt_sh;
+    u32x4 vf[DB][2];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16_t* vp = vbase + (long)(db * 16 + fr) * a.vt_sd + s0 + kk * 32 + fq * 4;
+            const u32x2 lo = ld8(vp), hi = ld8(vp + 16);
+            vf[db][kk].x = lo.x; vf[db][kk].y = lo.y; vf[db][kk].z = hi.x; vf[db][kk].w = hi.y;
+        }
+    // ---- query row: this lane's four 8-dim slices {32 s + 8 fq}; the rotation partner of slice s is slice s ^ (DS/2)
+    const bf16_t* qp = a.qkv + (long)b * a.ldqkv + (long)hq * HD;
+    float qv[DS][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+        unpack8(ld16(qp + s * 32 + fq * 8), qv[s]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss += qv[s][i] * qv[s][i];
+    }
+    ss += wave_shfl_xor(ss, 16);
+    ss += wave_shfl_xor(ss, 32);
+    const float rstd = rsqrtf(ss / (float)HD + a.eps);
+    const int p = a.pos[b];
+    const float* cosr = a.cosT + (long)p * (HD / 2);
+    const float* sinr = a.sinT + (long)p * (HD / 2);
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+        float w[8];
+        unpack8(ld16(a.qw + s * 32 + fq * 8), w);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[s][i] = round_bf(w[i] * round_bf(qv[s][i] * rstd));
+    }
+    const float sc = a.scale * kLog2eD;
+    u32x4 qf[DS];
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+        const bool upper = s >= DS / 2;
+        const int sp = s ^ (DS / 2);
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int hidx = (s & (DS / 2 - 1)) * 32 + fq * 8 + i;      // index into the half-dim cos / sin row
+            const float cv = cosr[hidx], sv = sinr[hidx];
+            const float rot = upper ? qv[s][i] * cv + qv[sp][i] * sv : qv[s][i] * cv - qv[sp][i] * sv;
+            o[i] = round_bf(rot) * sc;
+        }
+        qf[s] = pack8(o);
+    }
+    // ---- validity of the 64 prompt positions of this chunk
+    uint64_t vbits;
+    {
+        const int key = s0 + lane;
+        const bool okk = key < a.P;
+        const uint8_t mb = a.pmask ? a.pmask[(long)r * a.P + (okk ? key : a.P - 1)] : (uint8_t)1;
+        vbits = wave_ballot(okk && mb != 0);
+    }
+    // ---- scores: D[key = 4 fq + j][row = fr] per 16-key block
+    f32x4 sreg[4];
+    float m = kNegD;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < DS; ++s) acc = mfma_16x16x32(kf[kb][s], qf[s], acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rel_ = kb * 16 + 4 * fq + j;
+            const bool ok = (vbits >> rel_) & 1ull;
+            acc[j] = ok ? acc[j] : kNegD;
+            m = fmaxf(m, acc[j]);
+        }
+        sreg[kb] = acc;
+    }
+    m = fmaxf(m, wave_shfl_xor(m, 16));
+    m = fmaxf(m, wave_shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pr = sreg[kb][j] > 0.5f * kNegD ? exp2f(sreg[kb][j] - m) : 0.f;
+            sreg[kb][j] = pr;
+            l += pr;
+        }
+    l += wave_shfl_xor(l, 16);
+    l += wave_shfl_xor(l, 32);
+    // ---- O^T[d][row] += V^T . P : k-slots of lane group fq <-> keys {32 kk + 4 fq + j} U {32 kk + 16 + 4 fq + j}
+    const long base = ((long)b * a.Hq + hq) * a.nchunk_tot + c;
+    const bool live = fr < rows;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 pf;
+            pf.x = pack_bf2(sreg[2 * kk][0], sreg[2 * kk][1]);
+            pf.y = pack_bf2(sreg[2 * kk][2], sreg[2 * kk][3]);
+            pf.z = pack_bf2(sreg[2 * kk + 1][0], sreg[2 * kk + 1][1]);
+            pf.w = pack_bf2(sreg[2 * kk + 1][2], sreg[2 * kk + 1][3]);
+            acc = mfma_16x16x32(vf[db][kk], pf, acc);
+        }
+        if (live) *reinterpret_cast<f32x4*>(a.part_o + base * HD + db * 16 + 4 * fq) = acc;   // d = 16 db + 4 fq + j
+    }
+    if (live && fq == 0) { a.part_ml[base * 2] = m; a.part_ml[base * 2 + 1] = l; }
+}
+
+}  // namespace bra
+
+extern "C" int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, const float* cosT, const float* sinT,
+                                   const int* pos, const void* kp, long kp_sr, long kp_sh, long kp_ss, const void* vtp,
+                                   long vt_sr, long vt_sh, long vt_sd, const void* pmask, float* part_o, float* part_ml,
+                                   int R, int copies, int Hq, int Hkv, int hd, int P, int nchunk_tot, float eps,
+                                   float scale, void* stream) {
+    if (R <= 0 || copies <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || P <= 0) return BRA_ERR_ARG;
+    const int G = Hq / Hkv;
+    if (copies * G > 16) return BRA_ERR_UNSUPPORTED;
+    if (!qkv || !qw || !cosT || !sinT || !pos || !kp || !vtp || !part_o || !part_ml) return BRA_ERR_ARG;
+    if (vt_sd < ((P + 63) / 64) * 64 || vt_sd % 4 || kp_ss % 8) return BRA_ERR_ARG;
+    DecSharedArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, cosT, sinT, pos, (const bf16_t*)kp, kp_sr, kp_sh, kp_ss,
+                       (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask, part_o, part_ml, R, copies, Hq, Hkv, P,
+                       nchunk_tot, eps, scale};
+    bra_stream_t st = (bra_stream_t)stream;
+    dim3 grid((P + 63) / 64, Hkv, R);
+#define BRA_DS(HD_, G_)                                                                         \
+    if (hd == HD_ && G == G_) {                                                                 \
+        BRA_LAUNCH((dec_attn_shared_kernel<HD_, G_>), grid, dim3(64), 0, st, a);                \
+        return BRA_LAUNCH_STATUS();                                                             \
+    }
+    BRA_DS(128, 1) BRA_DS(128, 2) BRA_DS(128, 4) BRA_DS(64, 1) BRA_DS(64, 2) BRA_DS(64, 4)   // hd 32: per-copy path
+#undef BRA_DS
     return BRA_ERR_UNSUPPORTED;
 }

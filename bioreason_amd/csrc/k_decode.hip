@@ -14,6 +14,7 @@ struct Layer {
     int r_qkv, r_o, r_gu, r_d;                                         // padded ranks
     float s_qkv, s_o, s_gu, s_d;                                       // alpha / r
     void *kc, *vc;                                                     // KV cache [B, Hkv, Smax, hd]
+    const void *kp, *vtp;                                              // shared prompt K [R,Hkv,P,hd] and V^T [R,Hkv,hd,pitch]
 };
 
 }  // namespace
@@ -81,8 +82,42 @@ extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B,
         const Layer& l = ls[li];
         CK(bra_dec_gemm(x, H, l.ln1, eps, l.Wqkv, H, nullptr, 0, qkv, Nqkv, B, Nqkv, H, 0, 0, stream));
         CK(bra_dec_attn_partial(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, l.kc, l.vc, kmask, part_o, part_ml, B, Hq, Hkv, hd,
-                                Smax, cur_len, eps, scale, stream));
+                                Smax, cur_len, eps, scale, 0, 0, stream));
         CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, nchunk, stream));
+        CK(bra_dec_gemm(o, Nq, nullptr, 0.f, l.Wo, Nq, x, H, h, H, B, H, Nq, 0, 0, stream));
+        CK(bra_dec_gemm(h, H, l.ln2, eps, l.Wgu, H, nullptr, 0, act, F, B, 2 * F, H, 1, 0, stream));
+        CK(bra_dec_gemm(act, F, nullptr, 0.f, l.Wd, F, h, H, x, H, B, H, F, 0, 0, stream));
+    }
+    if (logits) CK(bra_dec_gemm(x, H, norm_w, eps, E, H, nullptr, 0, logits, V, B, V, H, 0, 1, stream));
+#undef CK
+    return 0;
+}
+
+
+// Shared-prefix variant: the B = R * copies sequences are grouped by prompt; the prompt part of the attention reads
+// ONE copy of the prompt K / V^T (bra_dec_attn_shared), the completion part the per-sequence completion cache
+// kc / vc [B, Hkv, C, hd] at index `t` (number of completion tokens already cached).  7 launches per layer.
+extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R, int copies, int H, int Hq, int Hkv, int hd,
+                                           int F, int P, long vt_pitch, int C, int V, float eps, float scale, const void* E,
+                                           const void* norm_w, const float* cosT, const float* sinT, const int* tok,
+                                           const int* pos, const void* pmask, int t, void* x, void* qkv, void* o, void* h,
+                                           void* act, float* part_o, float* part_ml, float* logits, void* stream) {
+    const Layer* ls = (const Layer*)layers_host;
+    const int B = R * copies;
+    const int Nq = Hq * hd, Nkv = Hkv * hd, Nqkv = Nq + 2 * Nkv;
+    const int npc = (P + 63) / 64, ncc = (t + 1 + 63) / 64, ntot = npc + ncc;
+    int rc;
+#define CK(call) do { rc = (call); if (rc) return rc; } while (0)
+    CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));
+    for (int li = 0; li < L; ++li) {
+        const Layer& l = ls[li];
+        CK(bra_dec_gemm(x, H, l.ln1, eps, l.Wqkv, H, nullptr, 0, qkv, Nqkv, B, Nqkv, H, 0, 0, stream));
+        CK(bra_dec_attn_shared(qkv, Nqkv, l.qn, cosT, sinT, pos, l.kp, (long)Hkv * P * hd, (long)P * hd, (long)hd, l.vtp,
+                               (long)Hkv * hd * vt_pitch, (long)hd * vt_pitch, vt_pitch, pmask, part_o, part_ml, R, copies, Hq,
+                               Hkv, hd, P, ntot, eps, scale, stream));
+        CK(bra_dec_attn_partial(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, l.kc, l.vc, nullptr, part_o, part_ml, B, Hq, Hkv, hd,
+                                C, t, eps, scale, npc, ntot, stream));
+        CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, ntot, stream));
         CK(bra_dec_gemm(o, Nq, nullptr, 0.f, l.Wo, Nq, x, H, h, H, B, H, Nq, 0, 0, stream));
         CK(bra_dec_gemm(h, H, l.ln2, eps, l.Wgu, H, nullptr, 0, act, F, B, 2 * F, H, 1, 0, stream));
         CK(bra_dec_gemm(act, F, nullptr, 0.f, l.Wd, F, h, H, x, H, B, H, F, 0, 0, stream));

@@ -188,12 +188,14 @@ class QwenEngine:
             v = torch.empty((B, S, self.Hkv, self.hd), dtype=BF16, device=x.device)
             s_off = 0
         else:
-            kc, vc, s_off = kv_out
+            kc, vc, s_off = kv_out[:3]
             k, v = kc.permute(0, 2, 1, 3), vc.permute(0, 2, 1, 3)        # [B, Smax, Hkv, hd] views
         ops.qk_norm_rope_fwd(qkv, L.qn, L.kn, cosT, sinT, m.pos, S, self.Hq, self.Hkv, self.hd, self.eps, 1.0, q, k, v, s_off)
         if kv_out is not None:
             k, v = k[:, :s_off + S], v[:, :s_off + S]
         vt = ops.head_transpose(v)
+        if kv_out is not None and len(kv_out) > 3 and kv_out[3] is not None:
+            kv_out[3].append(vt)                                          # the prompt's V^T image, kept for shared-prefix decode
         o, lse = ops.attn_fwd(q, k, vt, m.kmask, True, self.scale, need_lse=save)
         o2 = o.view(T, self.Nq)
         h, t2 = self._lora_fwd(o2, L.Wo, L.lora["o"], m.lora_on, res=x)

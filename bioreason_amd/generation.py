@@ -31,7 +31,8 @@ class KVCache:
 
 
 @torch.no_grad()
-def prefill(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, cache: KVCache, pos: torch.Tensor):
+def prefill(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, cache: KVCache, pos: torch.Tensor,
+            vt_sink=None):
     """Runs the prompt through the stack writing K/V into the cache; returns the last-position hidden rows [B, H]."""
     eng = model.ensure_packed()
     B, S, H = inputs_embeds.shape
@@ -40,7 +41,7 @@ def prefill(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, ca
                    max_pos=cache.Smax + 1)
     x = inputs_embeds.reshape(B * S, H).to(BF16).contiguous()
     for li in range(eng.L):
-        x, _ = eng.layer_fwd(li, x, meta, save=False, kv_out=(cache.k[li], cache.v[li], 0))
+        x, _ = eng.layer_fwd(li, x, meta, save=False, kv_out=(cache.k[li], cache.v[li], 0, vt_sink))
     last = (torch.arange(B, device=x.device, dtype=torch.int32) * S + (S - 1))
     xl = ops.gather_rows(last, x)
     return ops.rmsnorm_fwd(xl, eng.norm_w, eng.eps)
@@ -51,7 +52,7 @@ class _LayerDesc(ctypes.Structure):
                                                 "B_o", "A_gu", "B_gu", "A_d", "B_d")]
                 + [(n, ctypes.c_int) for n in ("r_qkv", "r_o", "r_gu", "r_d")]
                 + [(n, ctypes.c_float) for n in ("s_qkv", "s_o", "s_gu", "s_d")]
-                + [("kc", ctypes.c_void_p), ("vc", ctypes.c_void_p)])
+                + [("kc", ctypes.c_void_p), ("vc", ctypes.c_void_p), ("kp", ctypes.c_void_p), ("vtp", ctypes.c_void_p)])
 
 
 class DecodeState:
@@ -155,6 +156,57 @@ class FusedDecodeState:
                        self.x, self.qkv, self.o, self.h, self.act, self.part_o, self.part_ml, logits, current_stream(self.x))
 
 
+class SharedDecodeState:
+    """`bra_qwen_decode_step_shared`: R prompts x `copies` sequences; prompt K / V^T are held once per prompt, each
+    sequence owns only a completion cache [Hkv, C, hd]."""
+
+    def __init__(self, model, cache_r: KVCache, vtp, R: int, copies: int, P: int, C: int):
+        eng: QwenEngine = model.engine
+        dev = eng.device
+        B = R * copies
+        self.eng, self.R, self.copies, self.P, self.C, self.B = eng, R, copies, P, C, B
+        self.rw = rollout_weights(model)
+        self.kp, self.vtp = cache_r.k, vtp                       # [R,Hkv,P,hd], [R,Hkv,hd,pitch]
+        self.kc = [torch.zeros((B, eng.Hkv, C, eng.hd), dtype=BF16, device=dev) for _ in range(eng.L)]
+        self.vc = [torch.zeros((B, eng.Hkv, C, eng.hd), dtype=BF16, device=dev) for _ in range(eng.L)]
+        self.vt_pitch = vtp[0].shape[-1]
+        arr = (_LayerDesc * eng.L)()
+        for i, (L, Rw) in enumerate(zip(eng.layers, self.rw)):
+            d = arr[i]
+            d.ln1, d.ln2, d.qn, d.kn = L.ln1.data_ptr(), L.ln2.data_ptr(), L.qn.data_ptr(), L.kn.data_ptr()
+            d.Wqkv, d.Wo, d.Wgu, d.Wd = Rw["Wqkv"].data_ptr(), Rw["Wo"].data_ptr(), Rw["Wgu"].data_ptr(), Rw["Wd"].data_ptr()
+            d.kc, d.vc = self.kc[i].data_ptr(), self.vc[i].data_ptr()
+            d.kp, d.vtp = self.kp[i].data_ptr(), self.vtp[i].data_ptr()
+        self.arr = arr
+
+        def buf(n):
+            return torch.empty((B, n), dtype=BF16, device=dev)
+
+        self.x, self.h, self.qkv, self.o, self.act = buf(eng.H), buf(eng.H), buf(eng.Nq + 2 * eng.Nkv), buf(eng.Nq), buf(eng.F)
+        nch = (P + 63) // 64 + (C + 63) // 64
+        self.part_o = torch.empty((B, eng.Hq, nch, eng.hd), dtype=torch.float32, device=dev)
+        self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
+        self.cosT, self.sinT = eng.rope(P + C + 1)
+
+    def step(self, tok, pos, pmask, t: int, logits: torch.Tensor):
+        e = self.eng
+        get_lib().call("bra_qwen_decode_step_shared", ctypes.addressof(self.arr), e.L, self.R, self.copies, e.H, e.Hq, e.Hkv,
+                       e.hd, e.F, self.P, self.vt_pitch, self.C, e.V, e.eps, e.scale, e.E, e.norm_w, self.cosT, self.sinT, tok,
+                       pos, pmask, t, self.x, self.qkv, self.o, self.h, self.act, self.part_o, self.part_ml, logits,
+                       current_stream(self.x))
+
+
+def _uniform_groups(prompt_alias):
+    """-> (R, copies) if the aliases describe R contiguous groups of equal size led by their first row, else None"""
+    B = len(prompt_alias)
+    reps = sorted(set(prompt_alias))
+    R = len(reps)
+    if R == 0 or B % R:
+        return None
+    c = B // R
+    return (R, c) if all(prompt_alias[b] == (b // c) * c for b in range(B)) else None
+
+
 @torch.no_grad()
 def decode_step(model, tok: torch.Tensor, cache: KVCache, kmask: torch.Tensor, pos: torch.Tensor, cur_len: int):
     """(Python-orchestrated variant, kept for tests) tok int32 [B] -> final hidden [B, H]."""
@@ -202,6 +254,10 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     pos_prompt = (am.cumsum(-1) - 1).masked_fill(am == 0, 0).to(torch.int32)      # TF:generation/utils.py:763-765
     kmask = torch.ones((B, Smax), dtype=torch.uint8, device=dev)
     kmask[:, :P] = am.to(torch.uint8)
+    shared = None
+    grp = _uniform_groups(prompt_alias) if prompt_alias is not None else None
+    use_shared = (grp is not None and native_step and decode_impl == "fused" and eng.hd >= 64
+                  and grp[1] * (eng.Hq // eng.Hkv) <= 16)
     if prompt_alias is None:
         cache = KVCache(eng, B, Smax, dev)
         hid = prefill(model, inputs_embeds, attention_mask, cache, pos_prompt)
@@ -212,14 +268,23 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         where = {r: i for i, r in enumerate(reps)}
         sel = torch.tensor(reps, device=dev)
         gmap = torch.tensor([where[a] for a in prompt_alias], device=dev)
-        cache_r = KVCache(eng, len(reps), Smax, dev)
-        hid_r = prefill(model, inputs_embeds[sel], attention_mask[sel], cache_r, pos_prompt[sel])
-        cache = KVCache.__new__(KVCache)
-        cache.Smax = Smax
-        cache.k = [t.index_select(0, gmap) for t in cache_r.k]
-        cache.v = [t.index_select(0, gmap) for t in cache_r.v]
+        if use_shared:
+            # decode reads ONE copy of the prompt K / V^T per prompt (bra_dec_attn_shared); no per-copy replication
+            cache_r = KVCache(eng, len(reps), P, dev)
+            vtp = []
+            hid_r = prefill(model, inputs_embeds[sel], attention_mask[sel], cache_r, pos_prompt[sel], vt_sink=vtp)
+            shared = SharedDecodeState(model, cache_r, vtp, grp[0], grp[1], P, max_new_tokens)
+            pmask = am[sel].to(torch.uint8).contiguous()
+            cache = None
+        else:
+            cache_r = KVCache(eng, len(reps), Smax, dev)
+            hid_r = prefill(model, inputs_embeds[sel], attention_mask[sel], cache_r, pos_prompt[sel])
+            cache = KVCache.__new__(KVCache)
+            cache.Smax = Smax
+            cache.k = [t.index_select(0, gmap) for t in cache_r.k]
+            cache.v = [t.index_select(0, gmap) for t in cache_r.v]
+            del cache_r
         hid = hid_r.index_select(0, gmap).contiguous()
-        del cache_r
     next_pos = (pos_prompt[:, -1] + 1).contiguous()                               # TF:generation/utils.py:979-984
 
     tokens = torch.full((B, max_new_tokens), pad, dtype=torch.int32, device=dev)
@@ -231,7 +296,9 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     kk = (min(top_k, 64) if top_k > 0 else 64) if do_sample else 1
     sample_ws = torch.empty((2 * B * 64 * kk,), dtype=torch.float32, device=dev) if eng.V >= 4096 else None
     fused = native_step and decode_impl == "fused"
-    state = (FusedDecodeState(model, cache, B) if fused else DecodeState(model, cache, B)) if native_step else None
+    state = None
+    if shared is None and native_step:
+        state = FusedDecodeState(model, cache, B) if fused else DecodeState(model, cache, B)
     ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
     for t in range(max_new_tokens):
         ops.sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished if eos >= 0 else None, pad,
@@ -243,7 +310,9 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             break
         if force_tokens is not None:
             cur = force_tokens[:, t].to(torch.int32).contiguous()
-        if fused:
+        if shared is not None:
+            shared.step(cur, next_pos, pmask, t, logits)
+        elif fused:
             state.step(cur, next_pos, kmask, P + t, logits)
         else:
             if state is not None:

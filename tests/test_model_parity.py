@@ -225,3 +225,32 @@ def test_shared_prefix_paths_equal_full_paths(backend):
         shared = grpo.per_token_logps_shared_prefix(m, ids, mask, comp, cmask, alias, **mm)
     w = cmask.bool().cpu()
     assert (full.cpu()[w] - shared.cpu()[w]).abs().max() < 0.05
+
+
+def test_shared_prefix_decode_kernel_matches_per_copy_decode(backend):
+    """bra_dec_attn_shared (one MFMA pass over the prompt K / V^T for all copies of a prompt) + per-copy completion
+    attention against the per-copy fused decode: same choices under teacher forcing (hd = 128, G = 2, 2 copies)."""
+    fix = torch.load(os.path.join(GOLD, "tiny_b.pt"), weights_only=False)
+    cfg = fix["config"]
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    rows = [0, 0, 1, 1]
+    ids, mask = b["input_ids"][rows], b["attention_mask"][rows]
+    dna = {k: v[rows] for k, v in b["dna_tokenized"].items()}       # one DNA sequence per sample in tiny_b
+    mm = {"dna_tokenized": dna, "batch_idx_map": [0, 1, 2, 3]}
+    want = fix["fp32_lora"]["greedy_ids"][rows].to(backend)
+    scores = fix["fp32_lora"]["greedy_scores"][rows]
+    kw = dict(max_new_tokens=cfg["gen_tokens"], do_sample=False, eos_token_id=None, force_tokens=want)
+    g_u = m.generate(input_ids=ids, attention_mask=mask, **mm, **kw)
+    g_s = m.generate(input_ids=ids, attention_mask=mask, **mm, prompt_alias=[0, 0, 2, 2], **kw)
+    diff = (g_u != g_s).nonzero().tolist()
+    for bi, t in diff:
+        a, c = int(g_u[bi, t]), int(g_s[bi, t])
+        assert abs((scores[bi, t, a] - scores[bi, t, c]).item()) < 0.02 * scores[bi, t].abs().max().item() + 0.05
+    assert len(diff) <= 2
+    # and with sampling the two paths draw from the same distribution: identical seeds give identical tokens unless a
+    # probability boundary falls inside the bf16 noise of the two attention orders
+    kw2 = dict(max_new_tokens=6, do_sample=True, temperature=0.6, top_k=20, top_p=0.95, eos_token_id=None, seed=11)
+    s_u = m.generate(input_ids=ids, attention_mask=mask, **mm, **kw2)
+    s_s = m.generate(input_ids=ids, attention_mask=mask, **mm, prompt_alias=[0, 0, 2, 2], **kw2)
+    assert (s_u[:, 0] == s_s[:, 0]).all()        # first token comes from the prefill in both

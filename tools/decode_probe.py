@@ -14,7 +14,7 @@ if os.environ.get("PROBE_LORA", "1") == "1":
     m.text_model.apply_lora(r=32, alpha=64.0, arena=m.arena)
 b = synth_prompt_batch(B=8, n_unique=1, dna_token_id=m.dna_token_id, device=dev)
 kw = dict(input_ids=b["input_ids"], attention_mask=b["attention_mask"], dna_tokenized=b["dna_tokenized"], batch_idx_map=b["batch_idx_map"],
-          dna_alias=b["dna_alias"], do_sample=True, temperature=0.6, top_k=20, top_p=0.95, eos_token_id=None)
+          dna_alias=b["dna_alias"], prompt_alias=b["prompt_alias"], do_sample=True, temperature=0.6, top_k=20, top_p=0.95, eos_token_id=None)
 for it in range(2):
     torch.cuda.synchronize(); t0 = time.time()
     m.generate(max_new_tokens=1, **kw); torch.cuda.synchronize(); t1 = time.time()
