@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue the rollout's decode steps eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-shared-decode", action="store_true", help="per-copy prompt K/V in the decode attention")
     ap.add_argument("--completion-len", type=int, default=C)
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the oracle timing leg and print its JSON")
     args = ap.parse_args()
@@ -140,7 +142,8 @@ def main():
         if "lora_B" in n:
             p.data.copy_((torch.randn(p.shape, generator=gen) * 0.01).to(dev))
     model.arena.pack()
-    cfg = GRPOConfig(num_generations=G, max_completion_length=args.completion_len, eos_token_id=None, seed=42)
+    cfg = GRPOConfig(num_generations=G, max_completion_length=args.completion_len, eos_token_id=None, seed=42,
+                     rollout_graph=False if args.no_graph else None, rollout_shared_prefix=not args.no_shared_decode)
     runner = GRPOStepRunner(model, cfg)
     batch = synth_prompt_batch(B=G, n_unique=1, Sd=SD, text_len=TEXT_LEN, n_dna=NDNA, dna_token_id=model.dna_token_id,
                                device=dev, seed=42 + rank)

@@ -546,6 +546,7 @@ struct DecodeArgs {
     bf16_t* o;            // [B, Hq*hd]
     int B, Hq, Hkv, hd, Smax, len, chunk, nchunk;
     float scale;
+    const int* t_ptr; int npc;   // merge only: device-side chunk count = npc + ceil((t+1)/64)
 };
 
 // partial kernel: a wave owns CK = 128 consecutive cached positions of one (sequence, kv-head).
@@ -658,15 +659,16 @@ template <int HD>
 __global__ __launch_bounds__(64) void attn_decode_merge_kernel(DecodeArgs a) {
     const int lane = lane_id();
     const int hq = (int)blockIdx.x, b = (int)blockIdx.y;
-    const long base = ((long)b * a.Hq + hq) * a.nchunk;
+    const int nchunk = a.t_ptr ? a.npc + (a.t_ptr[0] + 64) / 64 : a.nchunk;
+    const long base = ((long)b * a.Hq + hq) * nchunk;
     // lane c holds the (max, sum) pair of chunk c (+64, ...): one round of loads, then wave reductions
     float mc[4], lc[4];
     float m = kNeg;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int c = lane + 64 * r;
-        mc[r] = c < a.nchunk ? a.part_ml[(base + c) * 2] : kNeg;
-        lc[r] = c < a.nchunk ? a.part_ml[(base + c) * 2 + 1] : 0.f;
+        mc[r] = c < nchunk ? a.part_ml[(base + c) * 2] : kNeg;
+        lc[r] = c < nchunk ? a.part_ml[(base + c) * 2 + 1] : 0.f;
         m = fmaxf(m, mc[r]);
     }
     m = wave_max<64>(m);
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(64) void attn_decode_merge_kernel(DecodeArgs a) {
     float acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    const int nc = a.nchunk < 256 ? a.nchunk : 256;
+    const int nc = nchunk < 256 ? nchunk : 256;
     for (int c0 = 0; c0 < nc; c0 += 8) {
         float v[8][EPL], w[8];
 #pragma unroll
@@ -814,11 +816,11 @@ extern "C" int bra_attn_decode(const void* q, const void* kc, const void* vc, co
 }
 
 extern "C" int bra_attn_decode_merge(const float* part_o, const float* part_ml, void* o, int B, int Hq, int hd, int nchunk,
-                                     void* stream) {
+                                     const int* t_dev, int npc, void* stream) {
     if (B <= 0 || Hq <= 0 || nchunk <= 0 || !part_o || !part_ml || !o) return BRA_ERR_ARG;
     DecodeArgs a = {};
     a.part_o = const_cast<float*>(part_o); a.part_ml = const_cast<float*>(part_ml); a.o = (bf16_t*)o;
-    a.B = B; a.Hq = Hq; a.hd = hd; a.nchunk = nchunk;
+    a.B = B; a.Hq = Hq; a.hd = hd; a.nchunk = nchunk; a.t_ptr = t_dev; a.npc = npc;
     bra_stream_t st = (bra_stream_t)stream;
     if (hd == 128) BRA_LAUNCH((attn_decode_merge_kernel<128>), dim3(Hq, B), dim3(64), 0, st, a);
     else if (hd == 64) BRA_LAUNCH((attn_decode_merge_kernel<64>), dim3(Hq, B), dim3(64), 0, st, a);

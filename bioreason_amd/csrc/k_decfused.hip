@@ -185,6 +185,7 @@ struct DecAttnArgs {
     int B, Hq, Hkv, Smax, cur_len, nchunk;
     float eps, scale;
     int chunk_off, nchunk_tot;             // slot of this call's chunks inside the partial buffers (shared-prefix split)
+    const int* t_ptr;                      // optional device-side cur_len (graph replay: the launch arguments stay constant)
 };
 
 // per-head RMSNorm (optional weight) + rotate-half RoPE of the 8-dim slice this lane owns (dims 8*dl .. 8*dl+7);
@@ -219,8 +220,10 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
     const int lane = lane_id();
     const int c = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     const int hkv = (int)blockIdx.y, b = (int)blockIdx.z;
-    if (c >= a.nchunk) return;
-    const int len = a.cur_len + 1;
+    int cur_len = a.cur_len, nchunk = a.nchunk, nchunk_tot = a.nchunk_tot;
+    if (a.t_ptr) { cur_len = a.t_ptr[0]; nchunk = (cur_len + 64) / 64; nchunk_tot = a.chunk_off + nchunk; }
+    if (c >= nchunk) return;
+    const int len = cur_len + 1;
     const int s_begin = c * CK;
     int s_end = s_begin + CK;
     s_end = s_end < len ? s_end : len;
@@ -261,19 +264,19 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
     unpack8(ld16(row + Nq + (long)hkv * HD + dl * 8), kn);
     norm_rope_slice<HD>(kn, a.kw, cosr, sinr, dl, a.eps);
     unpack8(ld16(row + Nq + Nkv + (long)hkv * HD + dl * 8), vn);
-    const bool owns_new = a.cur_len >= s_begin && a.cur_len < s_begin + CK;
+    const bool owns_new = cur_len >= s_begin && cur_len < s_begin + CK;
     if (owns_new && kg == 0) {
-        st16(kb_ + (long)a.cur_len * HD, pack8(kn));
-        st16(vb_ + (long)a.cur_len * HD, pack8(vn));
+        st16(kb_ + (long)cur_len * HD, pack8(kn));
+        st16(vb_ + (long)cur_len * HD, pack8(vn));
     }
-    const int new_rel = owns_new ? a.cur_len - s_begin : -1;
+    const int new_rel = owns_new ? cur_len - s_begin : -1;
     // ---- validity bits of the 128 positions
     uint64_t vbits;
     {
         const int key = s_begin + lane;
         const bool okk = key < s_end;
         const uint8_t mraw = a.kmask ? a.kmask[(long)b * a.Smax + (okk ? key : s_end - 1)] : (uint8_t)1;
-        vbits = wave_ballot(okk && (mraw != 0 || key == a.cur_len));
+        vbits = wave_ballot(okk && (mraw != 0 || key == cur_len));
     }
     float sco[NIT][G];
     float m[G];
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
             for (int e = 0; e < 8; ++e) acc[g][e] += wave_shfl_xor(acc[g][e], mk);
         }
         const int hq = hkv * G + g;
-        const long base = ((long)b * a.Hq + hq) * a.nchunk_tot + a.chunk_off + c;
+        const long base = ((long)b * a.Hq + hq) * nchunk_tot + a.chunk_off + c;
         if (kg == 0) {
             f32x4 lo = {acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
             f32x4 hi = {acc[g][4], acc[g][5], acc[g][6], acc[g][7]};
@@ -397,13 +400,13 @@ extern "C" int bra_dec_gemm(const void* x, long ldx, const void* norm_w, float e
 extern "C" int bra_dec_attn_partial(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT,
                                     const float* sinT, const int* pos, void* kc, void* vc, const void* kmask,
                                     float* part_o, float* part_ml, int B, int Hq, int Hkv, int hd, int Smax, int cur_len,
-                                    float eps, float scale, int chunk_off, int nchunk_tot, void* stream) {
+                                    float eps, float scale, int chunk_off, int nchunk_tot, const int* t_dev, void* stream) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || cur_len < 0 || cur_len >= Smax) return BRA_ERR_ARG;
     if (!qkv || !qw || !kw || !cosT || !sinT || !pos || !kc || !vc || !part_o || !part_ml) return BRA_ERR_ARG;
     const int G = Hq / Hkv;
     DecAttnArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, (bf16_t*)kc, (bf16_t*)vc,
                      (const uint8_t*)kmask, part_o, part_ml, B, Hq, Hkv, Smax, cur_len, (cur_len + 1 + 63) / 64, eps, scale, chunk_off,
-                     nchunk_tot > 0 ? nchunk_tot : (cur_len + 1 + 63) / 64};
+                     nchunk_tot > 0 ? nchunk_tot : (cur_len + 1 + 63) / 64, t_dev};
     bra_stream_t st = (bra_stream_t)stream;
     dim3 grid((a.nchunk + 3) / 4, Hkv, B);
 #define BRA_DA(HD_, G_)                                                                         \
@@ -437,6 +440,7 @@ struct DecSharedArgs {
     float* part_o; float* part_ml;
     int R, copies, Hq, Hkv, P, nchunk_tot;
     float eps, scale;
+    const int* t_ptr;                     // optional device-side completion index t: nchunk_tot = ceil(P/64) + ceil((t+1)/64)
 };
 
 template <int HD, int G>
@@ -549,7 +553,8 @@ __global__ __launch_bounds__(64) void dec_attn_shared_kernel(DecSharedArgs a) {
     l += wave_shfl_xor(l, 16);
     l += wave_shfl_xor(l, 32);
     // ---- O^T[d][row] += V^T . P : k-slots of lane group fq <-> keys {32 kk + 4 fq + j} U {32 kk + 16 + 4 fq + j}
-    const long base = ((long)b * a.Hq + hq) * a.nchunk_tot + c;
+    const int ntot = a.t_ptr ? (a.P + 63) / 64 + (a.t_ptr[0] + 64) / 64 : a.nchunk_tot;
+    const long base = ((long)b * a.Hq + hq) * ntot + c;
     const bool live = fr < rows;
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
@@ -574,7 +579,7 @@ extern "C" int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, 
                                    const int* pos, const void* kp, long kp_sr, long kp_sh, long kp_ss, const void* vtp,
                                    long vt_sr, long vt_sh, long vt_sd, const void* pmask, float* part_o, float* part_ml,
                                    int R, int copies, int Hq, int Hkv, int hd, int P, int nchunk_tot, float eps,
-                                   float scale, void* stream) {
+                                   float scale, const int* t_dev, void* stream) {
     if (R <= 0 || copies <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || P <= 0) return BRA_ERR_ARG;
     const int G = Hq / Hkv;
     if (copies * G > 16) return BRA_ERR_UNSUPPORTED;
@@ -582,7 +587,7 @@ extern "C" int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, 
     if (vt_sd < ((P + 63) / 64) * 64 || vt_sd % 4 || kp_ss % 8) return BRA_ERR_ARG;
     DecSharedArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, cosT, sinT, pos, (const bf16_t*)kp, kp_sr, kp_sh, kp_ss,
                        (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask, part_o, part_ml, R, copies, Hq, Hkv, P,
-                       nchunk_tot, eps, scale};
+                       nchunk_tot, eps, scale, t_dev};
     bra_stream_t st = (bra_stream_t)stream;
     dim3 grid((P + 63) / 64, Hkv, R);
 #define BRA_DS(HD_, G_)                                                                         \

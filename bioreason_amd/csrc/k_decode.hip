@@ -70,7 +70,7 @@ extern "C" int bra_qwen_decode_step(const void* layers_host, int L, int B, int H
 extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B, int H, int Hq, int Hkv, int hd, int F,
                                           int Smax, int V, float eps, float scale, const void* E, const void* norm_w,
                                           const float* cosT, const float* sinT, const int* tok, const int* pos,
-                                          const void* kmask, int cur_len, void* x, void* qkv, void* o, void* h, void* act,
+                                          const void* kmask, int cur_len, const int* len_dev, void* x, void* qkv, void* o, void* h, void* act,
                                           float* part_o, float* part_ml, float* logits, void* stream) {
     const Layer* ls = (const Layer*)layers_host;
     const int Nq = Hq * hd, Nkv = Hkv * hd, Nqkv = Nq + 2 * Nkv;
@@ -82,8 +82,8 @@ extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B,
         const Layer& l = ls[li];
         CK(bra_dec_gemm(x, H, l.ln1, eps, l.Wqkv, H, nullptr, 0, qkv, Nqkv, B, Nqkv, H, 0, 0, stream));
         CK(bra_dec_attn_partial(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, l.kc, l.vc, kmask, part_o, part_ml, B, Hq, Hkv, hd,
-                                Smax, cur_len, eps, scale, 0, 0, stream));
-        CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, nchunk, stream));
+                                Smax, cur_len, eps, scale, 0, 0, len_dev, stream));
+        CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, nchunk, len_dev, 0, stream));
         CK(bra_dec_gemm(o, Nq, nullptr, 0.f, l.Wo, Nq, x, H, h, H, B, H, Nq, 0, 0, stream));
         CK(bra_dec_gemm(h, H, l.ln2, eps, l.Wgu, H, nullptr, 0, act, F, B, 2 * F, H, 1, 0, stream));
         CK(bra_dec_gemm(act, F, nullptr, 0.f, l.Wd, F, h, H, x, H, B, H, F, 0, 0, stream));
@@ -97,11 +97,13 @@ extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B,
 // Shared-prefix variant: the B = R * copies sequences are grouped by prompt; the prompt part of the attention reads
 // ONE copy of the prompt K / V^T (bra_dec_attn_shared), the completion part the per-sequence completion cache
 // kc / vc [B, Hkv, C, hd] at index `t` (number of completion tokens already cached).  7 launches per layer.
+// With `t_dev` (device int) the kernels read t from memory and the host `t` only sizes the grids (pass C - 1): the
+// launch arguments are then identical for every step, so the step can be captured once in a hipGraph and replayed.
 extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R, int copies, int H, int Hq, int Hkv, int hd,
                                            int F, int P, long vt_pitch, int C, int V, float eps, float scale, const void* E,
                                            const void* norm_w, const float* cosT, const float* sinT, const int* tok,
-                                           const int* pos, const void* pmask, int t, void* x, void* qkv, void* o, void* h,
-                                           void* act, float* part_o, float* part_ml, float* logits, void* stream) {
+                                           const int* pos, const void* pmask, int t, const int* t_dev, void* x, void* qkv, void* o,
+                                           void* h, void* act, float* part_o, float* part_ml, float* logits, void* stream) {
     const Layer* ls = (const Layer*)layers_host;
     const int B = R * copies;
     const int Nq = Hq * hd, Nkv = Hkv * hd, Nqkv = Nq + 2 * Nkv;
@@ -114,10 +116,10 @@ extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R
         CK(bra_dec_gemm(x, H, l.ln1, eps, l.Wqkv, H, nullptr, 0, qkv, Nqkv, B, Nqkv, H, 0, 0, stream));
         CK(bra_dec_attn_shared(qkv, Nqkv, l.qn, cosT, sinT, pos, l.kp, (long)Hkv * P * hd, (long)P * hd, (long)hd, l.vtp,
                                (long)Hkv * hd * vt_pitch, (long)hd * vt_pitch, vt_pitch, pmask, part_o, part_ml, R, copies, Hq,
-                               Hkv, hd, P, ntot, eps, scale, stream));
+                               Hkv, hd, P, ntot, eps, scale, t_dev, stream));
         CK(bra_dec_attn_partial(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, l.kc, l.vc, nullptr, part_o, part_ml, B, Hq, Hkv, hd,
-                                C, t, eps, scale, npc, ntot, stream));
-        CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, ntot, stream));
+                                C, t, eps, scale, npc, ntot, t_dev, stream));
+        CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, ntot, t_dev, npc, stream));
         CK(bra_dec_gemm(o, Nq, nullptr, 0.f, l.Wo, Nq, x, H, h, H, B, H, Nq, 0, 0, stream));
         CK(bra_dec_gemm(h, H, l.ln2, eps, l.Wgu, H, nullptr, 0, act, F, B, 2 * F, H, 1, 0, stream));
         CK(bra_dec_gemm(act, F, nullptr, 0.f, l.Wd, F, h, H, x, H, B, H, F, 0, 0, stream));

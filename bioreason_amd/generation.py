@@ -149,11 +149,14 @@ class FusedDecodeState:
         self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
         self.cosT, self.sinT = eng.rope(cache.Smax + 1)
 
-    def step(self, tok, pos, kmask, cur_len: int, logits: torch.Tensor):
+    def step(self, tok, pos, kmask, cur_len: int, logits: torch.Tensor, len_dev=None):
+        """`len_dev` (device int32 [1] holding cur_len): the kernels read the length from memory and `cur_len` only
+        sizes the grids, so the call can be captured once and replayed."""
         e = self.eng
         get_lib().call("bra_qwen_decode_step_fused", ctypes.addressof(self.arr), e.L, self.B, e.H, e.Hq, e.Hkv, e.hd, e.F,
                        self.cache.Smax, e.V, e.eps, e.scale, e.E, e.norm_w, self.cosT, self.sinT, tok, pos, kmask, cur_len,
-                       self.x, self.qkv, self.o, self.h, self.act, self.part_o, self.part_ml, logits, current_stream(self.x))
+                       len_dev, self.x, self.qkv, self.o, self.h, self.act, self.part_o, self.part_ml, logits,
+                       current_stream(self.x))
 
 
 class SharedDecodeState:
@@ -188,11 +191,11 @@ class SharedDecodeState:
         self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
         self.cosT, self.sinT = eng.rope(P + C + 1)
 
-    def step(self, tok, pos, pmask, t: int, logits: torch.Tensor):
+    def step(self, tok, pos, pmask, t: int, logits: torch.Tensor, t_dev=None):
         e = self.eng
         get_lib().call("bra_qwen_decode_step_shared", ctypes.addressof(self.arr), e.L, self.R, self.copies, e.H, e.Hq, e.Hkv,
                        e.hd, e.F, self.P, self.vt_pitch, self.C, e.V, e.eps, e.scale, e.E, e.norm_w, self.cosT, self.sinT, tok,
-                       pos, pmask, t, self.x, self.qkv, self.o, self.h, self.act, self.part_o, self.part_ml, logits,
+                       pos, pmask, t, t_dev, self.x, self.qkv, self.o, self.h, self.act, self.part_o, self.part_ml, logits,
                        current_stream(self.x))
 
 
@@ -239,9 +242,13 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
              eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None, seed: int = 0,
              check_every: int = 16, return_full_length: bool = False,
              force_tokens: Optional[torch.Tensor] = None, native_step: bool = True,
-             decode_impl: str = "fused", prompt_alias=None) -> torch.Tensor:
+             decode_impl: str = "fused", prompt_alias=None, use_graph: Optional[bool] = None,
+             shared_prefix_decode: bool = True) -> torch.Tensor:
     """`force_tokens` [B, max_new_tokens] (optional): teacher forcing — the model's own choice is still recorded
-    in the output, but the given token is fed back (used to compare decodes position by position)."""
+    in the output, but the given token is fed back (used to compare decodes position by position).
+    `use_graph` (default: on for the fused native step on a GPU): sample + decode step + counter updates are captured
+    once in a hipGraph and replayed per token — a step is ~200 dependent launches of a few microseconds each, so
+    issuing them from the host one by one makes the rollout CPU-launch bound."""
     eng = model.ensure_packed()
     B, P, H = inputs_embeds.shape
     dev = inputs_embeds.device
@@ -256,7 +263,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     kmask[:, :P] = am.to(torch.uint8)
     shared = None
     grp = _uniform_groups(prompt_alias) if prompt_alias is not None else None
-    use_shared = (grp is not None and native_step and decode_impl == "fused" and eng.hd >= 64
+    use_shared = (grp is not None and shared_prefix_decode and native_step and decode_impl == "fused" and eng.hd >= 64
                   and grp[1] * (eng.Hq // eng.Hkv) <= 16)
     if prompt_alias is None:
         cache = KVCache(eng, B, Smax, dev)
@@ -300,28 +307,59 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     if shared is None and native_step:
         state = FusedDecodeState(model, cache, B) if fused else DecodeState(model, cache, B)
     ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
-    for t in range(max_new_tokens):
+    len_t = torch.full((1,), P, dtype=torch.int32, device=dev)          # device-side cur_len of the fused step
+    if use_graph is None:
+        use_graph = dev.type == "cuda"
+    use_graph = bool(use_graph) and fused and force_tokens is None and max_new_tokens > 2
+
+    def sample_():
         ops.sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished if eos >= 0 else None, pad,
                    cur, None, eos_id=eos, tokens_out=tokens, ws=sample_ws)
-        if eos >= 0 and force_tokens is None and (t + 1) % check_every == 0 and bool(finished.all().item()):
-            n_done = t + 1
-            break
-        if t + 1 == max_new_tokens:
-            break
-        if force_tokens is not None:
-            cur = force_tokens[:, t].to(torch.int32).contiguous()
+
+    def advance_(t_grid: int):
+        """one fused decode step; the kernels take the step index from step_t / len_t, `t_grid` only sizes grids"""
         if shared is not None:
-            shared.step(cur, next_pos, pmask, t, logits)
-        elif fused:
-            state.step(cur, next_pos, kmask, P + t, logits)
+            shared.step(cur, next_pos, pmask, t_grid, logits, t_dev=step_t)
         else:
+            state.step(cur, next_pos, kmask, P + t_grid, logits, len_dev=len_t)
+        next_pos.add_(1)
+        step_t.add_(1)
+        len_t.add_(1)
+
+    if use_graph:
+        sample_()
+        advance_(0)                                     # eager first step: one-time kernel attribute set-up happens here
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            sample_()
+            advance_(max_new_tokens - 1)
+        for t in range(1, max_new_tokens - 1):
+            graph.replay()
+            if eos >= 0 and (t + 1) % check_every == 0 and bool(finished.all().item()):
+                n_done = t + 1
+                break
+        else:
+            sample_()
+    else:
+        for t in range(max_new_tokens):
+            sample_()
+            if eos >= 0 and force_tokens is None and (t + 1) % check_every == 0 and bool(finished.all().item()):
+                n_done = t + 1
+                break
+            if t + 1 == max_new_tokens:
+                break
+            if force_tokens is not None:
+                cur.copy_(force_tokens[:, t].to(torch.int32))
+            if fused:
+                advance_(t)
+                continue
             if state is not None:
                 hid = state.step(cur, next_pos, kmask, P + t, model._lora_enabled)
             else:
                 hid = decode_step(model, cur, cache, kmask, next_pos, P + t)
             ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
-        next_pos += 1
-        step_t += 1
+            next_pos += 1
+            step_t += 1
     out = tokens[:, :n_done]
     if eos >= 0 and not return_full_length and force_tokens is None:
         # HF stops right after the step in which the last row finished: trim the all-pad tail we may have produced

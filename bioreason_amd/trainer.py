@@ -42,6 +42,10 @@ class GRPOConfig:
     eos_token_id: Optional[int] = None
     pad_token_id: Optional[int] = None
     seed: int = 42
+    # execution knobs of the rollout (no effect on the arithmetic): hipGraph replay of the token loop, and decode
+    # attention over one shared copy of each prompt's K/V
+    rollout_graph: Optional[bool] = None
+    rollout_shared_prefix: bool = True
 
 
 def token_stat_rewards(completion_ids: torch.Tensor, completion_mask: torch.Tensor) -> torch.Tensor:
@@ -83,7 +87,8 @@ class GRPOStepRunner:
                                     max_new_tokens=c.max_completion_length, do_sample=True, temperature=c.temperature,
                                     top_k=c.top_k, top_p=c.top_p, eos_token_id=c.eos_token_id, pad_token_id=c.pad_token_id,
                                     seed=c.seed + 1000003 * self.step_idx + self.rank, return_full_length=True,
-                                    prompt_alias=batch.get("prompt_alias"))
+                                    prompt_alias=batch.get("prompt_alias"), use_graph=c.rollout_graph,
+                                    shared_prefix_decode=c.rollout_shared_prefix)
         mark("rollout")
         if c.eos_token_id is not None:
             cmask = grpo.completion_mask(completion_ids, c.eos_token_id)

@@ -140,20 +140,23 @@ int bra_dec_gemm(const void* x, long ldx, const void* norm_w, float eps, const v
 int bra_dec_attn_partial(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT,
                          const float* sinT, const int* pos, void* kc, void* vc, const void* kmask, float* part_o,
                          float* part_ml, int B, int Hq, int Hkv, int hd, int Smax, int cur_len, float eps, float scale,
-                         int chunk_off, int nchunk_tot, void* stream);
+                         int chunk_off, int nchunk_tot, const int* t_dev, void* stream);
+/* `t_dev` / `len_dev` (optional device int): when given, the attention kernels read the current length from it and
+ * the host-side `cur_len` / `t` only size the grids (pass the maximum); the launch arguments are then identical for
+ * every step, so one captured hipGraph replays the whole rollout (HF `_sample` loop, TF:generation/utils.py:2876-2925). */
 /* shared-prefix decode attention: the `copies` sequences of each of R prompts (GRPO's G rollouts, grpo_trainer.py:107-116)
  * attend to ONE copy of the prompt K / V^T; writes chunk partials 0 .. ceil(P/64)-1 of every (sequence, q-head) */
 int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, const float* cosT, const float* sinT, const int* pos,
                         const void* kp, long kp_sr, long kp_sh, long kp_ss, const void* vtp, long vt_sr, long vt_sh,
                         long vt_sd, const void* pmask, float* part_o, float* part_ml, int R, int copies, int Hq, int Hkv,
-                        int hd, int P, int nchunk_tot, float eps, float scale, void* stream);
+                        int hd, int P, int nchunk_tot, float eps, float scale, const int* t_dev, void* stream);
 int bra_attn_decode_merge(const float* part_o, const float* part_ml, void* o, int B, int Hq, int hd, int nchunk,
-                          void* stream);
+                          const int* t_dev, int npc, void* stream);
 int bra_qwen_decode_step_fused(const void* layers_host, int L, int B, int H, int Hq, int Hkv, int hd, int F, int Smax,
                                int V, float eps, float scale, const void* E, const void* norm_w, const float* cosT,
                                const float* sinT, const int* tok, const int* pos, const void* kmask, int cur_len,
-                               void* x, void* qkv, void* o, void* h, void* act, float* part_o, float* part_ml,
-                               float* logits, void* stream);
+                               const int* len_dev, void* x, void* qkv, void* o, void* h, void* act, float* part_o,
+                               float* part_ml, float* logits, void* stream);
 
 /* shared-prefix step: B = R * copies sequences grouped by prompt; layer records additionally carry kp (prompt K
  * [R,Hkv,P,hd]) and vtp (prompt V^T [R,Hkv,hd,vt_pitch]); kc / vc are the per-sequence COMPLETION caches [B,Hkv,C,hd]
@@ -161,8 +164,8 @@ int bra_qwen_decode_step_fused(const void* layers_host, int L, int B, int H, int
 int bra_qwen_decode_step_shared(const void* layers_host, int L, int R, int copies, int H, int Hq, int Hkv, int hd, int F,
                                 int P, long vt_pitch, int C, int V, float eps, float scale, const void* E,
                                 const void* norm_w, const float* cosT, const float* sinT, const int* tok, const int* pos,
-                                const void* pmask, int t, void* x, void* qkv, void* o, void* h, void* act, float* part_o,
-                                float* part_ml, float* logits, void* stream);
+                                const void* pmask, int t, const int* t_dev, void* x, void* qkv, void* o, void* h, void* act,
+                                float* part_o, float* part_ml, float* logits, void* stream);
 
 /* ---- data movement around the kernels (k_misc.hip) ---------------------------- */
 int bra_head_transpose(const void* x, long sb, long ss, long sh, void* xt, long t_sb, long t_sh, long pitch, int B,

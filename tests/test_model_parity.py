@@ -254,3 +254,27 @@ def test_shared_prefix_decode_kernel_matches_per_copy_decode(backend):
     s_u = m.generate(input_ids=ids, attention_mask=mask, **mm, **kw2)
     s_s = m.generate(input_ids=ids, attention_mask=mask, **mm, prompt_alias=[0, 0, 2, 2], **kw2)
     assert (s_u[:, 0] == s_s[:, 0]).all()        # first token comes from the prefill in both
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alias", [None, [0, 0, 2, 2]])
+def test_graph_replayed_rollout_equals_eager_rollout(backend, alias):
+    """the hipGraph-replayed token loop (device-side step counter) produces the same tokens as the eager loop, with and
+    without EOS early stopping; same kernels, same arguments, so the comparison is exact"""
+    if backend.type == "cpu":
+        pytest.skip("graph capture needs a GPU stream")
+    fix = torch.load(os.path.join(GOLD, "tiny_b.pt"), weights_only=False)
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    rows = [0, 0, 1, 1]
+    ids, mask = b["input_ids"][rows], b["attention_mask"][rows]
+    dna = {k: v[rows] for k, v in b["dna_tokenized"].items()}
+    mm = {"dna_tokenized": dna, "batch_idx_map": [0, 1, 2, 3]}
+    extra = {} if alias is None else {"prompt_alias": alias}
+    for kw in (dict(max_new_tokens=70, do_sample=False, eos_token_id=None),
+               dict(max_new_tokens=70, do_sample=True, temperature=0.8, top_k=20, top_p=0.95, eos_token_id=None, seed=5),
+               dict(max_new_tokens=70, do_sample=True, temperature=1.0, top_k=8, eos_token_id=3, pad_token_id=0, seed=9,
+                    check_every=4)):
+        g_e = m.generate(input_ids=ids, attention_mask=mask, **mm, **extra, use_graph=False, **kw)
+        g_g = m.generate(input_ids=ids, attention_mask=mask, **mm, **extra, use_graph=True, **kw)
+        assert g_e.shape == g_g.shape and (g_e == g_g).all()

@@ -15,8 +15,11 @@ if os.environ.get("PROBE_LORA", "1") == "1":
 b = synth_prompt_batch(B=8, n_unique=1, dna_token_id=m.dna_token_id, device=dev)
 kw = dict(input_ids=b["input_ids"], attention_mask=b["attention_mask"], dna_tokenized=b["dna_tokenized"], batch_idx_map=b["batch_idx_map"],
           dna_alias=b["dna_alias"], prompt_alias=b["prompt_alias"], do_sample=True, temperature=0.6, top_k=20, top_p=0.95, eos_token_id=None)
-for it in range(2):
-    torch.cuda.synchronize(); t0 = time.time()
-    m.generate(max_new_tokens=1, **kw); torch.cuda.synchronize(); t1 = time.time()
-    m.generate(max_new_tokens=C, **kw); torch.cuda.synchronize(); t2 = time.time()
-    print("prefill+1 ms", (t1 - t0) * 1e3, "gen", C, "ms", (t2 - t1) * 1e3, "per decode step ms", ((t2 - t1) - (t1 - t0)) * 1e3 / (C - 1), flush=True)
+for shared_dec, graph in ((True, True), (True, False), (False, True), (False, False)):
+    kw["shared_prefix_decode"], kw["use_graph"] = shared_dec, graph
+    for it in range(2):
+        torch.cuda.synchronize(); t0 = time.time()
+        m.generate(max_new_tokens=1, **kw); torch.cuda.synchronize(); t1 = time.time()
+        m.generate(max_new_tokens=C, **kw); torch.cuda.synchronize(); t2 = time.time()
+        print("shared", shared_dec, "graph", graph, "prefill+1 ms %.1f" % ((t1 - t0) * 1e3), "gen", C, "ms %.1f" % ((t2 - t1) * 1e3),
+              "per decode step ms %.3f" % (((t2 - t1) - (t1 - t0)) * 1e3 / (C - 1)), flush=True)
