@@ -225,6 +225,18 @@ __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfi
 #endif
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+// makes `v` opaque to the compiler at this point: nothing computed from it can be scheduled (or hoisted) above
+#ifdef BRA_EMU
+__device__ __forceinline__ void reg_fence(f32x4&) {}
+#else
+__device__ __forceinline__ void reg_fence(f32x4& v) { asm volatile("" : "+v"(v)); }
+#endif
+// streaming (read-once) 16-byte load: weights of the decode projections must not displace the activations in L2
+#ifdef BRA_EMU
+__device__ __forceinline__ u32x4 ld16_nt(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+#else
+__device__ __forceinline__ u32x4 ld16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+#endif
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 __device__ __forceinline__ u32x2 ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
 __device__ __forceinline__ void st8(void* p, const u32x2& v) { *reinterpret_cast<u32x2*>(p) = v; }

@@ -1,0 +1,235 @@
+// k_decgemm.hip — weight-streaming projections of the single-token decode step, second generation.
+// Arithmetic: y[M<=8, N] = rmsnorm(x; w, eps) W^T (+ res) | SwiGLU | fp32 logits — Qwen3DecoderLayer.forward with a
+// KV cache (TF:qwen3:294-323), Qwen3RMSNorm (TF:qwen3:59-64), Qwen3MLP (TF:qwen3:81-83), tied lm_head (TF:qwen3:495).
+//
+// At M = 8 rows a projection is pure HBM streaming of its weight matrix (8.4 - 50 MB per launch), and a launch lasts
+// only a few microseconds, so what decides its speed is how many bytes are in flight how soon after the launch:
+//   * every lane requests ALL the 16-byte weight chunks it will consume (NL per lane, non-temporal) in its first
+//     instructions, together with the activations, the residual and the norm statistics; nothing waits on anything
+//     before the first MFMA;
+//   * no RMSNorm prologue pass: the PRODUCER of x (o_proj / down_proj epilogue here, bra_row_sumsq after the embedding
+//     gather) leaves per-workgroup partial sums of squares [8][nss]; every wave folds them in a fixed order
+//     (deterministic) and normalises just the fragments it multiplies;
+//   * N = hidden projections (o_proj, down_proj) use 8-column workgroups so that 256 workgroups exist, and fill the
+//     16x16x32 MFMA by putting two K-halves on the two row halves of A and B ("diagonal" mode): the products
+//     C[j][b] and C[j+8][b+8] are the two K-halves of output (b, j); all 64 lanes stream weights.
+#include "bra_device.h"
+#include "bra_api_internal.h"
+
+namespace bra {
+
+struct DecGemm2Args {
+    const bf16_t* x; long ldx;          // [M, K]
+    const float* ss_in; int nss_in;     // NORM: partial sums of squares of the rows of x, [8][nss_in]
+    const bf16_t* nw; float eps;        // NORM: RMSNorm weight [K]
+    const bf16_t* W; long ldw;          // [N, K]
+    const bf16_t* res; long ldres;      // [M, N] or null
+    void* out; long ldo;                // bf16 [M, N] | bf16 [M, N/2] (ACT) | f32 [M, N]
+    float* ss_out; int nss_out;         // partial sums of squares of the bf16 outputs, [8][nss_out], column = workgroup
+    int M, N, K;
+};
+
+__device__ __forceinline__ float silu_g(float x) { return x / (1.f + __expf(-x)); }
+
+// MODE 0: 16 output columns per workgroup, 32 k per step.  MODE 1: 8 columns, 64 k per step (diagonal).
+template <int MODE, int NORM, int ACT, int OUTF32, int NW, int NL>
+__global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
+    __shared__ float red[NW][64][4];
+    constexpr int KS = MODE ? 64 : 32;
+    constexpr int NCOL = MODE ? 8 : 16;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = (int)blockIdx.x * NCOL;
+    const int nsteps = g.K / KS;
+    const int lrow = MODE ? (fr & 7) : fr;                            // A row = weight row, B row = batch row
+    const int koff = MODE ? ((fr >> 3) * 32 + fq * 8) : fq * 8;
+    int rn = n0 + lrow; rn = rn < g.N ? rn : g.N - 1;
+    const int xr = lrow < g.M ? lrow : g.M - 1;
+    const bf16_t* wp = g.W + (long)rn * g.ldw + koff;
+    const bf16_t* xp = g.x + (long)xr * g.ldx + koff;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const int rounds = (nsteps + NW * NL - 1) / (NW * NL);
+
+    // epilogue operands requested now (all waves, clamped addresses: no branch around a load)
+    const int em = fr < g.M ? fr : g.M - 1;
+    int en = n0 + 4 * fq; en = en + 3 < g.N ? en : (g.N >= 4 ? g.N - 4 : 0);
+    u32x2 resv = {0u, 0u};
+    if (!ACT && !OUTF32 && g.res) resv = ld8(g.res + (long)em * g.ldres + en);
+
+    // NORM: lane l folds partials [per * (l & 7), per * (l & 7) + per) of row l >> 3 (per <= 32, fixed order =>
+    // run-to-run identical); requested first, they are the smallest and the first thing the MFMAs need
+    const int per = NORM ? g.nss_in >> 3 : 0;
+    f32x4 pv[8];
+    if (NORM) {
+        const float* pp = g.ss_in + (long)(lane >> 3) * g.nss_in + (lane & 7) * per;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pv[i] = *reinterpret_cast<const f32x4*>(pp + (4 * i < per ? 4 * i : 0));
+    }
+    float rstd = 1.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int base = rd * NW * NL;
+        int st[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u)      // MODE 0: a wave takes both 64-byte halves of a 128-byte line back to back
+            st[u] = base + (MODE ? wave + NW * u : 2 * (wave + NW * (u >> 1)) + (u & 1));
+        u32x4 w[NL], x[NL], nv[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; w[u] = ld16_nt(wp + (long)sc * KS); }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; x[u] = ld16(xp + (long)sc * KS); }
+        if (NORM) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; nv[u] = ld16(g.nw + koff + (long)sc * KS); }
+            sched_fence();                // every request above is in flight before the first dependent instruction
+            if (rd == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) reg_fence(pv[i]);
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += 4 * i < per ? (pv[i][0] + pv[i][1]) + (pv[i][2] + pv[i][3]) : 0.f;
+                s += wave_shfl_xor(s, 1); s += wave_shfl_xor(s, 2); s += wave_shfl_xor(s, 4);
+                const float tot = wave_shfl(s, xr * 8);
+                rstd = rsqrtf(tot / (float)g.K + g.eps);
+            }
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                float xf[8], nf[8];
+                unpack8(x[u], xf); unpack8(nv[u], nf);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xf[i] = nf[i] * round_bf(xf[i] * rstd);
+                x[u] = pack8(xf);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) acc = mfma_16x16x32(st[u] < nsteps ? w[u] : zero4, x[u], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
+    __syncthreads();
+    if (wave != 0) return;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) s += red[wv][lane][r];
+        v[r] = s;
+    }
+    if (MODE) {                                   // second K-half of (n, m) sits at (n + 8, m + 8) = lane + 40
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += wave_shfl(v[r], lane + 40);
+    }
+    const int m = fr;
+    if (ACT) {
+        // workgroup rows = [8 gate | 8 up] of features 8*blk .. 8*blk+7: lanes fq < 2 own gate, partners (lane ^ 32) up
+        float up[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) up[r] = wave_shfl_xor(v[r], 32);
+        if (fq < 2 && m < g.M) {
+            const int f0 = (int)blockIdx.x * 8 + 4 * fq;
+            float a[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = round_bf(silu_g(round_bf(v[r]))) * round_bf(up[r]);
+            u32x2 o; o.x = pack_bf2(a[0], a[1]); o.y = pack_bf2(a[2], a[3]);
+            st8((bf16_t*)g.out + (long)m * g.ldo + f0, o);
+        }
+        return;
+    }
+    const int n = n0 + 4 * fq;
+    const bool live = m < g.M && n < g.N && 4 * fq < NCOL && (!MODE || fr < 8);
+    if (OUTF32) {
+        if (live) {
+            float* cp = (float*)g.out + (long)m * g.ldo + n;
+            for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = v[r];
+        }
+        return;
+    }
+    float ss = 0.f;
+    if (g.res) {
+        const float r0 = bf2f((bf16_t)(resv.x & 0xffffu)), r1 = bf2f((bf16_t)(resv.x >> 16));
+        const float r2 = bf2f((bf16_t)(resv.y & 0xffffu)), r3 = bf2f((bf16_t)(resv.y >> 16));
+        if (n == en) { v[0] = round_bf(v[0]) + r0; v[1] = round_bf(v[1]) + r1; v[2] = round_bf(v[2]) + r2; v[3] = round_bf(v[3]) + r3; }
+        else if (live) {
+            for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] = round_bf(v[r]) + bf2f(g.res[(long)m * g.ldres + n + r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] = round_bf(v[r]); if (live && n + r < g.N) ss += v[r] * v[r]; }
+    if (live) {
+        bf16_t* cp = (bf16_t*)g.out + (long)m * g.ldo + n;
+        if (n + 3 < g.N) { u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); st8(cp, o); }
+        else for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = f2bf(v[r]);
+    }
+    if (g.ss_out) {
+        if (!live) ss = 0.f;
+        ss += wave_shfl_xor(ss, 16);
+        ss += wave_shfl_xor(ss, 32);
+        if (fq == 0 && fr < 8 && m < g.M) g.ss_out[(long)m * g.nss_out + blockIdx.x] = ss;
+    }
+}
+
+// sums of squares of the rows of x [M <= 8, K] (after the embedding gather): ss[r][0] = sum, ss[r][1 .. nss) = 0
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const bf16_t* x, long ldx, int K, float* ss, int nss) {
+    __shared__ float part[4];
+    const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
+    float s = 0.f;
+    for (int j = tid; j < K / 8; j += 256) {
+        float f[8];
+        unpack8(ld16(x + (long)r * ldx + j * 8), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += f[i] * f[i];
+    }
+    s = wave_sum<64>(s);
+    if ((tid & 63) == 0) part[tid >> 6] = s;
+    __syncthreads();
+    for (int j = tid; j < nss; j += 256) ss[(long)r * nss + j] = j == 0 ? (part[0] + part[1]) + (part[2] + part[3]) : 0.f;
+}
+
+template <int MODE, int NORM, int ACT, int OUTF32>
+static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
+    constexpr int KS = MODE ? 64 : 32;
+    const int nsteps = g.K / KS;
+    const int nw = nsteps >= 64 ? 8 : 4;
+    const int spw = (nsteps + nw - 1) / nw;
+    const int nl = (spw >= 12 && spw % 12 == 0) ? 12 : (spw > 4 ? 8 : 4);
+    const dim3 grid(MODE ? g.N / 8 : (g.N + 15) / 16);
+#define BRA_DG2(NW_, NL_) BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_>), grid, dim3(NW_ * 64), 0, st, g)
+    if (nw == 8) { if (nl == 12) BRA_DG2(8, 12); else if (nl == 8) BRA_DG2(8, 8); else BRA_DG2(8, 4); }
+    else { if (nl == 12) BRA_DG2(4, 12); else if (nl == 8) BRA_DG2(4, 8); else BRA_DG2(4, 4); }
+#undef BRA_DG2
+    return BRA_LAUNCH_STATUS();
+}
+
+}  // namespace bra
+
+using namespace bra;
+
+extern "C" int bra_dec_gemm2(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
+                             const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
+                             int nss_out, int M, int N, int K, int act, int out_f32, void* stream) {
+    if (M <= 0 || M > 8 || N <= 0 || K <= 0 || K % 32 || ldx % 8 || ldw % 8 || !x || !W || !out) return BRA_ERR_ARG;
+    if (act && (N % 16 || out_f32 || res || ss_out)) return BRA_ERR_ARG;
+    if (out_f32 && (res || ss_out)) return BRA_ERR_ARG;
+    if (norm_w && (!ss_in || nss_in < 32 || nss_in % 32 || nss_in > 256)) return BRA_ERR_ARG;
+    if (res && ldres % 4) return BRA_ERR_ARG;
+    const bool diag = !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256;
+    if (ss_out && nss_out < (diag ? N / 8 : (N + 15) / 16)) return BRA_ERR_ARG;
+    DecGemm2Args g = {(const bf16_t*)x, ldx, ss_in, nss_in, (const bf16_t*)norm_w, eps, (const bf16_t*)W, ldw,
+                      (const bf16_t*)res, ldres, out, ldo, ss_out, nss_out, M, N, K};
+    bra_stream_t st = (bra_stream_t)stream;
+    if (norm_w) {
+        if (act) return launch_dg2<0, 1, 1, 0>(g, st);
+        if (out_f32) return launch_dg2<0, 1, 0, 1>(g, st);
+        return diag ? launch_dg2<1, 1, 0, 0>(g, st) : launch_dg2<0, 1, 0, 0>(g, st);
+    }
+    if (act) return launch_dg2<0, 0, 1, 0>(g, st);
+    if (out_f32) return launch_dg2<0, 0, 0, 1>(g, st);
+    return diag ? launch_dg2<1, 0, 0, 0>(g, st) : launch_dg2<0, 0, 0, 0>(g, st);
+}
+
+extern "C" int bra_row_sumsq(const void* x, long ldx, int M, int K, float* ss, int nss, void* stream) {
+    if (M <= 0 || M > 8 || K <= 0 || K % 8 || ldx % 8 || !x || !ss || nss < 1) return BRA_ERR_ARG;
+    BRA_LAUNCH(row_sumsq_kernel, dim3(M), dim3(256), 0, (bra_stream_t)stream, (const bf16_t*)x, ldx, K, ss, nss);
+    return BRA_LAUNCH_STATUS();
+}

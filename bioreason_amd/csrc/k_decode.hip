@@ -63,6 +63,44 @@ extern "C" int bra_qwen_decode_step(const void* layers_host, int L, int B, int H
     return 0;
 }
 
+// The four projections of a decoder layer at decode time, in either generation of the streaming GEMM: `ss` != null selects
+// bra_dec_gemm2 (k_decgemm.hip), whose RMSNorm statistics travel as partial sums of squares from epilogue to consumer.
+struct StepGemms {
+    bool v2; float* ssx; float* ssh; int nss;
+    int B, H, Nq, Nqkv, F, V; float eps; void* stream;
+};
+static StepGemms step_gemms(float* ss_ws, int nss, int B, int H, int Nq, int Nqkv, int F, int V, float eps, void* stream) {
+    StepGemms s;
+    const int nblk = (H % 8 == 0 && (H + 15) / 16 < 256) ? H / 8 : (H + 15) / 16;      // workgroups of an N = H projection
+    s.v2 = ss_ws && B <= 8 && nss >= 32 && nss % 32 == 0 && nss <= 256 && nss >= nblk;
+    s.ssx = ss_ws; s.ssh = ss_ws ? ss_ws + 8 * (long)nss : nullptr; s.nss = nss;
+    s.B = B; s.H = H; s.Nq = Nq; s.Nqkv = Nqkv; s.F = F; s.V = V; s.eps = eps; s.stream = stream;
+    return s;
+}
+static int sg_begin(const StepGemms& s, const void* x) {
+    return s.v2 ? bra_row_sumsq(x, s.H, s.B, s.H, s.ssx, s.nss, s.stream) : 0;
+}
+static int sg_qkv(const StepGemms& s, const Layer& l, const void* x, void* qkv) {
+    if (s.v2) return bra_dec_gemm2(x, s.H, s.ssx, s.nss, l.ln1, s.eps, l.Wqkv, s.H, nullptr, 0, qkv, s.Nqkv, nullptr, 0, s.B, s.Nqkv, s.H, 0, 0, s.stream);
+    return bra_dec_gemm(x, s.H, l.ln1, s.eps, l.Wqkv, s.H, nullptr, 0, qkv, s.Nqkv, s.B, s.Nqkv, s.H, 0, 0, s.stream);
+}
+// h = x + o Wo^T;  act = swiglu(rmsnorm(h) Wgu^T);  x = h + act Wd^T
+static int sg_tail(const StepGemms& s, const Layer& l, const void* o, void* x, void* h, void* act) {
+    int rc;
+    if (s.v2) {
+        if ((rc = bra_dec_gemm2(o, s.Nq, nullptr, 0, nullptr, 0.f, l.Wo, s.Nq, x, s.H, h, s.H, s.ssh, s.nss, s.B, s.H, s.Nq, 0, 0, s.stream))) return rc;
+        if ((rc = bra_dec_gemm2(h, s.H, s.ssh, s.nss, l.ln2, s.eps, l.Wgu, s.H, nullptr, 0, act, s.F, nullptr, 0, s.B, 2 * s.F, s.H, 1, 0, s.stream))) return rc;
+        return bra_dec_gemm2(act, s.F, nullptr, 0, nullptr, 0.f, l.Wd, s.F, h, s.H, x, s.H, s.ssx, s.nss, s.B, s.H, s.F, 0, 0, s.stream);
+    }
+    if ((rc = bra_dec_gemm(o, s.Nq, nullptr, 0.f, l.Wo, s.Nq, x, s.H, h, s.H, s.B, s.H, s.Nq, 0, 0, s.stream))) return rc;
+    if ((rc = bra_dec_gemm(h, s.H, l.ln2, s.eps, l.Wgu, s.H, nullptr, 0, act, s.F, s.B, 2 * s.F, s.H, 1, 0, s.stream))) return rc;
+    return bra_dec_gemm(act, s.F, nullptr, 0.f, l.Wd, s.F, h, s.H, x, s.H, s.B, s.H, s.F, 0, 0, s.stream);
+}
+static int sg_head(const StepGemms& s, const void* x, const void* norm_w, const void* E, float* logits) {
+    if (s.v2) return bra_dec_gemm2(x, s.H, s.ssx, s.nss, norm_w, s.eps, E, s.H, nullptr, 0, logits, s.V, nullptr, 0, s.B, s.V, s.H, 0, 1, s.stream);
+    return bra_dec_gemm(x, s.H, norm_w, s.eps, E, s.H, nullptr, 0, logits, s.V, s.B, s.V, s.H, 0, 1, s.stream);
+}
+
 // Fused variant (k_decfused.hip): 6 launches per layer.  The layer records carry ROLLOUT weights in
 // Wqkv / Wo / Wgu / Wd: LoRA already merged (W + s B A, the same merge PEFT's merge_and_unload performs,
 // reason.py:428-446) and gate/up rows interleaved in blocks of 8 for the SwiGLU epilogue; the LoRA fields are unused.
@@ -71,24 +109,24 @@ extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B,
                                           int Smax, int V, float eps, float scale, const void* E, const void* norm_w,
                                           const float* cosT, const float* sinT, const int* tok, const int* pos,
                                           const void* kmask, int cur_len, const int* len_dev, void* x, void* qkv, void* o, void* h, void* act,
-                                          float* part_o, float* part_ml, float* logits, void* stream) {
+                                          float* ss_ws, int nss, float* part_o, float* part_ml, float* logits, void* stream) {
     const Layer* ls = (const Layer*)layers_host;
     const int Nq = Hq * hd, Nkv = Hkv * hd, Nqkv = Nq + 2 * Nkv;
     const int nchunk = (cur_len + 1 + 63) / 64;
     int rc;
 #define CK(call) do { rc = (call); if (rc) return rc; } while (0)
+    const StepGemms sg = step_gemms(ss_ws, nss, B, H, Nq, Nqkv, F, V, eps, stream);
     CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));
+    CK(sg_begin(sg, x));
     for (int li = 0; li < L; ++li) {
         const Layer& l = ls[li];
-        CK(bra_dec_gemm(x, H, l.ln1, eps, l.Wqkv, H, nullptr, 0, qkv, Nqkv, B, Nqkv, H, 0, 0, stream));
+        CK(sg_qkv(sg, l, x, qkv));
         CK(bra_dec_attn_partial(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, l.kc, l.vc, kmask, part_o, part_ml, B, Hq, Hkv, hd,
                                 Smax, cur_len, eps, scale, 0, 0, len_dev, stream));
         CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, nchunk, len_dev, 0, stream));
-        CK(bra_dec_gemm(o, Nq, nullptr, 0.f, l.Wo, Nq, x, H, h, H, B, H, Nq, 0, 0, stream));
-        CK(bra_dec_gemm(h, H, l.ln2, eps, l.Wgu, H, nullptr, 0, act, F, B, 2 * F, H, 1, 0, stream));
-        CK(bra_dec_gemm(act, F, nullptr, 0.f, l.Wd, F, h, H, x, H, B, H, F, 0, 0, stream));
+        CK(sg_tail(sg, l, o, x, h, act));
     }
-    if (logits) CK(bra_dec_gemm(x, H, norm_w, eps, E, H, nullptr, 0, logits, V, B, V, H, 0, 1, stream));
+    if (logits) CK(sg_head(sg, x, norm_w, E, logits));
 #undef CK
     return 0;
 }
@@ -103,28 +141,28 @@ extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R
                                            int F, int P, long vt_pitch, int C, int V, float eps, float scale, const void* E,
                                            const void* norm_w, const float* cosT, const float* sinT, const int* tok,
                                            const int* pos, const void* pmask, int t, const int* t_dev, void* x, void* qkv, void* o,
-                                           void* h, void* act, float* part_o, float* part_ml, float* logits, void* stream) {
+                                           void* h, void* act, float* ss_ws, int nss, float* part_o, float* part_ml, float* logits, void* stream) {
     const Layer* ls = (const Layer*)layers_host;
     const int B = R * copies;
     const int Nq = Hq * hd, Nkv = Hkv * hd, Nqkv = Nq + 2 * Nkv;
     const int npc = (P + 63) / 64, ncc = (t + 1 + 63) / 64, ntot = npc + ncc;
     int rc;
 #define CK(call) do { rc = (call); if (rc) return rc; } while (0)
+    const StepGemms sg = step_gemms(ss_ws, nss, B, H, Nq, Nqkv, F, V, eps, stream);
     CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));
+    CK(sg_begin(sg, x));
     for (int li = 0; li < L; ++li) {
         const Layer& l = ls[li];
-        CK(bra_dec_gemm(x, H, l.ln1, eps, l.Wqkv, H, nullptr, 0, qkv, Nqkv, B, Nqkv, H, 0, 0, stream));
+        CK(sg_qkv(sg, l, x, qkv));
         CK(bra_dec_attn_shared(qkv, Nqkv, l.qn, cosT, sinT, pos, l.kp, (long)Hkv * P * hd, (long)P * hd, (long)hd, l.vtp,
                                (long)Hkv * hd * vt_pitch, (long)hd * vt_pitch, vt_pitch, pmask, part_o, part_ml, R, copies, Hq,
                                Hkv, hd, P, ntot, eps, scale, t_dev, stream));
         CK(bra_dec_attn_partial(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, l.kc, l.vc, nullptr, part_o, part_ml, B, Hq, Hkv, hd,
                                 C, t, eps, scale, npc, ntot, t_dev, stream));
         CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, ntot, t_dev, npc, stream));
-        CK(bra_dec_gemm(o, Nq, nullptr, 0.f, l.Wo, Nq, x, H, h, H, B, H, Nq, 0, 0, stream));
-        CK(bra_dec_gemm(h, H, l.ln2, eps, l.Wgu, H, nullptr, 0, act, F, B, 2 * F, H, 1, 0, stream));
-        CK(bra_dec_gemm(act, F, nullptr, 0.f, l.Wd, F, h, H, x, H, B, H, F, 0, 0, stream));
+        CK(sg_tail(sg, l, o, x, h, act));
     }
-    if (logits) CK(bra_dec_gemm(x, H, norm_w, eps, E, H, nullptr, 0, logits, V, B, V, H, 0, 1, stream));
+    if (logits) CK(sg_head(sg, x, norm_w, E, logits));
 #undef CK
     return 0;
 }

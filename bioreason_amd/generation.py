@@ -14,6 +14,7 @@ counter on the device.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -148,6 +149,7 @@ class FusedDecodeState:
         self.part_o = torch.empty((B, eng.Hq, nch, eng.hd), dtype=torch.float32, device=dev)
         self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
         self.cosT, self.sinT = eng.rope(cache.Smax + 1)
+        self.ss_ws, self.nss = _norm_stat_ws(eng, eng.device)
 
     def step(self, tok, pos, kmask, cur_len: int, logits: torch.Tensor, len_dev=None):
         """`len_dev` (device int32 [1] holding cur_len): the kernels read the length from memory and `cur_len` only
@@ -155,8 +157,8 @@ class FusedDecodeState:
         e = self.eng
         get_lib().call("bra_qwen_decode_step_fused", ctypes.addressof(self.arr), e.L, self.B, e.H, e.Hq, e.Hkv, e.hd, e.F,
                        self.cache.Smax, e.V, e.eps, e.scale, e.E, e.norm_w, self.cosT, self.sinT, tok, pos, kmask, cur_len,
-                       len_dev, self.x, self.qkv, self.o, self.h, self.act, self.part_o, self.part_ml, logits,
-                       current_stream(self.x))
+                       len_dev, self.x, self.qkv, self.o, self.h, self.act, self.ss_ws, self.nss, self.part_o, self.part_ml,
+                       logits, current_stream(self.x))
 
 
 class SharedDecodeState:
@@ -190,13 +192,24 @@ class SharedDecodeState:
         self.part_o = torch.empty((B, eng.Hq, nch, eng.hd), dtype=torch.float32, device=dev)
         self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
         self.cosT, self.sinT = eng.rope(P + C + 1)
+        self.ss_ws, self.nss = _norm_stat_ws(eng, dev)
 
     def step(self, tok, pos, pmask, t: int, logits: torch.Tensor, t_dev=None):
         e = self.eng
         get_lib().call("bra_qwen_decode_step_shared", ctypes.addressof(self.arr), e.L, self.R, self.copies, e.H, e.Hq, e.Hkv,
                        e.hd, e.F, self.P, self.vt_pitch, self.C, e.V, e.eps, e.scale, e.E, e.norm_w, self.cosT, self.sinT, tok,
-                       pos, pmask, t, t_dev, self.x, self.qkv, self.o, self.h, self.act, self.part_o, self.part_ml, logits,
-                       current_stream(self.x))
+                       pos, pmask, t, t_dev, self.x, self.qkv, self.o, self.h, self.act, self.ss_ws, self.nss, self.part_o,
+                       self.part_ml, logits, current_stream(self.x))
+
+
+def _norm_stat_ws(eng, dev):
+    """zeroed workspace [2][8][nss] of RMSNorm partial sums of squares for the bra_dec_gemm2 projections (None, 0: the
+    hidden size has more column workgroups than the 256 partials a consumer folds -> first-generation kernels)"""
+    nblk = eng.H // 8 if (eng.H % 8 == 0 and (eng.H + 15) // 16 < 256) else (eng.H + 15) // 16
+    nss = (nblk + 31) // 32 * 32
+    if nss > 256 or os.environ.get("BRA_DEC_GEMM_V1") == "1":
+        return None, 0
+    return torch.zeros((2, 8, nss), dtype=torch.float32, device=dev), nss
 
 
 def _uniform_groups(prompt_alias):

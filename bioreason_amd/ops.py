@@ -321,6 +321,26 @@ def sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished,
     return out_ids
 
 
+def row_sumsq(x: torch.Tensor, nss: int = 32) -> torch.Tensor:
+    """partial sums of squares of the rows of x [M<=8, K] in the layout bra_dec_gemm2 consumes: fp32 [8, nss]"""
+    ss = torch.zeros((8, nss), dtype=torch.float32, device=x.device)
+    get_lib().call("bra_row_sumsq", x, _ld(x), x.shape[0], x.shape[1], ss, nss, current_stream(x))
+    return ss
+
+
+def dec_gemm2(x, W, ss_in=None, norm_w=None, eps=1e-6, res=None, act=False, out_f32=False, want_ss=False):
+    """decode-time projection (bra_dec_gemm2): y = rmsnorm(x) W^T (+res | SwiGLU | fp32); returns (y, ss_out or None)"""
+    M, K = x.shape
+    N = W.shape[0]
+    out = torch.empty((M, N // 2 if act else N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    nss_out = (N // 8 + 32) // 32 * 32
+    ss_out = torch.zeros((8, nss_out), dtype=torch.float32, device=x.device) if want_ss else None
+    get_lib().call("bra_dec_gemm2", x, _ld(x), ss_in, ss_in.shape[1] if ss_in is not None else 0, norm_w, eps, W, _ld(W),
+                   res, _ld(res) if res is not None else 0, out, _ld(out), ss_out, nss_out if want_ss else 0, M, N, K,
+                   int(act), int(out_f32), current_stream(x))
+    return out, ss_out
+
+
 def eos_mask(ids32: torch.Tensor, eos_id: int):
     B, C = ids32.shape
     mask = torch.empty((B, C), dtype=torch.int32, device=ids32.device)

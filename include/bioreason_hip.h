@@ -141,6 +141,15 @@ int bra_dec_attn_partial(const void* qkv, long ldqkv, const void* qw, const void
                          const float* sinT, const int* pos, void* kc, void* vc, const void* kmask, float* part_o,
                          float* part_ml, int B, int Hq, int Hkv, int hd, int Smax, int cur_len, float eps, float scale,
                          int chunk_off, int nchunk_tot, const int* t_dev, void* stream);
+/* Second-generation streaming projection (k_decgemm.hip): same arithmetic as bra_dec_gemm for M <= 8 rows, but the
+ * RMSNorm statistics arrive as partial sums of squares ss_in[8][nss_in] (left by the producer's epilogue through
+ * ss_out[8][nss_out], column = workgroup, or by bra_row_sumsq) instead of a per-workgroup prologue pass over x;
+ * nss multiples of 32, unused columns zero.  `ss_ws` of the step functions = float [2][8][nss] zero-initialised,
+ * nss >= H/8 (null: first-generation kernels). */
+int bra_dec_gemm2(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps, const void* W,
+                  long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out, int nss_out, int M, int N,
+                  int K, int act, int out_f32, void* stream);
+int bra_row_sumsq(const void* x, long ldx, int M, int K, float* ss, int nss, void* stream);
 /* `t_dev` / `len_dev` (optional device int): when given, the attention kernels read the current length from it and
  * the host-side `cur_len` / `t` only size the grids (pass the maximum); the launch arguments are then identical for
  * every step, so one captured hipGraph replays the whole rollout (HF `_sample` loop, TF:generation/utils.py:2876-2925). */
@@ -155,8 +164,8 @@ int bra_attn_decode_merge(const float* part_o, const float* part_ml, void* o, in
 int bra_qwen_decode_step_fused(const void* layers_host, int L, int B, int H, int Hq, int Hkv, int hd, int F, int Smax,
                                int V, float eps, float scale, const void* E, const void* norm_w, const float* cosT,
                                const float* sinT, const int* tok, const int* pos, const void* kmask, int cur_len,
-                               const int* len_dev, void* x, void* qkv, void* o, void* h, void* act, float* part_o,
-                               float* part_ml, float* logits, void* stream);
+                               const int* len_dev, void* x, void* qkv, void* o, void* h, void* act, float* ss_ws, int nss,
+                               float* part_o, float* part_ml, float* logits, void* stream);
 
 /* shared-prefix step: B = R * copies sequences grouped by prompt; layer records additionally carry kp (prompt K
  * [R,Hkv,P,hd]) and vtp (prompt V^T [R,Hkv,hd,vt_pitch]); kc / vc are the per-sequence COMPLETION caches [B,Hkv,C,hd]
@@ -165,7 +174,7 @@ int bra_qwen_decode_step_shared(const void* layers_host, int L, int R, int copie
                                 int P, long vt_pitch, int C, int V, float eps, float scale, const void* E,
                                 const void* norm_w, const float* cosT, const float* sinT, const int* tok, const int* pos,
                                 const void* pmask, int t, const int* t_dev, void* x, void* qkv, void* o, void* h, void* act,
-                                float* part_o, float* part_ml, float* logits, void* stream);
+                                float* ss_ws, int nss, float* part_o, float* part_ml, float* logits, void* stream);
 
 /* ---- data movement around the kernels (k_misc.hip) ---------------------------- */
 int bra_head_transpose(const void* x, long sb, long ss, long sh, void* xt, long t_sb, long t_sh, long pitch, int B,

@@ -439,3 +439,38 @@ def test_gemm_tile_variants(backend, variant):
             assert (lse.cpu() - torch.logsumexp(lg, -1).cpu()).abs().max() < 2e-3
     finally:
         get_lib().call("bra_gemm_set_variant", -1)
+
+
+# ----------------------------------------------------------------------------- decode-time streaming projections
+@pytest.mark.parametrize("M,N,K", [(8, 64, 64), (5, 96, 256), (8, 2048, 2048), (8, 2048, 6144), (8, 4096, 2048), (3, 4104, 96), (1, 40, 128)])
+@pytest.mark.parametrize("norm", [False, True])
+def test_dec_gemm2(backend, M, N, K, norm):
+    """bra_dec_gemm2 against fp32 torch with the reference's rounding points (TF:qwen3:59-64 RMSNorm in fp32 -> bf16 ->
+    times weight; residual added to the bf16-rounded projection TF:qwen3:309,315; SwiGLU TF:qwen3:81-83)."""
+    if backend.type == "cpu" and N * K > 3e6:
+        pytest.skip("emulator: large shape covered on the GPU")
+    x, W = rnd(M, K, dev=backend), rnd(N, K, dev=backend, scale=K ** -0.5)
+    res, nw = rnd(M, N, dev=backend), (1 + 0.1 * rnd(K, dev=backend).float()).to(BF)
+    eps = 1e-6
+    xf = x.float()
+    if norm:
+        ss = ops.row_sumsq(x, 32)
+        assert rel(ss[:M, 0], (xf * xf).sum(1)) < 1e-5 and float(ss[:, 1:].abs().max()) == 0
+        xn = (nw.float() * (xf * torch.rsqrt((xf * xf).mean(1, keepdim=True) + eps)).to(BF).float()).to(BF).float()
+    else:
+        ss, xn = None, xf
+    ref = xn @ W.float().T
+    kw = dict(ss_in=ss, norm_w=nw if norm else None, eps=eps)
+    y, ss_out = ops.dec_gemm2(x, W, res=res, want_ss=True, **kw)
+    want = (ref.to(BF).float() + res.float()).to(BF)
+    assert rel(y, want) < 4e-3
+    # the epilogue's partial sums of squares describe exactly the bf16 rows it stored
+    assert rel(ss_out[:M].sum(1), (y.float() ** 2).sum(1)) < 1e-5
+    y32, _ = ops.dec_gemm2(x, W, out_f32=True, **kw)
+    assert rel(y32, ref) < (2e-5 if not norm else 1e-4)
+    if N % 16 == 0:
+        # rows interleaved [8 gate | 8 up] per 16-row block, as rollout_weights lays out gate_proj / up_proj
+        a, _ = ops.dec_gemm2(x, W, act=True, **kw)
+        r3 = ref.to(BF).float().view(M, N // 16, 2, 8)
+        g, u = r3[:, :, 0].reshape(M, -1), r3[:, :, 1].reshape(M, -1)
+        assert rel(a, (torch.nn.functional.silu(g).to(BF).float() * u).to(BF)) < 6e-3

@@ -15,7 +15,8 @@ if os.environ.get("PROBE_LORA", "1") == "1":
 b = synth_prompt_batch(B=8, n_unique=1, dna_token_id=m.dna_token_id, device=dev)
 kw = dict(input_ids=b["input_ids"], attention_mask=b["attention_mask"], dna_tokenized=b["dna_tokenized"], batch_idx_map=b["batch_idx_map"],
           dna_alias=b["dna_alias"], prompt_alias=b["prompt_alias"], do_sample=True, temperature=0.6, top_k=20, top_p=0.95, eos_token_id=None)
-for shared_dec, graph in ((True, True), (True, False), (False, True), (False, False)):
+MODES = {"sg": (True, True), "se": (True, False), "ng": (False, True), "ne": (False, False)}
+for shared_dec, graph in [MODES[k] for k in os.environ.get("PROBE_MODES", "sg,se,ng,ne").split(",")]:
     kw["shared_prefix_decode"], kw["use_graph"] = shared_dec, graph
     for it in range(2):
         torch.cuda.synchronize(); t0 = time.time()
