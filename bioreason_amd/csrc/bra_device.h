@@ -25,6 +25,7 @@ constexpr int kWave = 64;
 
 // ---- bf16 <-> f32 -----------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+#ifdef BRA_EMU
 __device__ __forceinline__ bf16_t f2bf(float f) {
     // round-to-nearest-even, NaN kept quiet (same rounding torch uses)
     uint32_t u = __builtin_bit_cast(uint32_t, f);
@@ -35,6 +36,15 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
+#else
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even): the compiler emits it for a plain cast
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    hw_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+#endif
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 // round an f32 to the nearest bf16 and back (the reference rounds module outputs to bf16)

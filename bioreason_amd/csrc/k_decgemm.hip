@@ -31,103 +31,25 @@ struct DecGemm2Args {
 
 __device__ __forceinline__ float silu_g(float x) { return x / (1.f + __expf(-x)); }
 
-// MODE 0: 16 output columns per workgroup, 32 k per step.  MODE 1: 8 columns, 64 k per step (diagonal).
-template <int MODE, int NORM, int ACT, int OUTF32, int NW, int NL>
-__global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
-    __shared__ float red[NW][64][4];
-    constexpr int KS = MODE ? 64 : 32;
+// epilogue of one column tile, executed by ONE wave on the K-reduced products v (lane: batch row fr, columns 4 fq .. + 3)
+template <int MODE, int ACT, int OUTF32>
+__device__ __forceinline__ void dg2_epilogue(const DecGemm2Args& g, float (&v)[4], int tile, int lane, bool have_res,
+                                             const u32x2& resv) {
     constexpr int NCOL = MODE ? 8 : 16;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = (int)blockIdx.x * NCOL;
-    const int nsteps = g.K / KS;
-    const int lrow = MODE ? (fr & 7) : fr;                            // A row = weight row, B row = batch row
-    const int koff = MODE ? ((fr >> 3) * 32 + fq * 8) : fq * 8;
-    int rn = n0 + lrow; rn = rn < g.N ? rn : g.N - 1;
-    const int xr = lrow < g.M ? lrow : g.M - 1;
-    const bf16_t* wp = g.W + (long)rn * g.ldw + koff;
-    const bf16_t* xp = g.x + (long)xr * g.ldx + koff;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    const int rounds = (nsteps + NW * NL - 1) / (NW * NL);
-
-    // epilogue operands requested now (all waves, clamped addresses: no branch around a load)
-    const int em = fr < g.M ? fr : g.M - 1;
-    int en = n0 + 4 * fq; en = en + 3 < g.N ? en : (g.N >= 4 ? g.N - 4 : 0);
-    u32x2 resv = {0u, 0u};
-    if (!ACT && !OUTF32 && g.res) resv = ld8(g.res + (long)em * g.ldres + en);
-
-    // NORM: lane l folds partials [per * (l & 7), per * (l & 7) + per) of row l >> 3 (per <= 32, fixed order =>
-    // run-to-run identical); requested first, they are the smallest and the first thing the MFMAs need
-    const int per = NORM ? g.nss_in >> 3 : 0;
-    f32x4 pv[8];
-    if (NORM) {
-        const float* pp = g.ss_in + (long)(lane >> 3) * g.nss_in + (lane & 7) * per;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pv[i] = *reinterpret_cast<const f32x4*>(pp + (4 * i < per ? 4 * i : 0));
-    }
-    float rstd = 1.f;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int rd = 0; rd < rounds; ++rd) {
-        const int base = rd * NW * NL;
-        int st[NL];
-#pragma unroll
-        for (int u = 0; u < NL; ++u)      // MODE 0: a wave takes both 64-byte halves of a 128-byte line back to back
-            st[u] = base + (MODE ? wave + NW * u : 2 * (wave + NW * (u >> 1)) + (u & 1));
-        u32x4 w[NL], x[NL], nv[NL];
-#pragma unroll
-        for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; w[u] = ld16_nt(wp + (long)sc * KS); }
-#pragma unroll
-        for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; x[u] = ld16(xp + (long)sc * KS); }
-        if (NORM) {
-#pragma unroll
-            for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; nv[u] = ld16(g.nw + koff + (long)sc * KS); }
-            sched_fence();                // every request above is in flight before the first dependent instruction
-            if (rd == 0) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) reg_fence(pv[i]);
-                float s = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s += 4 * i < per ? (pv[i][0] + pv[i][1]) + (pv[i][2] + pv[i][3]) : 0.f;
-                s += wave_shfl_xor(s, 1); s += wave_shfl_xor(s, 2); s += wave_shfl_xor(s, 4);
-                const float tot = wave_shfl(s, xr * 8);
-                rstd = rsqrtf(tot / (float)g.K + g.eps);
-            }
-#pragma unroll
-            for (int u = 0; u < NL; ++u) {
-                float xf[8], nf[8];
-                unpack8(x[u], xf); unpack8(nv[u], nf);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) xf[i] = nf[i] * round_bf(xf[i] * rstd);
-                x[u] = pack8(xf);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NL; ++u) acc = mfma_16x16x32(st[u] < nsteps ? w[u] : zero4, x[u], acc);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
-    __syncthreads();
-    if (wave != 0) return;
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float s = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < NW; ++wv) s += red[wv][lane][r];
-        v[r] = s;
-    }
+    const int n0 = tile * NCOL;
     if (MODE) {                                   // second K-half of (n, m) sits at (n + 8, m + 8) = lane + 40
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += wave_shfl(v[r], lane + 40);
     }
     const int m = fr;
     if (ACT) {
-        // workgroup rows = [8 gate | 8 up] of features 8*blk .. 8*blk+7: lanes fq < 2 own gate, partners (lane ^ 32) up
+        // tile rows = [8 gate | 8 up] of features 8*tile .. 8*tile+7: lanes fq < 2 own gate, partners (lane ^ 32) up
         float up[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) up[r] = wave_shfl_xor(v[r], 32);
         if (fq < 2 && m < g.M) {
-            const int f0 = (int)blockIdx.x * 8 + 4 * fq;
+            const int f0 = tile * 8 + 4 * fq;
             float a[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = round_bf(silu_g(round_bf(v[r]))) * round_bf(up[r]);
@@ -141,16 +63,17 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
     if (OUTF32) {
         if (live) {
             float* cp = (float*)g.out + (long)m * g.ldo + n;
-            for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = v[r];
+            if (n + 3 < g.N && (g.ldo & 3) == 0) { f32x4 o = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(cp) = o; }
+            else for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = v[r];
         }
         return;
     }
     float ss = 0.f;
     if (g.res) {
-        const float r0 = bf2f((bf16_t)(resv.x & 0xffffu)), r1 = bf2f((bf16_t)(resv.x >> 16));
-        const float r2 = bf2f((bf16_t)(resv.y & 0xffffu)), r3 = bf2f((bf16_t)(resv.y >> 16));
-        if (n == en) { v[0] = round_bf(v[0]) + r0; v[1] = round_bf(v[1]) + r1; v[2] = round_bf(v[2]) + r2; v[3] = round_bf(v[3]) + r3; }
-        else if (live) {
+        if (have_res && n + 3 < g.N) {
+            v[0] = round_bf(v[0]) + bf_lo(resv.x); v[1] = round_bf(v[1]) + bf_hi(resv.x);
+            v[2] = round_bf(v[2]) + bf_lo(resv.y); v[3] = round_bf(v[3]) + bf_hi(resv.y);
+        } else if (live) {
             for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] = round_bf(v[r]) + bf2f(g.res[(long)m * g.ldres + n + r]);
         }
     }
@@ -165,7 +88,186 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
         if (!live) ss = 0.f;
         ss += wave_shfl_xor(ss, 16);
         ss += wave_shfl_xor(ss, 32);
-        if (fq == 0 && fr < 8 && m < g.M) g.ss_out[(long)m * g.nss_out + blockIdx.x] = ss;
+        if (fq == 0 && fr < 8 && m < g.M) g.ss_out[(long)m * g.nss_out + tile] = ss;
+    }
+}
+
+// MODE 0: 16 output columns per tile, 32 k per step.  MODE 1: 8 columns, 64 k per step (diagonal).
+// A workgroup walks the tiles blockIdx.x, + gridDim.x, ..: its waves split K, keep their (normalised) activation
+// fragments in registers for all tiles, request tile i+1's weights before multiplying tile i, and hand the K-reduction
+// and epilogue of tile i to wave i % NW through a double-buffered LDS slab (one barrier per tile).
+template <int MODE, int NORM, int ACT, int OUTF32, int NW, int NL>
+__global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
+    __shared__ float red[2][NW][64][4];
+    constexpr int KS = MODE ? 64 : 32;
+    constexpr int NCOL = MODE ? 8 : 16;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nsteps = g.K / KS;
+    const int ntiles = (g.N + NCOL - 1) / NCOL;
+    const int lrow = MODE ? (fr & 7) : fr;                            // A row = weight row, B row = batch row
+    const int koff = MODE ? ((fr >> 3) * 32 + fq * 8) : fq * 8;
+    const int xr = lrow < g.M ? lrow : g.M - 1;
+    const bf16_t* xp = g.x + (long)xr * g.ldx + koff;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const int rounds = (nsteps + NW * NL - 1) / (NW * NL);
+    int tile = (int)blockIdx.x;
+    int rn = tile * NCOL + lrow; rn = rn < g.N ? rn : g.N - 1;
+    const bf16_t* wp = g.W + (long)rn * g.ldw + koff;
+
+    // epilogue operand of the first tile requested now (all waves, clamped address: no branch around a load)
+    const int em = fr < g.M ? fr : g.M - 1;
+    int en = tile * NCOL + 4 * fq; en = en + 3 < g.N ? en : (g.N >= 4 ? g.N - 4 : 0);
+    u32x2 resv = {0u, 0u};
+    if (!ACT && !OUTF32 && g.res) resv = ld8(g.res + (long)em * g.ldres + en);
+
+    // NORM: lane l folds partials [per * (l & 7), per * (l & 7) + per) of row l >> 3 (per <= 32, fixed order =>
+    // run-to-run identical); requested first, they are the smallest and the first thing the MFMAs need
+    const int per = NORM ? g.nss_in >> 3 : 0;
+    f32x4 pv[8];
+    if (NORM) {
+        const float* pp = g.ss_in + (long)(lane >> 3) * g.nss_in + (lane & 7) * per;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pv[i] = *reinterpret_cast<const f32x4*>(pp + (4 * i < per ? 4 * i : 0));
+    }
+    float rstd = 1.f;
+
+    if (rounds == 1) {
+        int st[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u)      // MODE 0: a wave takes both 64-byte halves of a 128-byte line back to back
+            st[u] = MODE ? wave + NW * u : 2 * (wave + NW * (u >> 1)) + (u & 1);
+        long so[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) so[u] = (long)(st[u] < nsteps ? st[u] : nsteps - 1) * KS;
+        // request order = arrival order (one in-order counter per wave): statistics, activations, norm weights, then
+        // the weight tile, so that the normalisation below runs while the weights are still in flight
+        u32x4 w0[NL], w1[NL], x[NL], nv[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) x[u] = ld16(xp + so[u]);
+        if (NORM) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) nv[u] = ld16(g.nw + koff + so[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) w0[u] = ld16_nt(wp + so[u]);
+        sched_fence();                    // every request above is in flight before the first dependent instruction
+        if (NORM) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) reg_fence(pv[i]);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += 4 * i < per ? (pv[i][0] + pv[i][1]) + (pv[i][2] + pv[i][3]) : 0.f;
+            s += wave_shfl_xor(s, 1); s += wave_shfl_xor(s, 2); s += wave_shfl_xor(s, 4);
+            rstd = rsqrtf(wave_shfl(s, xr * 8) / (float)g.K + g.eps);
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                float xf[8], nf[8];
+                unpack8(x[u], xf); unpack8(nv[u], nf);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xf[i] = nf[i] * round_bf(xf[i] * rstd);
+                x[u] = pack8(xf);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) if (st[u] >= nsteps) x[u] = zero4;        // steps past K contribute zero
+        // weight registers ping-pong (w0 / w1): tile i+1 is requested before tile i is multiplied.  The requests sit
+        // in straight-line code (no branch around a load: the compiler would wait for them at the join), so the last
+        // one or two tiles are peeled.
+        const int G = (int)gridDim.x;
+        const int nmine = (ntiles - tile + G - 1) / G;
+        auto issue = [&](u32x4 (&wn)[NL], int t) {
+            int rnn = t * NCOL + lrow; rnn = rnn < g.N ? rnn : g.N - 1;
+            const bf16_t* wpn = g.W + (long)rnn * g.ldw + koff;
+#pragma unroll
+            for (int u = 0; u < NL; ++u) wn[u] = ld16_nt(wpn + so[u]);
+        };
+        auto compute = [&](u32x4 (&wc)[NL], int t, int it) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < NL; ++u) acc = mfma_16x16x32(wc[u], x[u], acc);
+            float (*slab)[64][4] = red[it & 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[wave][lane][r] = acc[r];
+            __syncthreads();
+            if (wave == it % NW) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int wv = 0; wv < NW; ++wv) sum += slab[wv][lane][r];
+                    v[r] = sum;
+                }
+                dg2_epilogue<MODE, ACT, OUTF32>(g, v, t, lane, it == 0, resv);
+            }
+        };
+        int it = 0;
+        for (; it + 2 < nmine; it += 2) {
+            issue(w1, tile + (it + 1) * G); compute(w0, tile + it * G, it);
+            issue(w0, tile + (it + 2) * G); compute(w1, tile + (it + 1) * G, it + 1);
+        }
+        if (nmine - it == 2) {
+            issue(w1, tile + (it + 1) * G); compute(w0, tile + it * G, it);
+            compute(w1, tile + (it + 1) * G, it + 1);
+        } else {
+            compute(w0, tile + it * G, it);
+        }
+        return;
+    }
+
+    // K larger than one register round (NW * NL steps): one tile per iteration, fragments re-read every round
+    for (int it = 0; tile < ntiles; ++it, tile += (int)gridDim.x) {
+        rn = tile * NCOL + lrow; rn = rn < g.N ? rn : g.N - 1;
+        wp = g.W + (long)rn * g.ldw + koff;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int rd = 0; rd < rounds; ++rd) {
+            const int base = rd * NW * NL;
+            int st[NL];
+#pragma unroll
+            for (int u = 0; u < NL; ++u) st[u] = base + (MODE ? wave + NW * u : 2 * (wave + NW * (u >> 1)) + (u & 1));
+            u32x4 w[NL], x[NL], nv[NL];
+#pragma unroll
+            for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; w[u] = ld16_nt(wp + (long)sc * KS); }
+#pragma unroll
+            for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; x[u] = ld16(xp + (long)sc * KS); }
+            if (NORM) {
+#pragma unroll
+                for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; nv[u] = ld16(g.nw + koff + (long)sc * KS); }
+                if (it == 0 && rd == 0) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) s += 4 * i < per ? (pv[i][0] + pv[i][1]) + (pv[i][2] + pv[i][3]) : 0.f;
+                    s += wave_shfl_xor(s, 1); s += wave_shfl_xor(s, 2); s += wave_shfl_xor(s, 4);
+                    rstd = rsqrtf(wave_shfl(s, xr * 8) / (float)g.K + g.eps);
+                }
+#pragma unroll
+                for (int u = 0; u < NL; ++u) {
+                    float xf[8], nf[8];
+                    unpack8(x[u], xf); unpack8(nv[u], nf);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xf[i] = nf[i] * round_bf(xf[i] * rstd);
+                    x[u] = pack8(xf);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NL; ++u) acc = mfma_16x16x32(st[u] < nsteps ? w[u] : zero4, x[u], acc);
+        }
+        float (*slab)[64][4] = red[it & 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[wave][lane][r] = acc[r];
+        __syncthreads();
+        if (wave == it % NW) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < NW; ++wv) s += slab[wv][lane][r];
+                v[r] = s;
+            }
+            dg2_epilogue<MODE, ACT, OUTF32>(g, v, tile, lane, it == 0, resv);
+        }
     }
 }
 
@@ -193,7 +295,9 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     const int nw = nsteps >= 64 ? 8 : 4;
     const int spw = (nsteps + nw - 1) / nw;
     const int nl = (spw >= 12 && spw % 12 == 0) ? 12 : (spw > 4 ? 8 : 4);
-    const dim3 grid(MODE ? g.N / 8 : (g.N + 15) / 16);
+    const int ntiles = MODE ? g.N / 8 : (g.N + 15) / 16;
+    const int gmax = nw == 8 ? 256 : 512;           // one workgroup of 8 waves (two of 4) per CU, looping over the tiles
+    const dim3 grid(ntiles < gmax ? ntiles : gmax);
 #define BRA_DG2(NW_, NL_) BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_>), grid, dim3(NW_ * 64), 0, st, g)
     if (nw == 8) { if (nl == 12) BRA_DG2(8, 12); else if (nl == 8) BRA_DG2(8, 8); else BRA_DG2(8, 4); }
     else { if (nl == 12) BRA_DG2(4, 12); else if (nl == 8) BRA_DG2(4, 8); else BRA_DG2(4, 4); }

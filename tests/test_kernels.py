@@ -442,7 +442,8 @@ def test_gemm_tile_variants(backend, variant):
 
 
 # ----------------------------------------------------------------------------- decode-time streaming projections
-@pytest.mark.parametrize("M,N,K", [(8, 64, 64), (5, 96, 256), (8, 2048, 2048), (8, 2048, 6144), (8, 4096, 2048), (3, 4104, 96), (1, 40, 128)])
+@pytest.mark.parametrize("M,N,K", [(8, 64, 64), (5, 96, 256), (8, 2048, 2048), (8, 2048, 6144), (8, 4096, 2048), (3, 4104, 96), (1, 40, 128),
+                                   (8, 9616, 64), (4, 48, 1664), (2, 16, 3328)])
 @pytest.mark.parametrize("norm", [False, True])
 def test_dec_gemm2(backend, M, N, K, norm):
     """bra_dec_gemm2 against fp32 torch with the reference's rounding points (TF:qwen3:59-64 RMSNorm in fp32 -> bf16 ->
