@@ -215,11 +215,9 @@ __device__ __forceinline__ void norm_rope_slice(float (&x)[8], const bf16_t* nw,
 }
 
 template <int HD, int G>
-__global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
+__device__ __forceinline__ void dec_attn_partial_body(const DecAttnArgs& a, const int c, const int hkv, const int b) {
     constexpr int CK = 64, LPK = HD / 8, KPI = 64 / LPK, NIT = CK / KPI, GRP = NIT / 2;   // 64 positions per wave
     const int lane = lane_id();
-    const int c = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    const int hkv = (int)blockIdx.y, b = (int)blockIdx.z;
     int cur_len = a.cur_len, nchunk = a.nchunk, nchunk_tot = a.nchunk_tot;
     if (a.t_ptr) { cur_len = a.t_ptr[0]; nchunk = (cur_len + 64) / 64; nchunk_tot = a.chunk_off + nchunk; }
     if (c >= nchunk) return;
@@ -358,6 +356,11 @@ __global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
     }
 }
 
+template <int HD, int G>
+__global__ __launch_bounds__(256) void dec_attn_partial_kernel(DecAttnArgs a) {
+    dec_attn_partial_body<HD, G>(a, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), (int)blockIdx.y, (int)blockIdx.z);
+}
+
 }  // namespace bra
 
 using namespace bra;
@@ -444,12 +447,11 @@ struct DecSharedArgs {
 };
 
 template <int HD, int G>
-__global__ __launch_bounds__(64) void dec_attn_shared_kernel(DecSharedArgs a) {
+__device__ __forceinline__ void dec_attn_shared_body(const DecSharedArgs& a, const int c, const int hkv, const int r) {
     constexpr int DS = HD / 32;           // 32-deep contraction steps over the head dim
     constexpr int DB = HD / 16;           // 16-wide output blocks over the head dim
     const int lane = lane_id();
     const int fr = lane & 15, fq = lane >> 4;
-    const int c = (int)blockIdx.x, hkv = (int)blockIdx.y, r = (int)blockIdx.z;
     const int s0 = c * 64;
     const int rows = a.copies * G;                         // live query rows (<= 16)
     const int qrow = fr < rows ? fr : rows - 1;
@@ -573,6 +575,26 @@ __global__ __launch_bounds__(64) void dec_attn_shared_kernel(DecSharedArgs a) {
     if (live && fq == 0) { a.part_ml[base * 2] = m; a.part_ml[base * 2 + 1] = l; }
 }
 
+template <int HD, int G>
+__global__ __launch_bounds__(64) void dec_attn_shared_kernel(DecSharedArgs a) {
+    dec_attn_shared_body<HD, G>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// both halves of the shared-prefix decode attention in ONE launch: single-wave workgroups [0, nsh) take the
+// (prompt, kv-head, prompt chunk) items, the rest the (sequence, kv-head, completion chunk) items; they are independent
+// (disjoint partial slots), so nothing orders them and a layer saves one dependent launch
+template <int HD, int G>
+__global__ __launch_bounds__(64) void dec_attn_both_kernel(DecSharedArgs s, DecAttnArgs a, int npc, int ncc) {
+    const int w = (int)blockIdx.x;
+    const int nsh = npc * s.Hkv * s.R;
+    if (w < nsh) {
+        dec_attn_shared_body<HD, G>(s, w % npc, (w / npc) % s.Hkv, w / (npc * s.Hkv));
+    } else {
+        const int v = w - nsh;
+        dec_attn_partial_body<HD, G>(a, v % ncc, (v / ncc) % a.Hkv, v / (ncc * a.Hkv));
+    }
+}
+
 }  // namespace bra
 
 extern "C" int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, const float* cosT, const float* sinT,
@@ -597,5 +619,33 @@ extern "C" int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, 
     }
     BRA_DS(128, 1) BRA_DS(128, 2) BRA_DS(128, 4) BRA_DS(64, 1) BRA_DS(64, 2) BRA_DS(64, 4)   // hd 32: per-copy path
 #undef BRA_DS
+    return BRA_ERR_UNSUPPORTED;
+}
+
+extern "C" int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT,
+                                 const float* sinT, const int* pos, const void* kp, long kp_sr, long kp_sh, long kp_ss,
+                                 const void* vtp, long vt_sr, long vt_sh, long vt_sd, const void* pmask, void* kc, void* vc,
+                                 float* part_o, float* part_ml, int R, int copies, int Hq, int Hkv, int hd, int P, int C,
+                                 int t, float eps, float scale, const int* t_dev, void* stream) {
+    if (R <= 0 || copies <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || P <= 0 || t < 0 || t >= C) return BRA_ERR_ARG;
+    const int G = Hq / Hkv, B = R * copies;
+    if (copies * G > 16) return BRA_ERR_UNSUPPORTED;
+    if (!qkv || !qw || !kw || !cosT || !sinT || !pos || !kp || !vtp || !kc || !vc || !part_o || !part_ml) return BRA_ERR_ARG;
+    if (vt_sd < ((P + 63) / 64) * 64 || vt_sd % 4 || kp_ss % 8) return BRA_ERR_ARG;
+    const int npc = (P + 63) / 64, ncc = (t + 64) / 64, ntot = npc + ncc;
+    DecSharedArgs s = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, cosT, sinT, pos, (const bf16_t*)kp, kp_sr, kp_sh, kp_ss,
+                       (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask, part_o, part_ml, R, copies, Hq, Hkv, P,
+                       ntot, eps, scale, t_dev};
+    DecAttnArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, (bf16_t*)kc,
+                     (bf16_t*)vc, nullptr, part_o, part_ml, B, Hq, Hkv, C, t, ncc, eps, scale, npc, ntot, t_dev};
+    bra_stream_t st = (bra_stream_t)stream;
+    const dim3 grid(npc * Hkv * R + ncc * Hkv * B);
+#define BRA_DB(HD_, G_)                                                                         \
+    if (hd == HD_ && G == G_) {                                                                 \
+        BRA_LAUNCH((dec_attn_both_kernel<HD_, G_>), grid, dim3(64), 0, st, s, a, npc, ncc);     \
+        return BRA_LAUNCH_STATUS();                                                             \
+    }
+    BRA_DB(128, 1) BRA_DB(128, 2) BRA_DB(128, 4) BRA_DB(64, 1) BRA_DB(64, 2) BRA_DB(64, 4)
+#undef BRA_DB
     return BRA_ERR_UNSUPPORTED;
 }

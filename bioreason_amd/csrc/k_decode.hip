@@ -134,7 +134,7 @@ extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B,
 
 // Shared-prefix variant: the B = R * copies sequences are grouped by prompt; the prompt part of the attention reads
 // ONE copy of the prompt K / V^T (bra_dec_attn_shared), the completion part the per-sequence completion cache
-// kc / vc [B, Hkv, C, hd] at index `t` (number of completion tokens already cached).  7 launches per layer.
+// kc / vc [B, Hkv, C, hd] at index `t` (number of completion tokens already cached).  6 launches per layer.
 // With `t_dev` (device int) the kernels read t from memory and the host `t` only sizes the grids (pass C - 1): the
 // launch arguments are then identical for every step, so the step can be captured once in a hipGraph and replayed.
 extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R, int copies, int H, int Hq, int Hkv, int hd,
@@ -154,11 +154,9 @@ extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R
     for (int li = 0; li < L; ++li) {
         const Layer& l = ls[li];
         CK(sg_qkv(sg, l, x, qkv));
-        CK(bra_dec_attn_shared(qkv, Nqkv, l.qn, cosT, sinT, pos, l.kp, (long)Hkv * P * hd, (long)P * hd, (long)hd, l.vtp,
-                               (long)Hkv * hd * vt_pitch, (long)hd * vt_pitch, vt_pitch, pmask, part_o, part_ml, R, copies, Hq,
-                               Hkv, hd, P, ntot, eps, scale, t_dev, stream));
-        CK(bra_dec_attn_partial(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, l.kc, l.vc, nullptr, part_o, part_ml, B, Hq, Hkv, hd,
-                                C, t, eps, scale, npc, ntot, t_dev, stream));
+        CK(bra_dec_attn_both(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, l.kp, (long)Hkv * P * hd, (long)P * hd, (long)hd, l.vtp,
+                             (long)Hkv * hd * vt_pitch, (long)hd * vt_pitch, vt_pitch, pmask, l.kc, l.vc, part_o, part_ml, R,
+                             copies, Hq, Hkv, hd, P, C, t, eps, scale, t_dev, stream));
         CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, ntot, t_dev, npc, stream));
         CK(sg_tail(sg, l, o, x, h, act));
     }

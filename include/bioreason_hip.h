@@ -159,6 +159,12 @@ int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, const float
                         const void* kp, long kp_sr, long kp_sh, long kp_ss, const void* vtp, long vt_sr, long vt_sh,
                         long vt_sd, const void* pmask, float* part_o, float* part_ml, int R, int copies, int Hq, int Hkv,
                         int hd, int P, int nchunk_tot, float eps, float scale, const int* t_dev, void* stream);
+/* bra_dec_attn_shared + bra_dec_attn_partial (on the completion caches kc / vc [B, Hkv, C, hd], index t) in one launch */
+int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT, const float* sinT,
+                      const int* pos, const void* kp, long kp_sr, long kp_sh, long kp_ss, const void* vtp, long vt_sr,
+                      long vt_sh, long vt_sd, const void* pmask, void* kc, void* vc, float* part_o, float* part_ml, int R,
+                      int copies, int Hq, int Hkv, int hd, int P, int C, int t, float eps, float scale, const int* t_dev,
+                      void* stream);
 int bra_attn_decode_merge(const float* part_o, const float* part_ml, void* o, int B, int Hq, int hd, int nchunk,
                           const int* t_dev, int npc, void* stream);
 int bra_qwen_decode_step_fused(const void* layers_host, int L, int B, int H, int Hq, int Hkv, int hd, int F, int Smax,

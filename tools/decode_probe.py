@@ -24,3 +24,12 @@ for shared_dec, graph in [MODES[k] for k in os.environ.get("PROBE_MODES", "sg,se
         m.generate(max_new_tokens=C, **kw); torch.cuda.synchronize(); t2 = time.time()
         print("shared", shared_dec, "graph", graph, "prefill+1 ms %.1f" % ((t1 - t0) * 1e3), "gen", C, "ms %.1f" % ((t2 - t1) * 1e3),
               "per decode step ms %.3f" % (((t2 - t1) - (t1 - t0)) * 1e3 / (C - 1)), flush=True)
+
+# cost of rebuilding the merged rollout weights (done once per training step, after the optimizer touched the adapters)
+from bioreason_amd import generation
+eng = m.text_model.engine
+for it in range(2):
+    eng._rollout = None
+    torch.cuda.synchronize(); t0 = time.time()
+    generation.rollout_weights(m.text_model); torch.cuda.synchronize()
+    print("rollout_weights rebuild ms %.2f" % ((time.time() - t0) * 1e3), flush=True)
