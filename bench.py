@@ -102,6 +102,24 @@ def cpu_baseline(max_seconds: float = 60.0):
                       f"policy fwd+bwd {t_pol:.1f}s; model build {build_s:.0f}s not counted"}
 
 
+def decode_roofline(model, rollout_profile, C):
+    """HBM roofline of the rollout's token loop (the largest phase of the step; every kernel in it is a weight / KV
+    stream): algorithmic bytes of one decode step = merged bf16 projection weights + tied lm_head + the K/V rows the
+    step attends to (prompt rows once per prompt, completion rows per sequence, averaged over the C steps), divided by
+    the measured time per step (host-synchronised wall time of the replayed hipGraph loop in the instrumented step)."""
+    e = model.text_model.engine
+    w_bytes = 2 * (e.L * ((e.Nq + 2 * e.Nkv) * e.H + e.H * e.Nq + 3 * e.F * e.H) + e.V * e.H)
+    kv_bytes = e.L * 2 * e.Nkv * 2 * (1 * 2180 + G * (C / 2.0))
+    ms = rollout_profile.get("decode_loop")
+    if not ms or C < 3:
+        return None
+    per_step_ms = ms / (C - 1)
+    ach = (w_bytes + kv_bytes) / (per_step_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+            "bytes_per_step": w_bytes + kv_bytes, "ms_per_token_step": per_step_ms,
+            "kernels": "dec_gemm2_kernel<...> x4 + dec_attn_both + attn_decode_merge per layer, lm_head, sampler"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,7 +171,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ops.GEMM_PROFILE = ops.GemmProfile(min_m=1024)
+    ops.GEMM_PROFILE = ops.GemmProfile(dominant_only=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -186,8 +204,10 @@ def main():
                        "global_batch": world * G, "prompt_len": 2180, "completion_len": args.completion_len, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": prof["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": prof["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
-                         "kernel": "gemm_nt_kernel<64,EPI_BF16> (launches with M>=1024)", "launches": prof["launches"],
-                         "avg_launch_ms": prof["avg_launch_ms"]},
+                         "kernel": "gemm_glds_kernel<*, 1> (256x128 LDS-DMA tiles: every projection / lm_head GEMM of the "
+                                   "prefill, ref, policy forward and backward passes that fills the chip)",
+                         "launches": prof["launches"], "avg_launch_ms": prof["avg_launch_ms"]},
+            "decode_roofline": decode_roofline(model, runner.rollout_profile, args.completion_len),
             "step_tflops": value / world * flops_per_sample() / 1e12,
             "step_frac_of_mfma_peak": value / world * flops_per_sample() / 1e12 / PEAK_BF16_TFLOPS,
             "phases_ms": {k: round(v, 2) for k, v in runner.timers.items()},

@@ -256,7 +256,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
              check_every: int = 16, return_full_length: bool = False,
              force_tokens: Optional[torch.Tensor] = None, native_step: bool = True,
              decode_impl: str = "fused", prompt_alias=None, use_graph: Optional[bool] = None,
-             shared_prefix_decode: bool = True) -> torch.Tensor:
+             shared_prefix_decode: bool = True, profile: Optional[dict] = None) -> torch.Tensor:
     """`force_tokens` [B, max_new_tokens] (optional): teacher forcing — the model's own choice is still recorded
     in the output, but the given token is fed back (used to compare decodes position by position).
     `use_graph` (default: on for the fused native step on a GPU): sample + decode step + counter updates are captured
@@ -265,6 +265,18 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     eng = model.ensure_packed()
     B, P, H = inputs_embeds.shape
     dev = inputs_embeds.device
+    import time as _time
+    _t0 = [_time.perf_counter()]
+
+    def _tick(name):
+        # `profile` (diagnostics only): host-synchronised wall time of the phases of this call, in ms
+        if profile is not None:
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            now = _time.perf_counter()
+            profile[name] = profile.get(name, 0.0) + (now - _t0[0]) * 1e3
+            _t0[0] = now
+
     if isinstance(eos_token_id, (list, tuple)):
         eos_token_id = eos_token_id[0]
     eos = -1 if eos_token_id is None else int(eos_token_id)
@@ -306,6 +318,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             del cache_r
         hid = hid_r.index_select(0, gmap).contiguous()
     next_pos = (pos_prompt[:, -1] + 1).contiguous()                               # TF:generation/utils.py:979-984
+    _tick("prefill")
 
     tokens = torch.full((B, max_new_tokens), pad, dtype=torch.int32, device=dev)
     finished = torch.zeros((B,), dtype=torch.uint8, device=dev)
@@ -339,6 +352,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         step_t.add_(1)
         len_t.add_(1)
 
+    _tick("decode_setup")
     if use_graph:
         sample_()
         advance_(0)                                     # eager first step: one-time kernel attribute set-up happens here
@@ -346,6 +360,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         with torch.cuda.graph(graph):
             sample_()
             advance_(max_new_tokens - 1)
+        _tick("graph_capture")
         for t in range(1, max_new_tokens - 1):
             graph.replay()
             if eos >= 0 and (t + 1) % check_every == 0 and bool(finished.all().item()):
@@ -373,6 +388,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
             next_pos += 1
             step_t += 1
+    _tick("decode_loop")
     out = tokens[:, :n_done]
     if eos >= 0 and not return_full_length and force_tokens is None:
         # HF stops right after the step in which the last row finished: trim the all-pad tail we may have produced

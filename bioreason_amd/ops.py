@@ -61,7 +61,7 @@ def gemm_nt(
         res = _as2d(res)
         assert res.shape == (M, N) and res.dtype == BF16
     prof = GEMM_PROFILE
-    timed = prof is not None and M >= prof.min_m and a.is_cuda
+    timed = prof is not None and a.is_cuda and prof.wants(M, N, K, K2)
     if timed:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -80,9 +80,18 @@ def gemm_nt(
 class GemmProfile:
     """bench.py hook: HIP events (on the launch stream) around every large-M launch of the dominant kernel."""
 
-    def __init__(self, min_m: int = 1024):
+    def __init__(self, min_m: int = 1024, dominant_only: bool = True):
         self.min_m = min_m
+        self.dominant_only = dominant_only
         self.records = []
+
+    def wants(self, M: int, N: int, K: int, K2: int) -> bool:
+        """dominant_only: exactly the launches k_gemm.hip's pick_variant() sends to gemm_glds_kernel<*, 1> (the 256x128
+        LDS-DMA tile kernel, MFMA-bound); otherwise every launch with M >= min_m (that also counts the N = 32 LoRA
+        projections, which are HBM-bound reads of the activations)"""
+        if not self.dominant_only:
+            return M >= self.min_m
+        return K % 64 == 0 and K2 % 64 == 0 and ((M + 255) // 256) * ((N + 127) // 128) >= 192
 
     def summary(self):
         torch.cuda.synchronize()

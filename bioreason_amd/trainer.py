@@ -65,6 +65,7 @@ class GRPOStepRunner:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.step_idx = 0
         self.timers: Dict[str, float] = {}
+        self.rollout_profile: Dict[str, float] = {}      # filled by step(timing=True): phases inside generate(), ms
 
     def step(self, batch: Dict, timing: bool = False) -> Dict[str, float]:
         m, c = self.model, self.cfg
@@ -78,6 +79,8 @@ class GRPOStepRunner:
                 e.record()
                 marks.append((name, e))
 
+        if timing:
+            self.rollout_profile.clear()
         mm = {"dna_tokenized": batch["dna_tokenized"], "batch_idx_map": batch["batch_idx_map"], "dna_alias": batch.get("dna_alias")}
         prompt_ids, prompt_mask = batch["input_ids"], batch["attention_mask"]
         B = prompt_ids.shape[0]
@@ -88,7 +91,8 @@ class GRPOStepRunner:
                                     top_k=c.top_k, top_p=c.top_p, eos_token_id=c.eos_token_id, pad_token_id=c.pad_token_id,
                                     seed=c.seed + 1000003 * self.step_idx + self.rank, return_full_length=True,
                                     prompt_alias=batch.get("prompt_alias"), use_graph=c.rollout_graph,
-                                    shared_prefix_decode=c.rollout_shared_prefix)
+                                    shared_prefix_decode=c.rollout_shared_prefix,
+                                    profile=self.rollout_profile if timing else None)
         mark("rollout")
         if c.eos_token_id is not None:
             cmask = grpo.completion_mask(completion_ids, c.eos_token_id)

@@ -25,6 +25,12 @@ for shared_dec, graph in [MODES[k] for k in os.environ.get("PROBE_MODES", "sg,se
         print("shared", shared_dec, "graph", graph, "prefill+1 ms %.1f" % ((t1 - t0) * 1e3), "gen", C, "ms %.1f" % ((t2 - t1) * 1e3),
               "per decode step ms %.3f" % (((t2 - t1) - (t1 - t0)) * 1e3 / (C - 1)), flush=True)
 
+prof = {}
+kw["shared_prefix_decode"], kw["use_graph"] = True, True
+torch.cuda.synchronize(); t0 = time.time()
+m.generate(max_new_tokens=C, profile=prof, **kw); torch.cuda.synchronize()
+print("generate total ms %.1f" % ((time.time() - t0) * 1e3), {k: round(v, 2) for k, v in prof.items()}, flush=True)
+
 # cost of rebuilding the merged rollout weights (done once per training step, after the optimizer touched the adapters)
 from bioreason_amd import generation
 eng = m.text_model.engine
