@@ -46,6 +46,7 @@ class TrainableArena:
         self._pack_max = 0
         self.step_count = 0
         self._sumsq: Optional[torch.Tensor] = None
+        self._sumsq_ws: Optional[torch.Tensor] = None
         # autograd anchor: a leaf that requires grad, passed into the fused Functions so that their backward
         # (which writes LoRA / projection gradients into `grads` as a side effect) always runs
         self.anchor = torch.zeros(1, dtype=torch.float32, device=self.device, requires_grad=True)
@@ -90,6 +91,7 @@ class TrainableArena:
                 setattr(self, nm, t.to(device))
         self.anchor = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)
         self._sumsq = None
+        self._sumsq_ws = None
         self._packs, self._pack_table = [], None
         for fn in self._rebind:
             fn()
@@ -151,8 +153,9 @@ class TrainableArena:
         self.step_count += 1
         ss = None
         if max_grad_norm and max_grad_norm > 0:
-            self._sumsq.zero_()
-            ops.sumsq(self.grads, self._sumsq, mask=self.mask)
+            if self._sumsq_ws is None:
+                self._sumsq_ws = torch.empty((1024,), dtype=torch.float32, device=self.device)
+            ops.sumsq(self.grads, self._sumsq, mask=self.mask, ws=self._sumsq_ws)
             ss = self._sumsq
         ops.adamw(self.params, self.grads, self.exp_avg, self.exp_avg_sq, lr, betas[0], betas[1], eps, weight_decay,
                   self.step_count, sumsq_t=ss, max_norm=max_grad_norm, grad_scale=grad_scale, mask=self.mask)

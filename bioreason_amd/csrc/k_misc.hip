@@ -282,12 +282,26 @@ __global__ __launch_bounds__(256) void vec_sum_kernel(const float* x, long n, fl
 // global-norm clip (max_grad_norm) read from a device scalar so no host sync is needed.
 // `mask` (bytes, optional): 0 marks structural zeros of the packed LoRA layout (off-diagonal blocks of a fused
 // B matrix, padding rows) — excluded from the norm and never updated.
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, const uint8_t* mask, long n, float* out) {
+// Two fixed-order stages (no atomics): data-parallel replicas must compute bit-identical clip factors from their
+// bit-identical all-reduced gradients, or they drift apart.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, const uint8_t* mask, long n, float* ws) {
+    __shared__ float part[4];
     float acc = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
         if (!mask || mask[i]) acc += g[i] * g[i];
     acc = wave_sum<64>(acc);
-    if (lane_id() == 0) atomicAdd(out, acc);
+    if (lane_id() == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* ws, int nblk, float* out) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    for (int i = (int)threadIdx.x; i < nblk; i += 256) acc += ws[i];
+    acc = wave_sum<64>(acc);
+    if (lane_id() == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v,
                                                     const uint8_t* mask, long n, float lr, float b1, float b2,
@@ -432,10 +446,13 @@ extern "C" int bra_vec_sum(const float* x, long n, float scale, float* out, void
     return BRA_LAUNCH_STATUS();
 }
 
-extern "C" int bra_sumsq(const float* g, const void* mask, long n, float* out, void* stream) {
-    if (n == 0) return 0;
-    if (!g || !out) return BRA_ERR_ARG;
-    BRA_LAUNCH(sumsq_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, g, (const uint8_t*)mask, n, out);
+extern "C" int bra_sumsq(const float* g, const void* mask, long n, float* out, float* ws, void* stream) {
+    if (!out || !ws) return BRA_ERR_ARG;
+    if (n > 0 && !g) return BRA_ERR_ARG;
+    int nblk = n > 0 ? ew_grid(n) : 1;
+    nblk = nblk < 1024 ? nblk : 1024;                    // ws holds 1024 floats
+    BRA_LAUNCH(sumsq_kernel, dim3(nblk), dim3(256), 0, stream, g, (const uint8_t*)mask, n, ws);
+    BRA_LAUNCH(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, ws, nblk, out);
     return BRA_LAUNCH_STATUS();
 }
 

@@ -381,8 +381,11 @@ def vec_sum(x: torch.Tensor, scale: float) -> torch.Tensor:
     return out
 
 
-def sumsq(g: torch.Tensor, out: torch.Tensor, mask=None):
-    get_lib().call("bra_sumsq", g, mask, g.numel(), out, current_stream(g))
+def sumsq(g: torch.Tensor, out: torch.Tensor, mask=None, ws: Optional[torch.Tensor] = None):
+    """out[0] = sum(g^2) (overwritten), summed in a fixed order"""
+    if ws is None:
+        ws = torch.empty((1024,), dtype=torch.float32, device=g.device)
+    get_lib().call("bra_sumsq", g, mask, g.numel(), out, ws, current_stream(g))
 
 
 def adamw(p, g, m, v, lr, b1, b2, eps, wd, step, sumsq_t=None, max_norm=0.0, grad_scale=1.0, mask=None):

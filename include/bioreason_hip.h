@@ -208,8 +208,10 @@ int bra_pack_params(const void* descs_dev, int ndesc, long max_elems, void* stre
 /* AdamW over one flat arena with device-side global-norm clip (train_dna_qwen.py:393-411, :1003 clip 1.0) */
 /* out[0] = scale * sum(x): the `mean` of F.cross_entropy (TF:loss/loss_utils.py:32-46) */
 int bra_vec_sum(const float* x, long n, float scale, float* out, void* stream);
-/* mask (bytes, optional): 0 = structural zero of the packed LoRA layout, excluded from norm and update */
-int bra_sumsq(const float* g, const void* mask, long n, float* out, void* stream);
+/* out[0] = sum of squares of g (global-norm clip, max_grad_norm); ws = float[1024] scratch.  Fixed summation order,
+ * no atomics: replicas holding identical gradients get identical norms.
+ * mask (bytes, optional): 0 = structural zero of the packed LoRA layout, excluded from norm and update */
+int bra_sumsq(const float* g, const void* mask, long n, float* out, float* ws, void* stream);
 int bra_adamw(float* p, const float* g, float* m, float* v, const void* mask, long n, float lr, float b1, float b2,
               float eps, float wd, int step, const float* sumsq, float max_norm, float grad_scale, void* stream);
 
