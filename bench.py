@@ -102,6 +102,16 @@ def cpu_baseline(max_seconds: float = 60.0):
                       f"policy fwd+bwd {t_pol:.1f}s; model build {build_s:.0f}s not counted"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (counters cannot be read from
+    inside the timed process); None when the summary is absent"""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c_pmc_gemm.json")) as fh:
+            return float(json.load(fh)["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def decode_roofline(model, rollout_profile, C):
     """HBM roofline of the rollout's token loop (the largest phase of the step; every kernel in it is a weight / KV
     stream): algorithmic bytes of one decode step = merged bf16 projection weights + tied lm_head + the K/V rows the
@@ -203,7 +213,10 @@ def main():
                                    "ref logps + policy fwd/bwd + AdamW; random-init weights" % args.completion_len,
                        "global_batch": world * G, "prompt_len": 2180, "completion_len": args.completion_len, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": prof["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": prof["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": prof["tflops"] / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(),
+                         "traffic_note": "HBM-side bytes per launch, rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + "
+                                         "WRITE_SIZE), collected offline: profiles/r1_c_pmc_gemm.json",
+                         "flops_per_launch": prof["flops_per_launch"], "algorithmic_bytes_per_launch": prof["bytes_per_launch"],
                          "kernel": "gemm_glds_kernel<*, 1> (256x128 LDS-DMA tiles: every projection / lm_head GEMM of the "
                                    "prefill, ref, policy forward and backward passes that fills the chip)",
                          "launches": prof["launches"], "avg_launch_ms": prof["avg_launch_ms"]},

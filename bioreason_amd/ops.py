@@ -73,7 +73,9 @@ def gemm_nt(
     if timed:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.records.append((2.0 * M * N * K, e0, e1))
+        # flops and algorithmic bytes (every operand once: A, B, LoRA pair, residual, output)
+        nbytes = 2.0 * (M * K + N * K + (M + N) * K2 + (M * N if res is not None else 0)) + M * N * (4.0 if out_f32 else 2.0)
+        prof.records.append((2.0 * M * N * (K + K2), e0, e1, nbytes))
     return out
 
 
@@ -98,7 +100,9 @@ class GemmProfile:
         fl = sum(r[0] for r in self.records)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
         n = len(self.records)
-        return {"launches": n, "flops": fl, "ms": ms, "avg_launch_ms": ms / max(n, 1), "tflops": fl / max(ms, 1e-9) / 1e9}
+        by = sum(r[3] for r in self.records)
+        return {"launches": n, "flops": fl, "ms": ms, "avg_launch_ms": ms / max(n, 1), "tflops": fl / max(ms, 1e-9) / 1e9,
+                "flops_per_launch": fl / max(n, 1), "bytes_per_launch": by / max(n, 1)}
 
 
 GEMM_PROFILE: Optional[GemmProfile] = None
