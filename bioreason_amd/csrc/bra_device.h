@@ -235,6 +235,20 @@ __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfi
 #endif
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+// returns x but hides its origin from the compiler: address arithmetic built on it cannot be hoisted out of a loop
+// (hipcc otherwise computes every lane-constant address at kernel entry and spills it around the tile loop)
+#ifdef BRA_EMU
+__device__ __forceinline__ int opaque_i(int x) { return x; }
+#else
+__device__ __forceinline__ int opaque_i(int x) { asm volatile("" : "+v"(x)); return x; }
+#endif
+// 2^x as the bare hardware instruction (v_exp_f32): no denormal rescue; softmax arguments are <= 0 and anything below
+// 2^-126 is zero for a probability that is about to be rounded to bf16
+#ifdef BRA_EMU
+__device__ __forceinline__ float fast_exp2(float x) { return exp2f(x); }
+#else
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
 // makes `v` opaque to the compiler at this point: nothing computed from it can be scheduled (or hoisted) above
 #ifdef BRA_EMU
 __device__ __forceinline__ void reg_fence(f32x4&) {}

@@ -133,13 +133,15 @@ __device__ __forceinline__ uint64_t key_valid_word(const AttnArgs& a, int b, int
 
 // ---------------------------------------------------------------------------
 // forward
-template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+// NW waves per workgroup (32 queries each); 8 waves = 2 per SIMD share one staged K / V^T tile
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
     using T = Tile<HD>;
+    constexpr int NT = NW * 64, QROWS = NW * 32;
     BRA_DYN_SMEM(smem);   // [2][K tile | V^T tile]
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int b = (int)blockIdx.z, hq = (int)blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
-    const int q0 = (int)blockIdx.x * 128;
+    const int q0 = (int)blockIdx.x * QROWS;
     const int qw0 = q0 + wave * 32;
     const int qi = qw0 + (lane & 31);                 // this lane's query
     const bf16_t* kb_ = a.k + b * a.k_sb + hkv * a.k_sh;
@@ -163,28 +165,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
     int kv_end = a.Sk;
     if (a.causal) {
-        int last = q0 + 127 + a.q_off + 1;
+        int last = q0 + QROWS - 1 + a.q_off + 1;
         kv_end = last < kv_end ? last : kv_end;
     }
     const int ntile = kv_end > 0 ? (kv_end + 63) / 64 : 0;
 
-    u32x4 rk[(64 * T::CH) / 256], rv[(HD * 8) / 256];
+    u32x4 rk[(64 * T::CH) / NT], rv[(HD * 8) / NT];
     if (ntile > 0) {
-        load_rows<HD, 256>(rk, kb_, a.k_ss, 0, a.Sk, tid);
-        load_trans<HD, 256>(rv, vtb, a.vt_sd, 0, tid);
-        store_rows<HD, 256>(smem, rk, tid);
-        store_trans<HD, 256>(smem + T::KBYTES, rv, tid);
+        load_rows<HD, NT>(rk, kb_, a.k_ss, 0, a.Sk, tid);
+        load_trans<HD, NT>(rv, vtb, a.vt_sd, 0, tid);
+        store_rows<HD, NT>(smem, rk, tid);
+        store_trans<HD, NT>(smem + T::KBYTES, rv, tid);
     }
     __syncthreads();
 
     for (int t = 0; t < ntile; ++t) {
         const int kv0 = t * 64;
+        const int tl = opaque_i(tid), ll = opaque_i(lane);      // per-iteration copies: keeps address math out of registers across the loop
         const char* sk = smem + (t & 1) * (T::KBYTES + T::TBYTES);
         const char* sv = sk + T::KBYTES;
         const bool more = t + 1 < ntile;
         if (more) {
-            load_rows<HD, 256>(rk, kb_, a.k_ss, kv0 + 64, a.Sk, tid);
-            load_trans<HD, 256>(rv, vtb, a.vt_sd, kv0 + 64, tid);
+            load_rows<HD, NT>(rk, kb_, a.k_ss, kv0 + 64, a.Sk, tl);
+            load_trans<HD, NT>(rv, vtb, a.vt_sd, kv0 + 64, tl);
         }
         const uint64_t valid = key_valid_word(a, b, kv0, lane);
         // wave-uniform skip: every key of this tile is after every query of this wave
@@ -197,40 +200,65 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
 #pragma unroll
                 for (int ds = 0; ds < T::DS; ++ds)
-                    st[kb] = mfma_32x32x16(frag_rows<HD>(sk, kb * 32, ds, lane), qf[ds], st[kb]);
+                    st[kb] = mfma_32x32x16(frag_rows<HD>(sk, kb * 32, ds, ll), qf[ds], st[kb]);
+                sched_fence();            // bounds how many fragment reads the scheduler keeps in flight (registers)
             }
-            // scale + mask, tile max
+            // tile max, probabilities, running statistics.  `full` (wave-uniform): every key of the tile is valid and
+            // visible to every query of this wave, so the per-element mask logic (most of the VALU work of a masked
+            // tile) is skipped; only diagonal tiles and tiles holding padded keys take the masked path.
+            const bool full = valid == ~0ull && (!a.causal || kv0 + 63 <= qw0 + a.q_off);
             float mx = kNeg;
+            if (full) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kl = kb * 32 + crow(r, h);
-                    bool ok = (valid >> kl) & 1ull;
-                    if (a.causal) ok = ok && (kv0 + kl <= qi + a.q_off);
-                    float s = ok ? st[kb][r] * sc : kNeg;
-                    st[kb][r] = s;
-                    mx = fmaxf(mx, s);
-                }
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+                mx *= sc;                                   // sc > 0: max(s) * sc == max(s * sc)
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kl = kb * 32 + crow(r, h);
+                        bool ok = (valid >> kl) & 1ull;
+                        if (a.causal) ok = ok && (kv0 + kl <= qi + a.q_off);
+                        float s = ok ? st[kb][r] * sc : kNeg;
+                        st[kb][r] = s;
+                        mx = fmaxf(mx, s);
+                    }
+            }
             mx = fmaxf(mx, wave_shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f(m_run - m_new);
+            const float alpha = fast_exp2(m_run - m_new);
             float rs = 0.f;
+            if (full) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float p = st[kb][r] > 0.5f * kNeg ? exp2f(st[kb][r] - m_new) : 0.f;
-                    st[kb][r] = p;
-                    rs += p;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = fast_exp2(fmaf(st[kb][r], sc, -m_new));
+                        st[kb][r] = p;
+                        rs += p;
+                    }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float p = st[kb][r] > 0.5f * kNeg ? fast_exp2(st[kb][r] - m_new) : 0.f;
+                        st[kb][r] = p;
+                        rs += p;
+                    }
+            }
             rs += wave_shfl_xor(rs, 32);
             l_run = l_run * alpha + rs;
             m_run = m_new;
+            if (wave_ballot(alpha != 1.f) != 0ull) {        // the running max moved for some query of this wave
 #pragma unroll
-            for (int i = 0; i < T::DB; ++i)
+                for (int i = 0; i < T::DB; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            }
             // O^T += V^T . P^T
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -242,13 +270,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 pf.w = pack_bf2(st[kb][r0 + 6], st[kb][r0 + 7]);
 #pragma unroll
                 for (int db = 0; db < T::DB; ++db)
-                    o[db] = mfma_32x32x16(frag_trans<HD>(sv, db * 32, s, lane), pf, o[db]);
+                    o[db] = mfma_32x32x16(frag_trans<HD>(sv, db * 32, s, ll), pf, o[db]);
+                sched_fence();
             }
         }
         if (more) {
             char* nk = smem + ((t + 1) & 1) * (T::KBYTES + T::TBYTES);
-            store_rows<HD, 256>(nk, rk, tid);
-            store_trans<HD, 256>(nk + T::KBYTES, rv, tid);
+            store_rows<HD, NT>(nk, rk, tl);
+            store_trans<HD, NT>(nk + T::KBYTES, rv, tl);
         }
         __syncthreads();
     }
@@ -274,14 +303,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // backward, dQ:   one workgroup = 128 queries of one (batch, q-head); loops over key tiles.
 //   S^T = K Q^T, dP^T = V dO^T (both [key][q], query on lanes), dS^T = P^T * (dP^T - delta[q]) * scale
 //   dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs a) {
     using T = Tile<HD>;
+    constexpr int NT = NW * 64, QROWS = NW * 32;
     BRA_DYN_SMEM(smem);   // [2][K tile | V tile | K^T tile]
     constexpr int STAGE = 2 * T::KBYTES + T::TBYTES;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int b = (int)blockIdx.z, hq = (int)blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
-    const int q0 = (int)blockIdx.x * 128;
+    const int q0 = (int)blockIdx.x * QROWS;
     const int qw0 = q0 + wave * 32;
     const int qi = qw0 + (lane & 31);
     const int qr = qi < a.Sq ? qi : a.Sq - 1;
@@ -308,30 +338,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
     int kv_end = a.Sk;
-    if (a.causal) { int last = q0 + 127 + a.q_off + 1; kv_end = last < kv_end ? last : kv_end; }
+    if (a.causal) { int last = q0 + QROWS - 1 + a.q_off + 1; kv_end = last < kv_end ? last : kv_end; }
     const int ntile = kv_end > 0 ? (kv_end + 63) / 64 : 0;
 
-    u32x4 rk[(64 * T::CH) / 256], rv[(64 * T::CH) / 256], rt[(HD * 8) / 256];
+    u32x4 rk[(64 * T::CH) / NT], rv[(64 * T::CH) / NT], rt[(HD * 8) / NT];
     if (ntile > 0) {
-        load_rows<HD, 256>(rk, kb_, a.k_ss, 0, a.Sk, tid);
-        load_rows<HD, 256>(rv, vb_, a.v_ss, 0, a.Sk, tid);
-        load_trans<HD, 256>(rt, ktb, a.kt_sd, 0, tid);
-        store_rows<HD, 256>(smem, rk, tid);
-        store_rows<HD, 256>(smem + T::KBYTES, rv, tid);
-        store_trans<HD, 256>(smem + 2 * T::KBYTES, rt, tid);
+        load_rows<HD, NT>(rk, kb_, a.k_ss, 0, a.Sk, tid);
+        load_rows<HD, NT>(rv, vb_, a.v_ss, 0, a.Sk, tid);
+        load_trans<HD, NT>(rt, ktb, a.kt_sd, 0, tid);
+        store_rows<HD, NT>(smem, rk, tid);
+        store_rows<HD, NT>(smem + T::KBYTES, rv, tid);
+        store_trans<HD, NT>(smem + 2 * T::KBYTES, rt, tid);
     }
     __syncthreads();
 
     for (int t = 0; t < ntile; ++t) {
         const int kv0 = t * 64;
+        const int tl = opaque_i(tid), ll = opaque_i(lane);      // see forward
         const char* sk = smem + (t & 1) * STAGE;
         const char* sv = sk + T::KBYTES;
         const char* skt = sk + 2 * T::KBYTES;
         const bool more = t + 1 < ntile;
         if (more) {
-            load_rows<HD, 256>(rk, kb_, a.k_ss, kv0 + 64, a.Sk, tid);
-            load_rows<HD, 256>(rv, vb_, a.v_ss, kv0 + 64, a.Sk, tid);
-            load_trans<HD, 256>(rt, ktb, a.kt_sd, kv0 + 64, tid);
+            load_rows<HD, NT>(rk, kb_, a.k_ss, kv0 + 64, a.Sk, tl);
+            load_rows<HD, NT>(rv, vb_, a.v_ss, kv0 + 64, a.Sk, tl);
+            load_trans<HD, NT>(rt, ktb, a.kt_sd, kv0 + 64, tl);
         }
         const uint64_t valid = key_valid_word(a, b, kv0, lane);
         const bool skip = a.causal && (kv0 > qw0 + 31 + a.q_off);
@@ -343,20 +374,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = 0.f; }
 #pragma unroll
                 for (int ds = 0; ds < T::DS; ++ds) {
-                    st[kb] = mfma_32x32x16(frag_rows<HD>(sk, kb * 32, ds, lane), qf[ds], st[kb]);
-                    dp[kb] = mfma_32x32x16(frag_rows<HD>(sv, kb * 32, ds, lane), dof[ds], dp[kb]);
+                    st[kb] = mfma_32x32x16(frag_rows<HD>(sk, kb * 32, ds, ll), qf[ds], st[kb]);
+                    dp[kb] = mfma_32x32x16(frag_rows<HD>(sv, kb * 32, ds, ll), dof[ds], dp[kb]);
+                    if (ds == T::DS / 2 - 1) sched_fence();
                 }
+                sched_fence();
             }
+            const bool full = valid == ~0ull && (!a.causal || kv0 + 63 <= qw0 + a.q_off);   // wave-uniform, see forward
+            if (full) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kl = kb * 32 + crow(r, h);
-                    bool ok = (valid >> kl) & 1ull;
-                    if (a.causal) ok = ok && (kv0 + kl <= qi + a.q_off);
-                    const float p = ok ? exp2f(st[kb][r] * sc - lse2) : 0.f;
-                    st[kb][r] = p * (dp[kb][r] - dlt) * a.scale;   // dS^T
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = fast_exp2(fmaf(st[kb][r], sc, -lse2));
+                        st[kb][r] = p * (dp[kb][r] - dlt) * a.scale;   // dS^T
+                    }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kl = kb * 32 + crow(r, h);
+                        bool ok = (valid >> kl) & 1ull;
+                        if (a.causal) ok = ok && (kv0 + kl <= qi + a.q_off);
+                        const float p = ok ? fast_exp2(st[kb][r] * sc - lse2) : 0.f;
+                        st[kb][r] = p * (dp[kb][r] - dlt) * a.scale;   // dS^T
+                    }
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int kb = s >> 1, r0 = 8 * (s & 1);
@@ -367,14 +411,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 sf.w = pack_bf2(st[kb][r0 + 6], st[kb][r0 + 7]);
 #pragma unroll
                 for (int db = 0; db < T::DB; ++db)
-                    dq[db] = mfma_32x32x16(frag_trans<HD>(skt, db * 32, s, lane), sf, dq[db]);
+                    dq[db] = mfma_32x32x16(frag_trans<HD>(skt, db * 32, s, ll), sf, dq[db]);
+                sched_fence();
             }
         }
         if (more) {
             char* nk = smem + ((t + 1) & 1) * STAGE;
-            store_rows<HD, 256>(nk, rk, tid);
-            store_rows<HD, 256>(nk + T::KBYTES, rv, tid);
-            store_trans<HD, 256>(nk + 2 * T::KBYTES, rt, tid);
+            store_rows<HD, NT>(nk, rk, tl);
+            store_rows<HD, NT>(nk + T::KBYTES, rv, tl);
+            store_trans<HD, NT>(nk + 2 * T::KBYTES, rt, tl);
         }
         __syncthreads();
     }
@@ -397,11 +442,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 // q-heads and over query tiles (so GQA's sum over the group needs no atomics).
 //   S[q][key] = Q K^T, dP[q][key] = dO V^T  (key on lanes, query on registers)
 //   dV^T[d][key] += dO^T[d][q] . P[q][key]      dK^T[d][key] += Q^T[d][q] . dS[q][key]
-template <int HD>
+// WHICH: 0 = dK and dV in one pass (hd <= 64), 1 = dV only, 2 = dK only.  At hd = 128 the two accumulator sets plus
+// both score tiles exceed the register file (the one-pass form spills, and a spill reload drains the tile prefetch),
+// so the work is split into two launches that each recompute S; every tile a variant does not need is neither
+// loaded nor staged.
+template <int HD, int WHICH>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     using T = Tile<HD>;
-    BRA_DYN_SMEM(smem);   // [2][Q tile | dO tile | Q^T tile | dO^T tile | lse(64) delta(64)]
-    constexpr int STAGE = 2 * T::KBYTES + 2 * T::TBYTES + 512;
+    constexpr bool DV = WHICH != 2, DK = WHICH != 1;
+    BRA_DYN_SMEM(smem);   // [2][Q tile | dO tile (DK) | Q^T tile (DK) | dO^T tile (DV) | lse(64) delta(64)]
+    constexpr int OFF_D = T::KBYTES;
+    constexpr int OFF_QT = OFF_D + (DK ? T::KBYTES : 0);
+    constexpr int OFF_DT = OFF_QT + (DK ? T::TBYTES : 0);
+    constexpr int OFF_L = OFF_DT + (DV ? T::TBYTES : 0);
+    constexpr int STAGE = OFF_L + 512;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int b = (int)blockIdx.z, hkv = (int)blockIdx.y;
     const int group = a.Hq / a.Hkv;
@@ -411,19 +465,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int kr = kj < a.Sk ? kj : a.Sk - 1;
     bool kvalid = kj < a.Sk;
     if (kvalid && a.kmask) kvalid = a.kmask[(long)b * a.Sk + kj] != 0;
+    const bool all_valid = wave_ballot(kvalid) == ~0ull;
 
-    u32x4 kf[T::DS], vf[T::DS];
+    u32x4 kf[T::DS], vf[DK ? T::DS : 1];
     {
         const bf16_t* kp = a.k + b * a.k_sb + (long)kr * a.k_ss + hkv * a.k_sh;
         const bf16_t* vp = a.v + b * a.v_sb + (long)kr * a.v_ss + hkv * a.v_sh;
 #pragma unroll
-        for (int ds = 0; ds < T::DS; ++ds) { kf[ds] = ld16(kp + ds * 16 + 8 * h); vf[ds] = ld16(vp + ds * 16 + 8 * h); }
+        for (int ds = 0; ds < T::DS; ++ds) {
+            kf[ds] = ld16(kp + ds * 16 + 8 * h);
+            if (DK) vf[ds] = ld16(vp + ds * 16 + 8 * h);
+        }
     }
-    f32x16 dk[T::DB], dv[T::DB];
+    f32x16 dk[DK ? T::DB : 1], dv[DV ? T::DB : 1];
 #pragma unroll
     for (int i = 0; i < T::DB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { if (DK) dk[i][r] = 0.f; if (DV) dv[i][r] = 0.f; }
     const float sc = a.scale * kLog2e;
 
     // first query tile that can see any key of this workgroup
@@ -433,15 +491,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int per_head = qt_end > qt_begin ? qt_end - qt_begin : 0;
     const int nit = per_head * group;
 
-    u32x4 rq[(64 * T::CH) / 256], rd[(64 * T::CH) / 256], rqt[(HD * 8) / 256], rdt[(HD * 8) / 256];
+    u32x4 rq[(64 * T::CH) / 256], rd[DK ? (64 * T::CH) / 256 : 1], rqt[DK ? (HD * 8) / 256 : 1], rdt[DV ? (HD * 8) / 256 : 1];
     float rl = 0.f;   // threads 0..63: lse, 64..127: delta
-    auto issue = [&](int it) {
+    auto issue = [&](int it, int tid) {
         const int hq = hkv * group + it / per_head;
         const int s0 = (qt_begin + it % per_head) * 64;
         load_rows<HD, 256>(rq, a.q + b * a.q_sb + hq * a.q_sh, a.q_ss, s0, a.Sq, tid);
-        load_rows<HD, 256>(rd, a.dout + b * a.do_sb + hq * a.do_sh, a.do_ss, s0, a.Sq, tid);
-        load_trans<HD, 256>(rqt, a.qt + b * a.qt_sb + hq * a.qt_sh, a.qt_sd, s0, tid);
-        load_trans<HD, 256>(rdt, a.dot + b * a.dot_sb + hq * a.dot_sh, a.dot_sd, s0, tid);
+        if constexpr (DK) {
+            load_rows<HD, 256>(rd, a.dout + b * a.do_sb + hq * a.do_sh, a.do_ss, s0, a.Sq, tid);
+            load_trans<HD, 256>(rqt, a.qt + b * a.qt_sb + hq * a.qt_sh, a.qt_sd, s0, tid);
+        }
+        if constexpr (DV) load_trans<HD, 256>(rdt, a.dot + b * a.dot_sb + hq * a.dot_sh, a.dot_sd, s0, tid);
         if (tid < 128) {
             int qq = s0 + (tid & 63);
             qq = qq < a.Sq ? qq : a.Sq - 1;
@@ -449,68 +509,89 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             rl = tid < 64 ? a.lse[li] * kLog2e : a.delta[li];
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, int tid) {
         char* s = smem + buf * STAGE;
         store_rows<HD, 256>(s, rq, tid);
-        store_rows<HD, 256>(s + T::KBYTES, rd, tid);
-        store_trans<HD, 256>(s + 2 * T::KBYTES, rqt, tid);
-        store_trans<HD, 256>(s + 2 * T::KBYTES + T::TBYTES, rdt, tid);
-        if (tid < 128) reinterpret_cast<float*>(s + 2 * T::KBYTES + 2 * T::TBYTES)[tid] = rl;
+        if constexpr (DK) {
+            store_rows<HD, 256>(s + OFF_D, rd, tid);
+            store_trans<HD, 256>(s + OFF_QT, rqt, tid);
+        }
+        if constexpr (DV) store_trans<HD, 256>(s + OFF_DT, rdt, tid);
+        if (tid < 128) reinterpret_cast<float*>(s + OFF_L)[tid] = rl;
     };
-    if (nit > 0) { issue(0); commit(0); }
+    if (nit > 0) { issue(0, tid); commit(0, tid); }
     __syncthreads();
 
     for (int it = 0; it < nit; ++it) {
         const int s0 = (qt_begin + it % per_head) * 64;
         const char* sq = smem + (it & 1) * STAGE;
-        const char* sd = sq + T::KBYTES;
-        const char* sqt = sq + 2 * T::KBYTES;
-        const char* sdt = sqt + T::TBYTES;
-        const float* sl = reinterpret_cast<const float*>(sdt + T::TBYTES);
+        const char* sd = sq + OFF_D;
+        const char* sqt = sq + OFF_QT;
+        const char* sdt = sq + OFF_DT;
+        const float* sl = reinterpret_cast<const float*>(sq + OFF_L);
         const bool more = it + 1 < nit;
-        if (more) issue(it + 1);
+        const int tl = opaque_i(tid), ll = opaque_i(lane);      // see forward
+        if (more) issue(it + 1, tl);
         // wave-uniform skip: every query of this tile is before every key of this wave
         const bool skip = a.causal && (s0 + 63 + a.q_off < kw0);
         if (!skip) {
-            f32x16 st[2], dp[2];
+            f32x16 st[2], dp[DK ? 2 : 1];
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { st[qb][r] = 0.f; dp[qb][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { st[qb][r] = 0.f; if (DK) dp[qb][r] = 0.f; }
 #pragma unroll
                 for (int ds = 0; ds < T::DS; ++ds) {
-                    st[qb] = mfma_32x32x16(frag_rows<HD>(sq, qb * 32, ds, lane), kf[ds], st[qb]);
-                    dp[qb] = mfma_32x32x16(frag_rows<HD>(sd, qb * 32, ds, lane), vf[ds], dp[qb]);
+                    st[qb] = mfma_32x32x16(frag_rows<HD>(sq, qb * 32, ds, ll), kf[ds], st[qb]);
+                    if constexpr (DK) dp[qb] = mfma_32x32x16(frag_rows<HD>(sd, qb * 32, ds, ll), vf[ds], dp[qb]);
                 }
             }
+            // wave-uniform: all 32 keys of this wave valid and visible to all 64 queries of the tile
+            const bool full = all_valid && s0 + 63 < a.Sq && (!a.causal || kw0 + 31 <= s0 + a.q_off);
+            if (full) {
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
+                for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = qb * 32 + crow(r, h);
-                    const int qi = s0 + ql;
-                    bool ok = kvalid && qi < a.Sq;
-                    if (a.causal) ok = ok && (kj <= qi + a.q_off);
-                    const float p = ok ? exp2f(st[qb][r] * sc - sl[ql]) : 0.f;
-                    st[qb][r] = p;                                              // P
-                    dp[qb][r] = p * (dp[qb][r] - sl[64 + ql]) * a.scale;         // dS
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int ql = qb * 32 + crow(r, h);
+                        const float p = fast_exp2(fmaf(st[qb][r], sc, -sl[ql]));
+                        st[qb][r] = p;                                                       // P
+                        if constexpr (DK) dp[qb][r] = p * (dp[qb][r] - sl[64 + ql]) * a.scale;   // dS
+                    }
+            } else {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ql = qb * 32 + crow(r, h);
+                        const int qi = s0 + ql;
+                        bool ok = kvalid && qi < a.Sq;
+                        if (a.causal) ok = ok && (kj <= qi + a.q_off);
+                        const float p = ok ? fast_exp2(st[qb][r] * sc - sl[ql]) : 0.f;
+                        st[qb][r] = p;                                                       // P
+                        if constexpr (DK) dp[qb][r] = p * (dp[qb][r] - sl[64 + ql]) * a.scale;   // dS
+                    }
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int qb = s >> 1, r0 = 8 * (s & 1);
-                u32x4 pf, sf;
-                pf.x = pack_bf2(st[qb][r0 + 0], st[qb][r0 + 1]); pf.y = pack_bf2(st[qb][r0 + 2], st[qb][r0 + 3]);
-                pf.z = pack_bf2(st[qb][r0 + 4], st[qb][r0 + 5]); pf.w = pack_bf2(st[qb][r0 + 6], st[qb][r0 + 7]);
-                sf.x = pack_bf2(dp[qb][r0 + 0], dp[qb][r0 + 1]); sf.y = pack_bf2(dp[qb][r0 + 2], dp[qb][r0 + 3]);
-                sf.z = pack_bf2(dp[qb][r0 + 4], dp[qb][r0 + 5]); sf.w = pack_bf2(dp[qb][r0 + 6], dp[qb][r0 + 7]);
+                if constexpr (DV) {
+                    u32x4 pf;
+                    pf.x = pack_bf2(st[qb][r0 + 0], st[qb][r0 + 1]); pf.y = pack_bf2(st[qb][r0 + 2], st[qb][r0 + 3]);
+                    pf.z = pack_bf2(st[qb][r0 + 4], st[qb][r0 + 5]); pf.w = pack_bf2(st[qb][r0 + 6], st[qb][r0 + 7]);
 #pragma unroll
-                for (int db = 0; db < T::DB; ++db) {
-                    dv[db] = mfma_32x32x16(frag_trans<HD>(sdt, db * 32, s, lane), pf, dv[db]);
-                    dk[db] = mfma_32x32x16(frag_trans<HD>(sqt, db * 32, s, lane), sf, dk[db]);
+                    for (int db = 0; db < T::DB; ++db) dv[db] = mfma_32x32x16(frag_trans<HD>(sdt, db * 32, s, ll), pf, dv[db]);
+                }
+                if constexpr (DK) {
+                    u32x4 sf;
+                    sf.x = pack_bf2(dp[qb][r0 + 0], dp[qb][r0 + 1]); sf.y = pack_bf2(dp[qb][r0 + 2], dp[qb][r0 + 3]);
+                    sf.z = pack_bf2(dp[qb][r0 + 4], dp[qb][r0 + 5]); sf.w = pack_bf2(dp[qb][r0 + 6], dp[qb][r0 + 7]);
+#pragma unroll
+                    for (int db = 0; db < T::DB; ++db) dk[db] = mfma_32x32x16(frag_trans<HD>(sqt, db * 32, s, ll), sf, dk[db]);
                 }
             }
         }
-        if (more) commit((it + 1) & 1);
+        if (more) commit((it + 1) & 1, tl);
         __syncthreads();
     }
     if (kj < a.Sk) {
@@ -521,12 +602,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2 w;
-                w.x = pack_bf2(dk[db][4 * g + 0], dk[db][4 * g + 1]);
-                w.y = pack_bf2(dk[db][4 * g + 2], dk[db][4 * g + 3]);
-                st8(kp + db * 32 + 8 * g + 4 * h, w);
-                w.x = pack_bf2(dv[db][4 * g + 0], dv[db][4 * g + 1]);
-                w.y = pack_bf2(dv[db][4 * g + 2], dv[db][4 * g + 3]);
-                st8(vp + db * 32 + 8 * g + 4 * h, w);
+                if constexpr (DK) {
+                    w.x = pack_bf2(dk[db][4 * g + 0], dk[db][4 * g + 1]);
+                    w.y = pack_bf2(dk[db][4 * g + 2], dk[db][4 * g + 3]);
+                    st8(kp + db * 32 + 8 * g + 4 * h, w);
+                }
+                if constexpr (DV) {
+                    w.x = pack_bf2(dv[db][4 * g + 0], dv[db][4 * g + 1]);
+                    w.y = pack_bf2(dv[db][4 * g + 2], dv[db][4 * g + 3]);
+                    st8(vp + db * 32 + 8 * g + 4 * h, w);
+                }
             }
     }
 }
@@ -710,23 +795,40 @@ using namespace bra;
 template <int HD>
 static int launch_fwd(const AttnArgs& a, bra_stream_t st) {
     const size_t smem = 2 * (Tile<HD>::KBYTES + Tile<HD>::TBYTES);
-    BRA_ALLOW_SMEM((attn_fwd_kernel<HD>), smem);
-    BRA_LAUNCH((attn_fwd_kernel<HD>), dim3((a.Sq + 127) / 128, a.Hq, a.B), dim3(256), smem, st, a);
+    if (HD >= 64 && a.Sq > 128) {
+        BRA_ALLOW_SMEM((attn_fwd_kernel<HD, (HD >= 64 ? 8 : 4)>), smem);
+        BRA_LAUNCH((attn_fwd_kernel<HD, (HD >= 64 ? 8 : 4)>), dim3((a.Sq + 255) / 256, a.Hq, a.B), dim3(512), smem, st, a);
+        return BRA_LAUNCH_STATUS();
+    }
+    BRA_ALLOW_SMEM((attn_fwd_kernel<HD, 4>), smem);
+    BRA_LAUNCH((attn_fwd_kernel<HD, 4>), dim3((a.Sq + 127) / 128, a.Hq, a.B), dim3(256), smem, st, a);
     return BRA_LAUNCH_STATUS();
 }
 template <int HD>
 static int launch_dq(const AttnArgs& a, bra_stream_t st) {
     const size_t smem = 2 * (2 * Tile<HD>::KBYTES + Tile<HD>::TBYTES);
-    BRA_ALLOW_SMEM((attn_bwd_dq_kernel<HD>), smem);
-    BRA_LAUNCH((attn_bwd_dq_kernel<HD>), dim3((a.Sq + 127) / 128, a.Hq, a.B), dim3(256), smem, st, a);
+    if (HD == 64 && a.Sq > 128) {       // hd 128: two accumulator sets + operands need more than the 256 registers of 2 waves / SIMD
+        BRA_ALLOW_SMEM((attn_bwd_dq_kernel<HD, (HD == 64 ? 8 : 4)>), smem);
+        BRA_LAUNCH((attn_bwd_dq_kernel<HD, (HD == 64 ? 8 : 4)>), dim3((a.Sq + 255) / 256, a.Hq, a.B), dim3(512), smem, st, a);
+    } else {
+        BRA_ALLOW_SMEM((attn_bwd_dq_kernel<HD, 4>), smem);
+        BRA_LAUNCH((attn_bwd_dq_kernel<HD, 4>), dim3((a.Sq + 127) / 128, a.Hq, a.B), dim3(256), smem, st, a);
+    }
+    return BRA_LAUNCH_STATUS();
+}
+template <int HD, int WHICH>
+static int launch_dkv_v(const AttnArgs& a, bra_stream_t st) {
+    constexpr bool DV = WHICH != 2, DK = WHICH != 1;
+    const size_t smem = 2 * (Tile<HD>::KBYTES + (DK ? Tile<HD>::KBYTES + Tile<HD>::TBYTES : 0) + (DV ? Tile<HD>::TBYTES : 0) + 512);
+    BRA_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, WHICH>), smem);
+    BRA_LAUNCH((attn_bwd_dkv_kernel<HD, WHICH>), dim3((a.Sk + 127) / 128, a.Hkv, a.B), dim3(256), smem, st, a);
     return BRA_LAUNCH_STATUS();
 }
 template <int HD>
 static int launch_dkv(const AttnArgs& a, bra_stream_t st) {
-    const size_t smem = 2 * (2 * Tile<HD>::KBYTES + 2 * Tile<HD>::TBYTES + 512);
-    BRA_ALLOW_SMEM((attn_bwd_dkv_kernel<HD>), smem);
-    BRA_LAUNCH((attn_bwd_dkv_kernel<HD>), dim3((a.Sk + 127) / 128, a.Hkv, a.B), dim3(256), smem, st, a);
-    return BRA_LAUNCH_STATUS();
+    if (HD < 128) return launch_dkv_v<HD, 0>(a, st);
+    int rc = launch_dkv_v<HD, 1>(a, st);
+    return rc ? rc : launch_dkv_v<HD, 2>(a, st);
 }
 
 static int attn_check(int B, int Hq, int Hkv, int Sq, int Sk, int hd) {
