@@ -367,51 +367,46 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs a) {
         const uint64_t valid = key_valid_word(a, b, kv0, lane);
         const bool skip = a.causal && (kv0 > qw0 + 31 + a.q_off);
         if (!skip) {
-            f32x16 st[2], dp[2];
+            const bool full = valid == ~0ull && (!a.causal || kv0 + 63 <= qw0 + a.q_off);   // wave-uniform, see forward
+            // one 32-key half at a time (scores, dS, its dQ contribution): halves the live score registers
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
+                f32x16 st, dp;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
                 for (int ds = 0; ds < T::DS; ++ds) {
-                    st[kb] = mfma_32x32x16(frag_rows<HD>(sk, kb * 32, ds, ll), qf[ds], st[kb]);
-                    dp[kb] = mfma_32x32x16(frag_rows<HD>(sv, kb * 32, ds, ll), dof[ds], dp[kb]);
-                    if (ds == T::DS / 2 - 1) sched_fence();
+                    st = mfma_32x32x16(frag_rows<HD>(sk, kb * 32, ds, ll), qf[ds], st);
+                    dp = mfma_32x32x16(frag_rows<HD>(sv, kb * 32, ds, ll), dof[ds], dp);
                 }
-                sched_fence();
-            }
-            const bool full = valid == ~0ull && (!a.causal || kv0 + 63 <= qw0 + a.q_off);   // wave-uniform, see forward
-            if (full) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                if (full) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float p = fast_exp2(fmaf(st[kb][r], sc, -lse2));
-                        st[kb][r] = p * (dp[kb][r] - dlt) * a.scale;   // dS^T
+                        const float p = fast_exp2(fmaf(st[r], sc, -lse2));
+                        st[r] = p * (dp[r] - dlt) * a.scale;   // dS^T
                     }
-            } else {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int kl = kb * 32 + crow(r, h);
                         bool ok = (valid >> kl) & 1ull;
                         if (a.causal) ok = ok && (kv0 + kl <= qi + a.q_off);
-                        const float p = ok ? fast_exp2(st[kb][r] * sc - lse2) : 0.f;
-                        st[kb][r] = p * (dp[kb][r] - dlt) * a.scale;   // dS^T
+                        const float p = ok ? fast_exp2(st[r] * sc - lse2) : 0.f;
+                        st[r] = p * (dp[r] - dlt) * a.scale;   // dS^T
                     }
-            }
+                }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int kb = s >> 1, r0 = 8 * (s & 1);
-                u32x4 sf;
-                sf.x = pack_bf2(st[kb][r0 + 0], st[kb][r0 + 1]);
-                sf.y = pack_bf2(st[kb][r0 + 2], st[kb][r0 + 3]);
-                sf.z = pack_bf2(st[kb][r0 + 4], st[kb][r0 + 5]);
-                sf.w = pack_bf2(st[kb][r0 + 6], st[kb][r0 + 7]);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int r0 = 8 * s2;
+                    u32x4 sf;
+                    sf.x = pack_bf2(st[r0 + 0], st[r0 + 1]);
+                    sf.y = pack_bf2(st[r0 + 2], st[r0 + 3]);
+                    sf.z = pack_bf2(st[r0 + 4], st[r0 + 5]);
+                    sf.w = pack_bf2(st[r0 + 6], st[r0 + 7]);
 #pragma unroll
-                for (int db = 0; db < T::DB; ++db)
-                    dq[db] = mfma_32x32x16(frag_trans<HD>(skt, db * 32, s, ll), sf, dq[db]);
+                    for (int db = 0; db < T::DB; ++db)
+                        dq[db] = mfma_32x32x16(frag_trans<HD>(skt, db * 32, kb * 2 + s2, ll), sf, dq[db]);
+                }
                 sched_fence();
             }
         }
@@ -446,9 +441,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs a) {
 // both score tiles exceed the register file (the one-pass form spills, and a spill reload drains the tile prefetch),
 // so the work is split into two launches that each recompute S; every tile a variant does not need is neither
 // loaded nor staged.
-template <int HD, int WHICH>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+template <int HD, int WHICH, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs a) {
     using T = Tile<HD>;
+    constexpr int NT = NW * 64, KROWS = NW * 32;      // NW waves of 32 keys
     constexpr bool DV = WHICH != 2, DK = WHICH != 1;
     BRA_DYN_SMEM(smem);   // [2][Q tile | dO tile (DK) | Q^T tile (DK) | dO^T tile (DV) | lse(64) delta(64)]
     constexpr int OFF_D = T::KBYTES;
@@ -459,7 +455,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int b = (int)blockIdx.z, hkv = (int)blockIdx.y;
     const int group = a.Hq / a.Hkv;
-    const int k0 = (int)blockIdx.x * 128;
+    const int k0 = (int)blockIdx.x * KROWS;
     const int kw0 = k0 + wave * 32;
     const int kj = kw0 + (lane & 31);                 // this lane's key
     const int kr = kj < a.Sk ? kj : a.Sk - 1;
@@ -491,17 +487,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int per_head = qt_end > qt_begin ? qt_end - qt_begin : 0;
     const int nit = per_head * group;
 
-    u32x4 rq[(64 * T::CH) / 256], rd[DK ? (64 * T::CH) / 256 : 1], rqt[DK ? (HD * 8) / 256 : 1], rdt[DV ? (HD * 8) / 256 : 1];
+    u32x4 rq[(64 * T::CH) / NT], rd[DK ? (64 * T::CH) / NT : 1], rqt[DK ? (HD * 8) / NT : 1], rdt[DV ? (HD * 8) / NT : 1];
     float rl = 0.f;   // threads 0..63: lse, 64..127: delta
     auto issue = [&](int it, int tid) {
         const int hq = hkv * group + it / per_head;
         const int s0 = (qt_begin + it % per_head) * 64;
-        load_rows<HD, 256>(rq, a.q + b * a.q_sb + hq * a.q_sh, a.q_ss, s0, a.Sq, tid);
+        load_rows<HD, NT>(rq, a.q + b * a.q_sb + hq * a.q_sh, a.q_ss, s0, a.Sq, tid);
         if constexpr (DK) {
-            load_rows<HD, 256>(rd, a.dout + b * a.do_sb + hq * a.do_sh, a.do_ss, s0, a.Sq, tid);
-            load_trans<HD, 256>(rqt, a.qt + b * a.qt_sb + hq * a.qt_sh, a.qt_sd, s0, tid);
+            load_rows<HD, NT>(rd, a.dout + b * a.do_sb + hq * a.do_sh, a.do_ss, s0, a.Sq, tid);
+            load_trans<HD, NT>(rqt, a.qt + b * a.qt_sb + hq * a.qt_sh, a.qt_sd, s0, tid);
         }
-        if constexpr (DV) load_trans<HD, 256>(rdt, a.dot + b * a.dot_sb + hq * a.dot_sh, a.dot_sd, s0, tid);
+        if constexpr (DV) load_trans<HD, NT>(rdt, a.dot + b * a.dot_sb + hq * a.dot_sh, a.dot_sd, s0, tid);
         if (tid < 128) {
             int qq = s0 + (tid & 63);
             qq = qq < a.Sq ? qq : a.Sq - 1;
@@ -511,12 +507,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     };
     auto commit = [&](int buf, int tid) {
         char* s = smem + buf * STAGE;
-        store_rows<HD, 256>(s, rq, tid);
+        store_rows<HD, NT>(s, rq, tid);
         if constexpr (DK) {
-            store_rows<HD, 256>(s + OFF_D, rd, tid);
-            store_trans<HD, 256>(s + OFF_QT, rqt, tid);
+            store_rows<HD, NT>(s + OFF_D, rd, tid);
+            store_trans<HD, NT>(s + OFF_QT, rqt, tid);
         }
-        if constexpr (DV) store_trans<HD, 256>(s + OFF_DT, rdt, tid);
+        if constexpr (DV) store_trans<HD, NT>(s + OFF_DT, rdt, tid);
         if (tid < 128) reinterpret_cast<float*>(s + OFF_L)[tid] = rl;
     };
     if (nit > 0) { issue(0, tid); commit(0, tid); }
@@ -535,60 +531,58 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         // wave-uniform skip: every query of this tile is before every key of this wave
         const bool skip = a.causal && (s0 + 63 + a.q_off < kw0);
         if (!skip) {
-            f32x16 st[2], dp[DK ? 2 : 1];
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { st[qb][r] = 0.f; if (DK) dp[qb][r] = 0.f; }
-#pragma unroll
-                for (int ds = 0; ds < T::DS; ++ds) {
-                    st[qb] = mfma_32x32x16(frag_rows<HD>(sq, qb * 32, ds, ll), kf[ds], st[qb]);
-                    if constexpr (DK) dp[qb] = mfma_32x32x16(frag_rows<HD>(sd, qb * 32, ds, ll), vf[ds], dp[qb]);
-                }
-            }
             // wave-uniform: all 32 keys of this wave valid and visible to all 64 queries of the tile
             const bool full = all_valid && s0 + 63 < a.Sq && (!a.causal || kw0 + 31 <= s0 + a.q_off);
-            if (full) {
+            // one 32-query half at a time (scores, P / dS, its dV / dK contribution): halves the live score registers
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb)
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16 st, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ds = 0; ds < T::DS; ++ds) {
+                    st = mfma_32x32x16(frag_rows<HD>(sq, qb * 32, ds, ll), kf[ds], st);
+                    if constexpr (DK) dp = mfma_32x32x16(frag_rows<HD>(sd, qb * 32, ds, ll), vf[ds], dp);
+                }
+                if (full) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ql = qb * 32 + crow(r, h);
-                        const float p = fast_exp2(fmaf(st[qb][r], sc, -sl[ql]));
-                        st[qb][r] = p;                                                       // P
-                        if constexpr (DK) dp[qb][r] = p * (dp[qb][r] - sl[64 + ql]) * a.scale;   // dS
+                        const float p = fast_exp2(fmaf(st[r], sc, -sl[ql]));
+                        st[r] = p;                                                     // P
+                        if constexpr (DK) dp[r] = p * (dp[r] - sl[64 + ql]) * a.scale;   // dS
                     }
-            } else {
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb)
+                } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ql = qb * 32 + crow(r, h);
                         const int qi = s0 + ql;
                         bool ok = kvalid && qi < a.Sq;
                         if (a.causal) ok = ok && (kj <= qi + a.q_off);
-                        const float p = ok ? fast_exp2(st[qb][r] * sc - sl[ql]) : 0.f;
-                        st[qb][r] = p;                                                       // P
-                        if constexpr (DK) dp[qb][r] = p * (dp[qb][r] - sl[64 + ql]) * a.scale;   // dS
+                        const float p = ok ? fast_exp2(st[r] * sc - sl[ql]) : 0.f;
+                        st[r] = p;                                                     // P
+                        if constexpr (DK) dp[r] = p * (dp[r] - sl[64 + ql]) * a.scale;   // dS
                     }
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int qb = s >> 1, r0 = 8 * (s & 1);
-                if constexpr (DV) {
-                    u32x4 pf;
-                    pf.x = pack_bf2(st[qb][r0 + 0], st[qb][r0 + 1]); pf.y = pack_bf2(st[qb][r0 + 2], st[qb][r0 + 3]);
-                    pf.z = pack_bf2(st[qb][r0 + 4], st[qb][r0 + 5]); pf.w = pack_bf2(st[qb][r0 + 6], st[qb][r0 + 7]);
-#pragma unroll
-                    for (int db = 0; db < T::DB; ++db) dv[db] = mfma_32x32x16(frag_trans<HD>(sdt, db * 32, s, ll), pf, dv[db]);
                 }
-                if constexpr (DK) {
-                    u32x4 sf;
-                    sf.x = pack_bf2(dp[qb][r0 + 0], dp[qb][r0 + 1]); sf.y = pack_bf2(dp[qb][r0 + 2], dp[qb][r0 + 3]);
-                    sf.z = pack_bf2(dp[qb][r0 + 4], dp[qb][r0 + 5]); sf.w = pack_bf2(dp[qb][r0 + 6], dp[qb][r0 + 7]);
 #pragma unroll
-                    for (int db = 0; db < T::DB; ++db) dk[db] = mfma_32x32x16(frag_trans<HD>(sqt, db * 32, s, ll), sf, dk[db]);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int r0 = 8 * s2, s = qb * 2 + s2;
+                    if constexpr (DV) {
+                        u32x4 pf;
+                        pf.x = pack_bf2(st[r0 + 0], st[r0 + 1]); pf.y = pack_bf2(st[r0 + 2], st[r0 + 3]);
+                        pf.z = pack_bf2(st[r0 + 4], st[r0 + 5]); pf.w = pack_bf2(st[r0 + 6], st[r0 + 7]);
+#pragma unroll
+                        for (int db = 0; db < T::DB; ++db) dv[db] = mfma_32x32x16(frag_trans<HD>(sdt, db * 32, s, ll), pf, dv[db]);
+                    }
+                    if constexpr (DK) {
+                        u32x4 sf;
+                        sf.x = pack_bf2(dp[r0 + 0], dp[r0 + 1]); sf.y = pack_bf2(dp[r0 + 2], dp[r0 + 3]);
+                        sf.z = pack_bf2(dp[r0 + 4], dp[r0 + 5]); sf.w = pack_bf2(dp[r0 + 6], dp[r0 + 7]);
+#pragma unroll
+                        for (int db = 0; db < T::DB; ++db) dk[db] = mfma_32x32x16(frag_trans<HD>(sqt, db * 32, s, ll), sf, dk[db]);
+                    }
                 }
+                sched_fence();
             }
         }
         if (more) commit((it + 1) & 1, tl);
@@ -807,28 +801,33 @@ static int launch_fwd(const AttnArgs& a, bra_stream_t st) {
 template <int HD>
 static int launch_dq(const AttnArgs& a, bra_stream_t st) {
     const size_t smem = 2 * (2 * Tile<HD>::KBYTES + Tile<HD>::TBYTES);
-    if (HD == 64 && a.Sq > 128) {       // hd 128: two accumulator sets + operands need more than the 256 registers of 2 waves / SIMD
-        BRA_ALLOW_SMEM((attn_bwd_dq_kernel<HD, (HD == 64 ? 8 : 4)>), smem);
-        BRA_LAUNCH((attn_bwd_dq_kernel<HD, (HD == 64 ? 8 : 4)>), dim3((a.Sq + 255) / 256, a.Hq, a.B), dim3(512), smem, st, a);
+    if (HD >= 64 && a.Sq > 128) {
+        BRA_ALLOW_SMEM((attn_bwd_dq_kernel<HD, (HD >= 64 ? 8 : 4)>), smem);
+        BRA_LAUNCH((attn_bwd_dq_kernel<HD, (HD >= 64 ? 8 : 4)>), dim3((a.Sq + 255) / 256, a.Hq, a.B), dim3(512), smem, st, a);
     } else {
         BRA_ALLOW_SMEM((attn_bwd_dq_kernel<HD, 4>), smem);
         BRA_LAUNCH((attn_bwd_dq_kernel<HD, 4>), dim3((a.Sq + 127) / 128, a.Hq, a.B), dim3(256), smem, st, a);
     }
     return BRA_LAUNCH_STATUS();
 }
-template <int HD, int WHICH>
+template <int HD, int WHICH, int NW>
 static int launch_dkv_v(const AttnArgs& a, bra_stream_t st) {
     constexpr bool DV = WHICH != 2, DK = WHICH != 1;
     const size_t smem = 2 * (Tile<HD>::KBYTES + (DK ? Tile<HD>::KBYTES + Tile<HD>::TBYTES : 0) + (DV ? Tile<HD>::TBYTES : 0) + 512);
-    BRA_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, WHICH>), smem);
-    BRA_LAUNCH((attn_bwd_dkv_kernel<HD, WHICH>), dim3((a.Sk + 127) / 128, a.Hkv, a.B), dim3(256), smem, st, a);
+    BRA_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, WHICH, NW>), smem);
+    BRA_LAUNCH((attn_bwd_dkv_kernel<HD, WHICH, NW>), dim3((a.Sk + NW * 32 - 1) / (NW * 32), a.Hkv, a.B), dim3(NW * 64), smem, st, a);
     return BRA_LAUNCH_STATUS();
 }
 template <int HD>
 static int launch_dkv(const AttnArgs& a, bra_stream_t st) {
-    if (HD < 128) return launch_dkv_v<HD, 0>(a, st);
-    int rc = launch_dkv_v<HD, 1>(a, st);
-    return rc ? rc : launch_dkv_v<HD, 2>(a, st);
+    if (HD < 128) return launch_dkv_v<HD, 0, 4>(a, st);
+    constexpr int NW = HD >= 128 ? 8 : 4;              // 8 waves = 2 per SIMD share one staged query tile
+    if (a.Sk <= 128) {
+        int rc = launch_dkv_v<HD, 1, 4>(a, st);
+        return rc ? rc : launch_dkv_v<HD, 2, 4>(a, st);
+    }
+    int rc = launch_dkv_v<HD, 1, NW>(a, st);
+    return rc ? rc : launch_dkv_v<HD, 2, NW>(a, st);
 }
 
 static int attn_check(int B, int Hq, int Hkv, int Sq, int Sk, int hd) {

@@ -205,6 +205,8 @@ def _attn_ref(q, k, v, kmask, causal, scale, q_off):
     (64, 2, 2, 100, 100, False, "right"),
     (32, 2, 1, 70, 70, True, None),
     (128, 2, 1, 40, 200, True, "left"),      # chunked prefill against a longer key range
+    (128, 2, 2, 300, 300, False, None),      # 8-wave workgroups, several unmasked tiles (fast path) at hd 128
+    (64, 2, 1, 260, 260, True, None),
 ])
 def test_attn_fwd_bwd(backend, hd, Hq, Hkv, Sq, Sk, causal, pad):
     B = 2
