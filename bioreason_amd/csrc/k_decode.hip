@@ -108,7 +108,7 @@ static int sg_head(const StepGemms& s, const void* x, const void* norm_w, const 
 extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B, int H, int Hq, int Hkv, int hd, int F,
                                           int Smax, int V, float eps, float scale, const void* E, const void* norm_w,
                                           const float* cosT, const float* sinT, const int* tok, const int* pos,
-                                          const void* kmask, int cur_len, const int* len_dev, void* x, void* qkv, void* o, void* h, void* act,
+                                          const void* kmask, int cur_len, const int* len_dev, int embed_done, void* x, void* qkv, void* o, void* h, void* act,
                                           float* ss_ws, int nss, float* part_o, float* part_ml, float* logits, void* stream) {
     const Layer* ls = (const Layer*)layers_host;
     const int Nq = Hq * hd, Nkv = Hkv * hd, Nqkv = Nq + 2 * Nkv;
@@ -116,8 +116,10 @@ extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B,
     int rc;
 #define CK(call) do { rc = (call); if (rc) return rc; } while (0)
     const StepGemms sg = step_gemms(ss_ws, nss, B, H, Nq, Nqkv, F, V, eps, stream);
-    CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));
-    CK(sg_begin(sg, x));
+    if (!(embed_done && sg.v2)) {          // else bra_sample_embed already left x = E[tok] and its RMSNorm statistics
+        CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));
+        CK(sg_begin(sg, x));
+    }
     for (int li = 0; li < L; ++li) {
         const Layer& l = ls[li];
         CK(sg_qkv(sg, l, x, qkv));
@@ -140,7 +142,7 @@ extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B,
 extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R, int copies, int H, int Hq, int Hkv, int hd,
                                            int F, int P, long vt_pitch, int C, int V, float eps, float scale, const void* E,
                                            const void* norm_w, const float* cosT, const float* sinT, const int* tok,
-                                           const int* pos, const void* pmask, int t, const int* t_dev, void* x, void* qkv, void* o,
+                                           const int* pos, const void* pmask, int t, const int* t_dev, int embed_done, void* x, void* qkv, void* o,
                                            void* h, void* act, float* ss_ws, int nss, float* part_o, float* part_ml, float* logits, void* stream) {
     const Layer* ls = (const Layer*)layers_host;
     const int B = R * copies;
@@ -149,8 +151,10 @@ extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R
     int rc;
 #define CK(call) do { rc = (call); if (rc) return rc; } while (0)
     const StepGemms sg = step_gemms(ss_ws, nss, B, H, Nq, Nqkv, F, V, eps, stream);
-    CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));
-    CK(sg_begin(sg, x));
+    if (!(embed_done && sg.v2)) {          // else bra_sample_embed already left x = E[tok] and its RMSNorm statistics
+        CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));
+        CK(sg_begin(sg, x));
+    }
     for (int li = 0; li < L; ++li) {
         const Layer& l = ls[li];
         CK(sg_qkv(sg, l, x, qkv));

@@ -73,6 +73,46 @@ __global__ __launch_bounds__(256) void topk_slices_kernel(const float* logits, l
     }
 }
 
+// temperature / top-p / draw over the k survivors (value-descending), executed by one thread
+// (HF: TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper, multinomial — TF:generation/logits_process.py, utils.py:2905-2925)
+__device__ inline void sample_pick(const float* top_v, const int* top_i, int k, int row, float temperature, float top_p,
+                                   int do_sample, uint32_t seed, const int* step_ptr, uint8_t* finished, int pad_id, int eos_id,
+                                   int* out_ids, float* out_logp, int* tokens_out, long ldt) {
+    int choice = top_i[0];
+    float lp = 0.f;
+    if (do_sample) {
+        // temperature, softmax over the top-k survivors
+        const float inv_t = 1.f / temperature;
+        float p[64];
+        const float mx = top_v[0] * inv_t;
+        float z = 0.f;
+        for (int j = 0; j < k; ++j) { p[j] = __expf(top_v[j] * inv_t - mx); z += p[j]; }
+        for (int j = 0; j < k; ++j) p[j] /= z;
+        // top-p (HF: sort ascending, drop tokens whose cumulative prob <= 1 - top_p, keep >= 1)
+        int keep = k;
+        if (top_p < 1.f) {
+            float cum = 0.f;
+            for (int j = k - 1; j >= 1; --j) {   // ascending order = from the tail of our descending list
+                cum += p[j];
+                if (cum <= 1.f - top_p) keep = j; else break;
+            }
+        }
+        float z2 = 0.f;
+        for (int j = 0; j < keep; ++j) z2 += p[j];
+        const float u = uniform01(seed, (uint32_t)(step_ptr ? step_ptr[0] : 0), (uint32_t)row) * z2;
+        float acc = 0.f;
+        int pick = keep - 1;
+        for (int j = 0; j < keep; ++j) { acc += p[j]; if (u < acc) { pick = j; break; } }
+        choice = top_i[pick];
+        lp = __logf(p[pick] / z2);
+    }
+    if (finished && finished[row]) choice = pad_id;   // HF: finished sequences emit pad_token_id
+    out_ids[row] = choice;
+    if (out_logp) out_logp[row] = lp;
+    if (tokens_out) tokens_out[(long)row * ldt + (step_ptr ? step_ptr[0] : 0)] = choice;
+    if (finished && eos_id >= 0 && choice == eos_id) finished[row] = 1;   // unfinished &= (token != eos)
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ldl, int V, const int* cand_idx, float temperature,
                                                     int top_k, float top_p, int do_sample, uint32_t seed,
@@ -114,41 +154,75 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ld
         last_v = top_v[round];
         last_i = top_i[round];
     }
-    if (tid == 0) {
-        int choice = top_i[0];
-        float lp = 0.f;
-        if (do_sample) {
-            // temperature, softmax over the top-k survivors
-            const float inv_t = 1.f / temperature;
-            float p[64];
-            const float mx = top_v[0] * inv_t;
-            float z = 0.f;
-            for (int j = 0; j < k; ++j) { p[j] = __expf(top_v[j] * inv_t - mx); z += p[j]; }
-            for (int j = 0; j < k; ++j) p[j] /= z;
-            // top-p (HF: sort ascending, drop tokens whose cumulative prob <= 1 - top_p, keep >= 1)
-            int keep = k;
-            if (top_p < 1.f) {
-                float cum = 0.f;
-                for (int j = k - 1; j >= 1; --j) {   // ascending order = from the tail of our descending list
-                    cum += p[j];
-                    if (cum <= 1.f - top_p) keep = j; else break;
-                }
-            }
-            float z2 = 0.f;
-            for (int j = 0; j < keep; ++j) z2 += p[j];
-            const float u = uniform01(seed, (uint32_t)(step_ptr ? step_ptr[0] : 0), (uint32_t)row) * z2;
-            float acc = 0.f;
-            int pick = keep - 1;
-            for (int j = 0; j < keep; ++j) { acc += p[j]; if (u < acc) { pick = j; break; } }
-            choice = top_i[pick];
-            lp = __logf(p[pick] / z2);
+    if (tid == 0)
+        sample_pick(top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr, finished, pad_id, eos_id, out_ids,
+                    out_logp, tokens_out, ldt);
+}
+
+// stage 2 of the sampler when stage 1 ran: ONE wave per sequence merges the 64 slice lists (each already in the
+// order value desc / index asc) — lane = slice, k rounds of a wave arg-max over the list heads, no barriers — then lane 0
+// draws, and the wave gathers the chosen token's embedding row into the decode step's input x [B, H] together with its
+// RMSNorm statistic (bra_row_sumsq layout), which is what the next launch of the token loop consumes.
+__global__ __launch_bounds__(64) void sample_merge_kernel(const float* cand_v, const int* cand_i, int k, float temperature,
+                                                          float top_p, int do_sample, uint32_t seed, const int* step_ptr,
+                                                          uint8_t* finished, int pad_id, int eos_id, int* out_ids,
+                                                          float* out_logp, int* tokens_out, long ldt, const bf16_t* E,
+                                                          long lde, int H, bf16_t* x, long ldx, float* ss, int nss) {
+    BRA_DYN_SMEM(smem);                           // values [64][k] | indices [64][k]
+    __shared__ float top_v[64];
+    __shared__ int top_i[64];
+    __shared__ int s_choice;
+    float* sv = reinterpret_cast<float*>(smem);
+    int* si = reinterpret_cast<int*>(smem) + kSlices * k;
+    const int row = (int)blockIdx.x, lane = lane_id();
+    const long base = (long)row * kSlices * k;
+    for (int j = lane; j < kSlices * k; j += 64) { sv[j] = cand_v[base + j]; si[j] = cand_i[base + j]; }
+    __syncthreads();
+    int ptr = 0;
+    float cv = sv[lane * k];
+    int ci = si[lane * k];
+    for (int round = 0; round < k; ++round) {
+        float bv = cv;
+        int bi = ci;
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = wave_shfl_xor(bv, m);
+            const int oi = wave_shfl_xor_i(bi, m);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        if (finished && finished[row]) choice = pad_id;   // HF: finished sequences emit pad_token_id
-        out_ids[row] = choice;
-        if (out_logp) out_logp[row] = lp;
-        if (tokens_out) tokens_out[(long)row * ldt + (step_ptr ? step_ptr[0] : 0)] = choice;
-        if (finished && eos_id >= 0 && choice == eos_id) finished[row] = 1;   // unfinished &= (token != eos)
+        if (lane == 0) { top_v[round] = bv; top_i[round] = bi; }
+        if (cv == bv && ci == bi) {               // the list that supplied the winner moves to its next entry
+            ++ptr;
+            cv = ptr < k ? sv[lane * k + ptr] : -3.0e38f;
+            ci = ptr < k ? si[lane * k + ptr] : 0x7fffffff;
+        }
     }
+    __syncthreads();
+    if (lane == 0) {
+        sample_pick(top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr, finished, pad_id, eos_id, out_ids,
+                    out_logp, tokens_out, ldt);
+        s_choice = out_ids[row];
+    }
+    __syncthreads();
+    if (!E) return;
+    const int tok = s_choice;
+    float acc = 0.f;
+    for (int j = lane; j < H / 8; j += 64) {
+        const u32x4 v = ld16(E + (long)tok * lde + j * 8);
+        st16(x + (long)row * ldx + j * 8, v);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += f[i] * f[i];
+    }
+    acc = wave_sum<64>(acc);
+    if (ss) for (int c = lane; c < nss; c += 64) ss[(long)row * nss + c] = c == 0 ? acc : 0.f;
+}
+
+// counters of the replayed token loop: pos[0 .. n) += 1 (rotary positions), a[0] += 1, b[0] += 1 (step index, cache length)
+__global__ __launch_bounds__(64) void advance_counters_kernel(int* pos, int n, int* a, int* b) {
+    const int i = (int)threadIdx.x;
+    for (int j = i; j < n; j += 64) pos[j] += 1;
+    if (i == 0) { if (a) a[0] += 1; if (b) b[0] += 1; }
 }
 
 // completion_mask[b, c] = c <= first_eos(b) ; also lengths[b] = mask.sum()
@@ -242,25 +316,45 @@ extern "C" int bra_sample_ws_floats(int B, int top_k) {     // workspace size in
     return 2 * B * kSlices * k;
 }
 
+// `E` (optional, with x / ss): the wave that draws the token also gathers its embedding row into x [B, H] and writes the
+// row's RMSNorm statistic (bra_row_sumsq layout) — the first two launches of the next decode step.  Needs the two-stage
+// path (ws given, 4096 <= V <= 64 * 4096); returns BRA_ERR_UNSUPPORTED otherwise.
+extern "C" int bra_sample_embed(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p,
+                                int do_sample, unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id,
+                                int* out_ids, float* out_logp, int* tokens_out, long ldt, void* ws, const void* E, long lde,
+                                int H, void* x, long ldx, float* ss, int nss, void* stream) {
+    if (B == 0) return 0;
+    if (!logits || !out_ids || V <= 0 || (do_sample && temperature <= 0.f)) return BRA_ERR_ARG;
+    if (!(ws && V <= kSlices * 4096 && V >= 4096)) return BRA_ERR_UNSUPPORTED;
+    if (E && (!x || H % 8 || lde % 8 || ldx % 8)) return BRA_ERR_ARG;
+    const int k = do_sample ? (top_k > 0 ? (top_k < 64 ? top_k : 64) : 64) : 1;
+    float* cv = (float*)ws;
+    int* ci = (int*)ws + (long)B * kSlices * k;
+    BRA_LAUNCH(topk_slices_kernel, dim3(kSlices, B), dim3(256), 0, stream, logits, ldl, V, k, cv, ci);
+    int r = BRA_LAUNCH_STATUS();
+    if (r) return r;
+    BRA_LAUNCH(sample_merge_kernel, dim3(B), dim3(64), (size_t)kSlices * k * 8, stream, (const float*)cv, (const int*)ci, k,
+               temperature, top_p, do_sample, (uint32_t)seed, step_ptr, (uint8_t*)finished, pad_id, eos_id, out_ids, out_logp,
+               tokens_out, ldt, (const bf16_t*)E, lde, H, (bf16_t*)x, ldx, ss, nss);
+    return BRA_LAUNCH_STATUS();
+}
+
 extern "C" int bra_sample(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p,
                           int do_sample, unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id,
                           int* out_ids, float* out_logp, int* tokens_out, long ldt, void* ws, void* stream) {
     if (B == 0) return 0;
     if (!logits || !out_ids || V <= 0 || (do_sample && temperature <= 0.f)) return BRA_ERR_ARG;
-    if (ws && V <= kSlices * 4096 && V >= 4096) {
-        const int k = do_sample ? (top_k > 0 ? (top_k < 64 ? top_k : 64) : 64) : 1;
-        float* cv = (float*)ws;
-        int* ci = (int*)ws + (long)B * kSlices * k;
-        BRA_LAUNCH(topk_slices_kernel, dim3(kSlices, B), dim3(256), 0, stream, logits, ldl, V, k, cv, ci);
-        int r = BRA_LAUNCH_STATUS();
-        if (r) return r;
-        BRA_LAUNCH((sample_kernel<1024>), dim3(B), dim3(1024), 0, stream, (const float*)cv, (long)kSlices * k, kSlices * k,
-                   (const int*)ci, temperature, top_k, top_p, do_sample, (uint32_t)seed, step_ptr, (uint8_t*)finished, pad_id,
-                   eos_id, out_ids, out_logp, tokens_out, ldt);
-        return BRA_LAUNCH_STATUS();
-    }
+    if (ws && V <= kSlices * 4096 && V >= 4096)
+        return bra_sample_embed(logits, ldl, B, V, temperature, top_k, top_p, do_sample, seed, step_ptr, finished, pad_id,
+                                eos_id, out_ids, out_logp, tokens_out, ldt, ws, nullptr, 0, 0, nullptr, 0, nullptr, 0, stream);
     BRA_LAUNCH((sample_kernel<1024>), dim3(B), dim3(1024), 0, stream, logits, ldl, V, (const int*)nullptr, temperature, top_k, top_p,
                do_sample, (uint32_t)seed, step_ptr, (uint8_t*)finished, pad_id, eos_id, out_ids, out_logp, tokens_out, ldt);
+    return BRA_LAUNCH_STATUS();
+}
+
+extern "C" int bra_advance_counters(int* pos, int n, int* a, int* b, void* stream) {
+    if (n < 0 || (n > 0 && !pos)) return BRA_ERR_ARG;
+    BRA_LAUNCH(advance_counters_kernel, dim3(1), dim3(64), 0, stream, pos, n, a, b);
     return BRA_LAUNCH_STATUS();
 }
 

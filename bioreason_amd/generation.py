@@ -151,13 +151,14 @@ class FusedDecodeState:
         self.cosT, self.sinT = eng.rope(cache.Smax + 1)
         self.ss_ws, self.nss = _norm_stat_ws(eng, eng.device)
 
-    def step(self, tok, pos, kmask, cur_len: int, logits: torch.Tensor, len_dev=None):
+    def step(self, tok, pos, kmask, cur_len: int, logits: torch.Tensor, len_dev=None, embed_done: bool = False):
         """`len_dev` (device int32 [1] holding cur_len): the kernels read the length from memory and `cur_len` only
         sizes the grids, so the call can be captured once and replayed."""
         e = self.eng
         get_lib().call("bra_qwen_decode_step_fused", ctypes.addressof(self.arr), e.L, self.B, e.H, e.Hq, e.Hkv, e.hd, e.F,
                        self.cache.Smax, e.V, e.eps, e.scale, e.E, e.norm_w, self.cosT, self.sinT, tok, pos, kmask, cur_len,
-                       len_dev, self.x, self.qkv, self.o, self.h, self.act, self.ss_ws, self.nss, self.part_o, self.part_ml,
+                       len_dev, int(embed_done), self.x, self.qkv, self.o, self.h, self.act, self.ss_ws, self.nss, self.part_o,
+                       self.part_ml,
                        logits, current_stream(self.x))
 
 
@@ -194,11 +195,12 @@ class SharedDecodeState:
         self.cosT, self.sinT = eng.rope(P + C + 1)
         self.ss_ws, self.nss = _norm_stat_ws(eng, dev)
 
-    def step(self, tok, pos, pmask, t: int, logits: torch.Tensor, t_dev=None):
+    def step(self, tok, pos, pmask, t: int, logits: torch.Tensor, t_dev=None, embed_done: bool = False):
         e = self.eng
         get_lib().call("bra_qwen_decode_step_shared", ctypes.addressof(self.arr), e.L, self.R, self.copies, e.H, e.Hq, e.Hkv,
                        e.hd, e.F, self.P, self.vt_pitch, self.C, e.V, e.eps, e.scale, e.E, e.norm_w, self.cosT, self.sinT, tok,
-                       pos, pmask, t, t_dev, self.x, self.qkv, self.o, self.h, self.act, self.ss_ws, self.nss, self.part_o,
+                       pos, pmask, t, t_dev, int(embed_done), self.x, self.qkv, self.o, self.h, self.act, self.ss_ws, self.nss,
+                       self.part_o,
                        self.part_ml, logits, current_stream(self.x))
 
 
@@ -338,19 +340,24 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         use_graph = dev.type == "cuda"
     use_graph = bool(use_graph) and fused and force_tokens is None and max_new_tokens > 2
 
+    dstate = shared if shared is not None else (state if fused else None)
+    # the drawing wave of the sampler also gathers x = E[token] and its RMSNorm statistic for the fused step (not under
+    # teacher forcing, where the token fed back is not the sampled one)
+    fuse_embed = (dstate is not None and dstate.ss_ws is not None and force_tokens is None and sample_ws is not None
+                  and B <= 8)
+
     def sample_():
         ops.sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished if eos >= 0 else None, pad,
-                   cur, None, eos_id=eos, tokens_out=tokens, ws=sample_ws)
+                   cur, None, eos_id=eos, tokens_out=tokens, ws=sample_ws,
+                   embed=(eng.E, dstate.x, dstate.ss_ws[0]) if fuse_embed else None)
 
     def advance_(t_grid: int):
         """one fused decode step; the kernels take the step index from step_t / len_t, `t_grid` only sizes grids"""
         if shared is not None:
-            shared.step(cur, next_pos, pmask, t_grid, logits, t_dev=step_t)
+            shared.step(cur, next_pos, pmask, t_grid, logits, t_dev=step_t, embed_done=fuse_embed)
         else:
-            state.step(cur, next_pos, kmask, P + t_grid, logits, len_dev=len_t)
-        next_pos.add_(1)
-        step_t.add_(1)
-        len_t.add_(1)
+            state.step(cur, next_pos, kmask, P + t_grid, logits, len_dev=len_t, embed_done=fuse_embed)
+        ops.advance_counters(next_pos, step_t, len_t)
 
     _tick("decode_setup")
     if use_graph:

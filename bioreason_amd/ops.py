@@ -323,15 +323,27 @@ def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- GRPO / optimiser
 def sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished, pad_id, out_ids, out_logp=None,
-           eos_id=-1, tokens_out=None, ws=None):
+           eos_id=-1, tokens_out=None, ws=None, embed=None):
+    """`embed` = (E [V, H], x [B, H], ss [8, nss] or None): the drawing wave also writes x[b] = E[token] and the RMSNorm
+    statistic of that row (two-stage path only: V >= 4096)."""
     B, V = logits.shape
     if ws is None and V >= 4096:
         k = min(top_k, 64) if top_k > 0 else 64
         ws = torch.empty((2 * B * 64 * k,), dtype=torch.float32, device=logits.device)
+    ldt = tokens_out.stride(0) if tokens_out is not None else 0
+    if embed is not None:
+        E, x, ss = embed
+        get_lib().call("bra_sample_embed", logits, _ld(logits), B, V, temperature, top_k, top_p, int(do_sample),
+                       seed & 0xFFFFFFFF, step_t, finished, pad_id, eos_id, out_ids, out_logp, tokens_out, ldt, ws, E, _ld(E),
+                       E.shape[1], x, _ld(x), ss, ss.shape[-1] if ss is not None else 0, current_stream(logits))
+        return out_ids
     get_lib().call("bra_sample", logits, _ld(logits), B, V, temperature, top_k, top_p, int(do_sample), seed & 0xFFFFFFFF,
-                   step_t, finished, pad_id, eos_id, out_ids, out_logp, tokens_out,
-                   tokens_out.stride(0) if tokens_out is not None else 0, ws, current_stream(logits))
+                   step_t, finished, pad_id, eos_id, out_ids, out_logp, tokens_out, ldt, ws, current_stream(logits))
     return out_ids
+
+
+def advance_counters(pos: torch.Tensor, a: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None):
+    get_lib().call("bra_advance_counters", pos, pos.numel(), a, b, current_stream(pos))
 
 
 def row_sumsq(x: torch.Tensor, nss: int = 32) -> torch.Tensor:

@@ -170,8 +170,8 @@ int bra_attn_decode_merge(const float* part_o, const float* part_ml, void* o, in
 int bra_qwen_decode_step_fused(const void* layers_host, int L, int B, int H, int Hq, int Hkv, int hd, int F, int Smax,
                                int V, float eps, float scale, const void* E, const void* norm_w, const float* cosT,
                                const float* sinT, const int* tok, const int* pos, const void* kmask, int cur_len,
-                               const int* len_dev, void* x, void* qkv, void* o, void* h, void* act, float* ss_ws, int nss,
-                               float* part_o, float* part_ml, float* logits, void* stream);
+                               const int* len_dev, int embed_done, void* x, void* qkv, void* o, void* h, void* act, float* ss_ws,
+                               int nss, float* part_o, float* part_ml, float* logits, void* stream);
 
 /* shared-prefix step: B = R * copies sequences grouped by prompt; layer records additionally carry kp (prompt K
  * [R,Hkv,P,hd]) and vtp (prompt V^T [R,Hkv,hd,vt_pitch]); kc / vc are the per-sequence COMPLETION caches [B,Hkv,C,hd]
@@ -179,8 +179,8 @@ int bra_qwen_decode_step_fused(const void* layers_host, int L, int B, int H, int
 int bra_qwen_decode_step_shared(const void* layers_host, int L, int R, int copies, int H, int Hq, int Hkv, int hd, int F,
                                 int P, long vt_pitch, int C, int V, float eps, float scale, const void* E,
                                 const void* norm_w, const float* cosT, const float* sinT, const int* tok, const int* pos,
-                                const void* pmask, int t, const int* t_dev, void* x, void* qkv, void* o, void* h, void* act,
-                                float* ss_ws, int nss, float* part_o, float* part_ml, float* logits, void* stream);
+                                const void* pmask, int t, const int* t_dev, int embed_done, void* x, void* qkv, void* o, void* h,
+                                void* act, float* ss_ws, int nss, float* part_o, float* part_ml, float* logits, void* stream);
 
 /* ---- data movement around the kernels (k_misc.hip) ---------------------------- */
 int bra_head_transpose(const void* x, long sb, long ss, long sh, void* xt, long t_sb, long t_sh, long pitch, int B,
@@ -227,6 +227,16 @@ int bra_sample(const float* logits, long ldl, int B, int V, float temperature, i
 /* ws (optional, bra_sample_ws_floats(B, top_k) 4-byte words): enables the two-stage top-k (64 vocabulary slices
  * per row in parallel, then a merge) instead of one workgroup per row scanning the vocabulary k times */
 int bra_sample_ws_floats(int B, int top_k);
+/* bra_sample on the two-stage path whose drawing wave also gathers x[b] = E[token] (HF embed_tokens of the next step,
+ * TF:qwen3:380) and its RMSNorm statistic ss[8][nss] (bra_row_sumsq layout): the decode step functions then start at
+ * the first projection (`embed_done`).  E may be null (sampling only).  BRA_ERR_UNSUPPORTED without ws / outside
+ * 4096 <= V <= 262144. */
+int bra_sample_embed(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p, int do_sample,
+                     unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id, int* out_ids,
+                     float* out_logp, int* tokens_out, long ldt, void* ws, const void* E, long lde, int H, void* x, long ldx,
+                     float* ss, int nss, void* stream);
+/* counters of the replayed token loop: pos[0..n) += 1, a[0] += 1, b[0] += 1 (a, b optional) */
+int bra_advance_counters(int* pos, int n, int* a, int* b, void* stream);
 /* completion mask up to and including the first EOS (grpo_trainer.py:605-609) */
 int bra_eos_mask(const int* ids, int B, int C, int eos_id, int* mask, int* lengths, void* stream);
 /* rewards [N,F] -> sum over F -> (r - mean_group) / (std_group + 1e-4), groups of G (grpo_trainer.py:682-691) */

@@ -416,6 +416,20 @@ def test_sampler_greedy_and_topk(backend):
     fin = torch.tensor([0, 1, 0], dtype=torch.uint8, device=backend)
     ops.sample(logits, T, k, p, True, 1, step, fin, 42, out)
     assert out[1].item() == 42
+    # fused tail: the drawing wave gathers x = E[token] and the row's RMSNorm statistic; same draw as the plain call
+    E = rnd(V, 64, dev=backend)
+    x = torch.zeros(B, 64, dtype=BF, device=backend)
+    ss = torch.full((8, 32), 7.0, device=backend)
+    out2 = torch.empty_like(out)
+    step.fill_(5)
+    ops.sample(logits, T, k, p, True, 1234, step, None, 0, out)
+    ops.sample(logits, T, k, p, True, 1234, step, None, 0, out2, embed=(E, x, ss))
+    assert out.tolist() == out2.tolist()
+    assert torch.equal(x.cpu(), E[out2.long()].cpu())
+    assert rel(ss[:B, 0], (x.float() ** 2).sum(1)) < 1e-5 and float(ss[:B, 1:].abs().max()) == 0 and float(ss[B:].min()) == 7.0
+    pos, a_, b_ = torch.arange(5, dtype=torch.int32, device=backend), torch.zeros(1, dtype=torch.int32, device=backend), torch.full((1,), 9, dtype=torch.int32, device=backend)
+    ops.advance_counters(pos, a_, b_)
+    assert pos.tolist() == [1, 2, 3, 4, 5] and a_.item() == 1 and b_.item() == 10
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
