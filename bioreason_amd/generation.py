@@ -261,9 +261,10 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
              shared_prefix_decode: bool = True, profile: Optional[dict] = None) -> torch.Tensor:
     """`force_tokens` [B, max_new_tokens] (optional): teacher forcing — the model's own choice is still recorded
     in the output, but the given token is fed back (used to compare decodes position by position).
-    `use_graph` (default: on for the fused native step on a GPU): sample + decode step + counter updates are captured
-    once in a hipGraph and replayed per token — a step is ~200 dependent launches of a few microseconds each, so
-    issuing them from the host one by one makes the rollout CPU-launch bound."""
+    `use_graph`: True = sample + decode step + counter update are captured once in a hipGraph and replayed per token
+    (a step is ~180 dependent launches of a few microseconds each; a slow host issuing them one by one makes the
+    rollout launch-bound); False = eager issue; None (default) = measured once per engine: eager unless the host
+    cannot stay ahead of the device."""
     eng = model.ensure_packed()
     B, P, H = inputs_embeds.shape
     dev = inputs_embeds.device
@@ -336,10 +337,9 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         state = FusedDecodeState(model, cache, B) if fused else DecodeState(model, cache, B)
     ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
     len_t = torch.full((1,), P, dtype=torch.int32, device=dev)          # device-side cur_len of the fused step
-    if use_graph is None:
-        use_graph = dev.type == "cuda"
-    use_graph = bool(use_graph) and fused and force_tokens is None and max_new_tokens > 2
-
+    # graph_mode: True / False as requested, None = decide by measurement (see below); graph_ok: replay is possible at all
+    graph_ok = dev.type == "cuda" and fused and force_tokens is None and max_new_tokens > 2
+    graph_mode = use_graph if use_graph is None else bool(use_graph)
     dstate = shared if shared is not None else (state if fused else None)
     # the drawing wave of the sampler also gathers x = E[token] and its RMSNorm statistic for the fused step (not under
     # teacher forcing, where the token fed back is not the sampled one)
@@ -360,42 +360,86 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         ops.advance_counters(next_pos, step_t, len_t)
 
     _tick("decode_setup")
-    if use_graph:
-        sample_()
-        advance_(0)                                     # eager first step: one-time kernel attribute set-up happens here
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+    last = max_new_tokens - 1                 # index of the final draw (no decode step follows it)
+    t = 0
+    alive = True                              # False once every row has emitted EOS
+
+    def eos_stop(tt: int) -> bool:
+        return eos >= 0 and force_tokens is None and (tt + 1) % check_every == 0 and bool(finished.all().item())
+
+    def eager_steps(n: int) -> bool:
+        """up to n (draw, decode step) pairs issued launch by launch; False if the EOS check ended the rollout"""
+        nonlocal t, n_done, hid
+        for _ in range(n):
+            if t >= last:
+                return True
             sample_()
-            advance_(max_new_tokens - 1)
-        _tick("graph_capture")
-        for t in range(1, max_new_tokens - 1):
-            graph.replay()
-            if eos >= 0 and (t + 1) % check_every == 0 and bool(finished.all().item()):
+            if eos_stop(t):
                 n_done = t + 1
-                break
-        else:
-            sample_()
-    else:
-        for t in range(max_new_tokens):
-            sample_()
-            if eos >= 0 and force_tokens is None and (t + 1) % check_every == 0 and bool(finished.all().item()):
-                n_done = t + 1
-                break
-            if t + 1 == max_new_tokens:
-                break
+                return False
             if force_tokens is not None:
                 cur.copy_(force_tokens[:, t].to(torch.int32))
             if fused:
                 advance_(t)
-                continue
-            if state is not None:
-                hid = state.step(cur, next_pos, kmask, P + t, model._lora_enabled)
             else:
-                hid = decode_step(model, cur, cache, kmask, next_pos, P + t)
-            ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
-            next_pos += 1
-            step_t += 1
+                if state is not None:
+                    hid = state.step(cur, next_pos, kmask, P + t, model._lora_enabled)
+                else:
+                    hid = decode_step(model, cur, cache, kmask, next_pos, P + t)
+                ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
+                next_pos.add_(1)
+                step_t.add_(1)
+            t += 1
+        return True
+
+    graph = None
+    want_graph = graph_mode
+    if want_graph is None and graph_ok:
+        # auto: replay a hipGraph only if the host cannot issue the ~180 launches of a step faster than the device runs
+        # them (measured once per engine over 8 eager steps).  On a fast host eager issue is the quicker of the two:
+        # graph nodes execute with larger gaps than back-to-back stream launches.
+        want_graph = getattr(eng, "_rollout_use_graph", None)
+        if want_graph is None and last >= 24:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            alive = eager_steps(2)                       # warm: one-time kernel attribute set-up, allocator
+            torch.cuda.synchronize()
+            h0 = _time.perf_counter()
+            e0.record()
+            if alive:
+                alive = eager_steps(8)
+            host_s = _time.perf_counter() - h0
+            e1.record()
+            e1.synchronize()
+            want_graph = host_s > 0.8 * e0.elapsed_time(e1) * 1e-3
+            eng._rollout_use_graph = want_graph
+            if profile is not None:
+                profile["auto_host_ms_per_step"] = host_s * 1e3 / 8
+                profile["auto_gpu_ms_per_step"] = e0.elapsed_time(e1) / 8
+    if alive and want_graph and graph_ok and t < last:
+        if t == 0:
+            alive = eager_steps(1)                       # eager first step: one-time kernel attribute set-up happens here
+        if alive and t < last:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                sample_()
+                advance_(max_new_tokens - 1)
+            _tick("graph_capture")
+            while t < last:
+                graph.replay()
+                if eos >= 0 and (t + 1) % check_every == 0 and bool(finished.all().item()):
+                    n_done = t + 1
+                    alive = False
+                    break
+                t += 1
+    elif alive:
+        alive = eager_steps(last - t)
+    if alive:
+        sample_()
     _tick("decode_loop")
+    if graph is not None:
+        graph.reset()            # release the executable graph here, not whenever the cyclic GC finds the closures
+        del graph
+        _tick("graph_reset")
     out = tokens[:, :n_done]
     if eos >= 0 and not return_full_length and force_tokens is None:
         # HF stops right after the step in which the last row finished: trim the all-pad tail we may have produced
