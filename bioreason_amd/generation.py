@@ -420,7 +420,8 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             alive = eager_steps(1)                       # eager first step: one-time kernel attribute set-up happens here
         if alive and t < last:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: other threads of the process (the RCCL watchdog of a data-parallel run) keep making HIP calls
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 sample_()
                 advance_(max_new_tokens - 1)
             _tick("graph_capture")
