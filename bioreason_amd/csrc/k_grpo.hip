@@ -176,7 +176,23 @@ __global__ __launch_bounds__(64) void sample_merge_kernel(const float* cand_v, c
     int* si = reinterpret_cast<int*>(smem) + kSlices * k;
     const int row = (int)blockIdx.x, lane = lane_id();
     const long base = (long)row * kSlices * k;
-    for (int j = lane; j < kSlices * k; j += 64) { sv[j] = cand_v[base + j]; si[j] = cand_i[base + j]; }
+    if ((k & 3) == 0) {
+        // lane = slice: its k candidates are contiguous; all 16-byte loads are requested before the first is used
+        const f32x4* gv = reinterpret_cast<const f32x4*>(cand_v + base + (long)lane * k);
+        const u32x4* gi = reinterpret_cast<const u32x4*>(cand_i + base + (long)lane * k);
+        f32x4 tv[16];
+        u32x4 ti[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int qq = 4 * q < k ? q : 0; tv[q] = gv[qq]; ti[q] = gi[qq]; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (4 * q < k) {
+                *reinterpret_cast<f32x4*>(sv + lane * k + 4 * q) = tv[q];
+                *reinterpret_cast<u32x4*>(si + lane * k + 4 * q) = ti[q];
+            }
+    } else {
+        for (int j = lane; j < kSlices * k; j += 64) { sv[j] = cand_v[base + j]; si[j] = cand_i[base + j]; }
+    }
     __syncthreads();
     int ptr = 0;
     float cv = sv[lane * k];

@@ -1,0 +1,142 @@
+// k_wgrad.hip — low-rank weight gradients straight from row-major activations.
+//   C[n, r] += alpha * sum_m Y[m, n] * T[m, r]            Y [M, N] bf16 (large), T [M, R] bf16 (R = 32, 64 or 128)
+// These are autograd's gradients of PEFT's lora_B (Y = dy, T = s * x A^T) and lora_A (Y = x, T = s * dy B, written
+// transposed), train_dna_qwen.py:155-167 / reason.py:376-388.  The contraction runs over the token index m, which is the
+// SLOW index of both operands, so neither is "K-contiguous" as an MFMA fragment wants.  The first version transposed
+// Y and T in HBM (one extra read + write of every activation) and ran a split-K NT GEMM; this kernel instead stages
+// row-major tiles in LDS with coalesced 16-byte accesses and builds the fragments with 2-byte LDS reads down a column:
+// eight times more LDS instructions than a b128 read, which is irrelevant for a kernel whose only real cost is
+// streaming Y once from HBM (≈16 FLOP per byte).
+#include "bra_device.h"
+#include "bra_api_internal.h"
+
+namespace bra {
+
+struct WgradArgs {
+    const bf16_t* Y; long ldy;
+    const bf16_t* T; long ldt;
+    float* C; long c_sn, c_sr;      // element strides of C over n and r: dB [N, R] = (ld, 1); dA [R, K] = (1, ld)
+    int M, N, R;
+    int m_chunk;                    // rows of m per workgroup (multiple of 32)
+    float alpha;
+};
+
+constexpr int WG_YP = 128 + 8;      // LDS row pitch of the Y tile (elements): 272 bytes, odd multiple of 16
+
+// one workgroup: 128 columns of Y x all R, over m in [blockIdx.y * m_chunk, + m_chunk); 4 waves x 32 columns
+template <int RB>
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
+    __shared__ bf16_t ys[2][32 * WG_YP];
+    constexpr int WG_TP = 32 * RB + 8, TPT = RB >= 2 ? RB / 2 : 1;      // T tile pitch; 16-byte chunks per thread
+    __shared__ bf16_t ts[2][32 * WG_TP];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int n0 = (int)blockIdx.x * 128;
+    const int m_lo = (int)blockIdx.y * g.m_chunk;
+    int m_hi = m_lo + g.m_chunk;
+    m_hi = m_hi < g.M ? m_hi : g.M;
+    const int nstep = m_hi > m_lo ? (m_hi - m_lo + 31) / 32 : 0;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    // staging roles: Y tile 32 x 128 = 512 chunks of 16 bytes (2 per thread), T tile 32 x (32 RB) = 128 RB chunks
+    const int yr = tid >> 4, yc = (tid & 15) * 8;                 // rows yr and yr + 16, column chunk yc
+    const bool ycol_ok = n0 + yc + 8 <= g.N;
+    u32x4 ry[2], rt[TPT];
+    auto issue = [&](int s) {
+        const int m0 = m_lo + 32 * s;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + yr + 16 * i;
+            const int mc = m < g.M ? m : g.M - 1;
+            const u32x4 v = ld16(g.Y + (long)mc * g.ldy + (ycol_ok ? n0 + yc : 0));
+            ry[i] = (m < m_hi && ycol_ok) ? v : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < TPT; ++i) {
+            const int c = tid + 256 * i, tr = c / (4 * RB), tc = (c % (4 * RB)) * 8;
+            const int m = m0 + (tr < 32 ? tr : 0);
+            const int mc = m < g.M ? m : g.M - 1;
+            const u32x4 v = ld16(g.T + (long)mc * g.ldt + tc);
+            rt[i] = (m < m_hi && tr < 32) ? v : zero4;
+        }
+    };
+    auto commit = [&](int buf) {
+        st16(&ys[buf][yr * WG_YP + yc], ry[0]);
+        st16(&ys[buf][(yr + 16) * WG_YP + yc], ry[1]);
+#pragma unroll
+        for (int i = 0; i < TPT; ++i) {
+            const int c = tid + 256 * i, tr = c / (4 * RB), tc = (c % (4 * RB)) * 8;
+            if (tr < 32) st16(&ts[buf][tr * WG_TP + tc], rt[i]);
+        }
+    };
+
+    f32x16 acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+
+    if (nstep > 0) { issue(0); commit(0); }
+    __syncthreads();
+    const int ncol = wave * 32 + (lane & 31);       // this lane's Y column inside the tile (A row)
+    for (int s = 0; s < nstep; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstep) issue(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int mb = 16 * kk + 8 * h;          // this lane's 8 consecutive m of the k = 16 step
+            uint32_t a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                a[j] = (uint32_t)ys[buf][(mb + 2 * j) * WG_YP + ncol] | ((uint32_t)ys[buf][(mb + 2 * j + 1) * WG_YP + ncol] << 16);
+            const u32x4 af = {a[0], a[1], a[2], a[3]};
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int rc = rb * 32 + (lane & 31);
+                uint32_t b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    b[j] = (uint32_t)ts[buf][(mb + 2 * j) * WG_TP + rc] | ((uint32_t)ts[buf][(mb + 2 * j + 1) * WG_TP + rc] << 16);
+                const u32x4 bf = {b[0], b[1], b[2], b[3]};
+                acc[rb] = mfma_32x32x16(af, bf, acc[rb]);
+            }
+        }
+        if (s + 1 < nstep) commit(buf ^ 1);
+        __syncthreads();
+    }
+    if (nstep == 0) return;
+    // D[i][j]: i = A row = column n of Y (register index), j = B row = r (lane & 31)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int r = rb * 32 + (lane & 31);
+        if (r >= g.R) continue;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int n = n0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (n < g.N) atomicAdd(g.C + (long)n * g.c_sn + (long)r * g.c_sr, g.alpha * acc[rb][q]);
+        }
+    }
+}
+
+}  // namespace bra
+
+using namespace bra;
+
+extern "C" int bra_wgrad_tn(const void* Y, long ldy, const void* T, long ldt, float* C, long c_sn, long c_sr, int M, int N,
+                            int R, float alpha, int m_chunk, void* stream) {
+    if (M == 0 || N == 0) return 0;
+    if (!Y || !T || !C || M < 0 || N < 0 || N % 8 || ldy % 8 || ldt % 8 || (R != 32 && R != 64 && R != 128)) return BRA_ERR_ARG;
+    if (m_chunk <= 0) {
+        // enough workgroups to fill the chip twice, at least 256 rows each
+        const int ntile = (N + 127) / 128;
+        int splits = (512 + ntile - 1) / ntile;
+        m_chunk = (M + splits - 1) / splits;
+        m_chunk = m_chunk < 256 ? 256 : m_chunk;
+    }
+    m_chunk = (m_chunk + 31) / 32 * 32;
+    WgradArgs g = {(const bf16_t*)Y, ldy, (const bf16_t*)T, ldt, C, c_sn, c_sr, M, N, R, m_chunk, alpha};
+    const dim3 grid((N + 127) / 128, (M + m_chunk - 1) / m_chunk);
+    if (R == 32) BRA_LAUNCH((wgrad_tn_kernel<1>), grid, dim3(256), 0, (bra_stream_t)stream, g);
+    else if (R == 64) BRA_LAUNCH((wgrad_tn_kernel<2>), grid, dim3(256), 0, (bra_stream_t)stream, g);
+    else BRA_LAUNCH((wgrad_tn_kernel<4>), grid, dim3(256), 0, (bra_stream_t)stream, g);
+    return BRA_LAUNCH_STATUS();
+}

@@ -164,12 +164,9 @@ class QwenEngine:
         if G is not None and on:
             dts = ops.gemm_nt(dy, G.BT, alpha=G.scaling)                 # [T, r_pad] = s * dy B
             dx = ops.gemm_nt(dy, WT, a2=dts, b2=G.AT)
-            dyT = ops.transpose2d(dy, pad_to=32)                         # [N, Tp]
-            tT = ops.transpose2d(t, pad_to=32)                           # [r_pad, Tp]
-            ops.gemm_nt_splitk(dyT, tT, G.B_grad)                        # dB += dy^T t      (t already holds s)
-            dtT = ops.transpose2d(dts, pad_to=32)
-            xT = ops.transpose2d(x2d, pad_to=32)                         # [K, Tp]
-            ops.gemm_nt_splitk(dtT, xT, G.A_grad)                        # dA += (s dy B)^T x
+            # weight gradients straight from the row-major activations (k_wgrad.hip): no transposed copies in HBM
+            ops.wgrad_tn(dy, t, G.B_grad)                                # dB [N, r] += dy^T t      (t already holds s)
+            ops.wgrad_tn(x2d, dts, G.A_grad, transposed_out=True)        # dA [r, K] += (s dy B)^T x
             return dx
         return ops.gemm_nt(dy, WT)
 

@@ -120,6 +120,17 @@ def gemm_nt_splitk(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: f
     return out
 
 
+def wgrad_tn(y: torch.Tensor, t: torch.Tensor, out: torch.Tensor, transposed_out: bool = False, alpha: float = 1.0,
+             m_chunk: int = 0) -> torch.Tensor:
+    """out += alpha * y^T t from row-major y [M, N], t [M, R]: out [N, R], or [R, N] with transposed_out"""
+    M, N = y.shape
+    R = t.shape[1]
+    assert t.shape[0] == M and out.dtype == torch.float32 and out.shape == ((R, N) if transposed_out else (N, R))
+    c_sn, c_sr = (1, _ld(out)) if transposed_out else (_ld(out), 1)
+    get_lib().call("bra_wgrad_tn", y, _ld(y), t, _ld(t), out, c_sn, c_sr, M, N, R, alpha, m_chunk, current_stream(y))
+    return out
+
+
 def lmhead_logprob(h: torch.Tensor, emb: torch.Tensor, tgt: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """-> (logp[M], lse[M]) of target tokens under softmax(h @ emb^T) without materialising logits."""
     M, K = h.shape

@@ -50,6 +50,13 @@ int bra_gemm_set_variant(int v);
 int bra_gemm_bf16_nt_splitk(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                             float alpha, int split_k, void* stream);
 
+/* Low-rank weight gradient from ROW-MAJOR operands (k_wgrad.hip): C[n, r] += alpha * sum_m Y[m, n] T[m, r], Y [M, N]
+ * bf16, T [M, R] bf16 with R in {32, 64, 128}; C fp32 addressed by element strides (c_sn, c_sr), so the same call
+ * writes dB [N_out, r] (Y = dy, T = s x A^T) and dA [r, K] transposed (Y = x, T = s dy B) — autograd of PEFT's
+ * lora_B / lora_A.  m_chunk = rows per workgroup (0: chosen to fill the chip); combined by fp32 atomics. */
+int bra_wgrad_tn(const void* Y, long ldy, const void* T, long ldt, float* C, long c_sn, long c_sr, int M, int N, int R,
+                 float alpha, int m_chunk, void* stream);
+
 /* Fused lm_head + log-softmax statistics WITHOUT materialising logits
  * (grpo_trainer.py:510-520 `_get_per_token_logps`; TF:loss/loss_utils.py:49-71 ForCausalLMLoss):
  * for every row m of H[M,K] (bf16) against E[V,K]: per 64-column chunk running max and sum-exp of the

@@ -491,3 +491,22 @@ def test_dec_gemm2(backend, M, N, K, norm):
         r3 = ref.to(BF).float().view(M, N // 16, 2, 8)
         g, u = r3[:, :, 0].reshape(M, -1), r3[:, :, 1].reshape(M, -1)
         assert rel(a, (torch.nn.functional.silu(g).to(BF).float() * u).to(BF)) < 6e-3
+
+
+# ----------------------------------------------------------------------------- low-rank weight gradients
+@pytest.mark.parametrize("M,N,R,chunk", [(100, 136, 32, 0), (300, 128, 64, 64), (257, 264, 128, 96), (33, 8, 64, 0)])
+def test_wgrad_tn(backend, M, N, R, chunk):
+    """bra_wgrad_tn against fp32 torch: out += alpha * y^T t, both output orientations, accumulating"""
+    y, t = rnd(M, N, dev=backend), rnd(M, R, dev=backend)
+    ref = y.float().T @ t.float()
+    out = torch.ones(N, R, device=backend)
+    ops.wgrad_tn(y, t, out, alpha=0.5, m_chunk=chunk)
+    assert rel(out, 0.5 * ref + 1) < 1e-5
+    outT = torch.zeros(R, N, device=backend)
+    ops.wgrad_tn(y, t, outT, transposed_out=True, m_chunk=chunk)
+    assert rel(outT, ref.T) < 1e-5
+    # strided views (a column block of a wider activation, as the fused projections hand over)
+    big = rnd(M, N + 16, dev=backend)
+    out2 = torch.zeros(N, R, device=backend)
+    ops.wgrad_tn(big[:, 8:8 + N], t, out2)
+    assert rel(out2, big[:, 8:8 + N].float().T @ t.float()) < 1e-5
