@@ -536,7 +536,7 @@ static int pick_variant(const GemmArgs& g) {
     // large-M shape of the path (850-1130 TFLOP/s vs 640-870 for the register-staged 128x128 kernel); it needs
     // K % 64 == 0 and enough 256x128 tiles to fill the chip, otherwise the 128x128 kernel keeps more CUs busy
     const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
-    if (g.K % 64 == 0 && g.K2 % 64 == 0 && tiles256 >= 192) return 5;
+    if (g.K % 64 == 0 && g.K2 % 64 == 0 && tiles256 >= 128) return 5;
     return 0;
 }
 

@@ -93,7 +93,7 @@ class GemmProfile:
         projections, which are HBM-bound reads of the activations)"""
         if not self.dominant_only:
             return M >= self.min_m
-        return K % 64 == 0 and K2 % 64 == 0 and ((M + 255) // 256) * ((N + 127) // 128) >= 192
+        return K % 64 == 0 and K2 % 64 == 0 and ((M + 255) // 256) * ((N + 127) // 128) >= 128
 
     def summary(self):
         torch.cuda.synchronize()

@@ -10,14 +10,21 @@ def timeit(fn, iters=10, warm=3):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / iters
 T = 8 * 2436
-shapes = [("qkv", T, 4096, 2048, 128), ("o", T, 2048, 2048, 64), ("gate_up", T, 12288, 2048, 64), ("down", T, 2048, 6144, 64),
+P1 = 2180
+if os.environ.get("GV_PREFILL") == "1":
+    # one-prompt prefill / encoder shapes (M ~ 2 k): fewer than 192 256x128 tiles
+    shapes = [("p_qkv", P1, 4096, 2048, 128), ("p_o", P1, 2048, 2048, 64), ("p_gate_up", P1, 12288, 2048, 64), ("p_down", P1, 2048, 6144, 64),
+              ("e_qkv", 2052, 3072, 1024, 0), ("e_o", 2052, 1024, 1024, 0), ("e_ffn_up", 2052, 8192, 1024, 0), ("e_ffn_dn", 2052, 1024, 4096, 0),
+              ("lora_A", T, 64, 2048, 0), ("lora_A_gu_bwd", T, 64, 12288, 0)]
+else:
+  shapes = [("qkv", T, 4096, 2048, 128), ("o", T, 2048, 2048, 64), ("gate_up", T, 12288, 2048, 64), ("down", T, 2048, 6144, 64),
           ("enc_qkv", 16384, 3072, 1024, 0), ("enc_ffn_dn", 16384, 1024, 4096, 0), ("lm_head", 2048, 151936, 2048, 0), ("sq8192", 8192, 8192, 8192, 0)]
 for name, M, N, K, K2 in shapes:
     a = torch.randn(M, K, device=dev).to(BF); b = torch.randn(N, K, device=dev).to(BF)
     a2 = torch.randn(M, K2, device=dev).to(BF) if K2 else None; b2 = torch.randn(N, K2, device=dev).to(BF) if K2 else None
     c = torch.empty(M, N, dtype=BF, device=dev)
     res = {}
-    for v in range(6):
+    for v in (0, 1, 4, 5):
         get_lib().call("bra_gemm_set_variant", v)
         ms = timeit(lambda: ops.gemm_nt(a, b, a2=a2, b2=b2, out=c))
         res[v] = round(2.0 * M * N * (K + K2) / ms / 1e9)
