@@ -1,0 +1,100 @@
+"""Edge cases of the reference's forward / generate that the golden fixtures do not contain, checked directly against
+the CPU oracle rebuilt from the fixture weights (fp32, eager attention): text-only batches (dna_llm.py:208-211 — no DNA
+branch), a batch where one sample has no DNA sequence (ragged `batch_idx_map`, dna_llm.py:163-177), and the EOS /
+padding bookkeeping of `generate` (TF:generation/utils.py:2897-2925: finished rows emit pad, the loop stops when every
+row has finished)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from test_model_parity import GOLD, build, rel, to_dev   # noqa: E402
+from test_oracle import rebuild                          # noqa: E402
+
+
+def _fix(name):
+    return torch.load(os.path.join(GOLD, f"{name}.pt"), weights_only=False)
+
+
+def rel_valid(got, want, mask):
+    """relative distance over the attended positions: the rows of left-padding queries see no key at all and are
+    unspecified in the reference (its eager softmax of an all-masked row), as in test_model_parity"""
+    w = mask.bool().cpu()[..., None]
+    return rel(got.float().cpu() * w, want.float().cpu() * w)
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b"])
+def test_text_only_batch(backend, name):
+    fix = _fix(name)
+    cfg = fix["config"]
+    ora = rebuild(fix, True)
+    m = build(fix, backend, True)
+    ids = fix["batch"]["input_ids"].clone()
+    ids[ids == cfg["dna_token_id"]] = 5                     # plain text: no placeholder rows at all
+    mask = fix["batch"]["attention_mask"]
+    labels = fix["batch"]["labels"]
+    with torch.no_grad():
+        want = ora(input_ids=ids, attention_mask=mask, labels=labels)
+    got = m(input_ids=ids.to(backend), attention_mask=mask.to(backend), labels=labels.to(backend))
+    assert rel_valid(got.logits, want.logits, mask) < 2e-2
+    assert abs(got.loss.item() - want.loss.item()) < 3e-2 * max(1.0, abs(want.loss.item()))
+    # and with the DNA arguments present but empty (reference: `if dna_tokenized is not None and batch_idx_map`)
+    got2 = m(input_ids=ids.to(backend), attention_mask=mask.to(backend), dna_tokenized=None, batch_idx_map=[])
+    assert rel_valid(got2.logits, got.logits, mask) == 0
+
+
+def test_sample_without_dna_among_samples_with_dna(backend):
+    """tiny_a holds two DNA sequences per sample; drop the second sample's sequences: its placeholder rows become text"""
+    fix = _fix("tiny_a")
+    cfg = fix["config"]
+    b = fix["batch"]
+    bim = list(b["batch_idx_map"])
+    keep = [i for i, s in enumerate(bim) if s == 0]
+    assert keep and len(keep) < len(bim)
+    ids = b["input_ids"].clone()
+    ids[1][ids[1] == cfg["dna_token_id"]] = 7
+    dna = {k: v[keep] for k, v in b["dna_tokenized"].items()}
+    ora = rebuild(fix, False)
+    with torch.no_grad():
+        want = ora(input_ids=ids, attention_mask=b["attention_mask"], dna_tokenized=dna, batch_idx_map=[0] * len(keep))
+    m = build(fix, backend, False)
+    got = m(input_ids=ids.to(backend), attention_mask=b["attention_mask"].to(backend),
+            dna_tokenized={k: v.to(backend) for k, v in dna.items()}, batch_idx_map=[0] * len(keep))
+    assert rel_valid(got.logits, want.logits, b["attention_mask"]) < 2e-2
+
+
+@pytest.mark.parametrize("decode_impl", ["fused", "unfused"])
+@pytest.mark.parametrize("row,step", [(0, 7), (1, 2)])
+def test_generate_eos_and_padding(backend, decode_impl, row, step):
+    """Pick as EOS the token the reference's greedy decode emits for `row` first at `step` (tiny_a with adapters:
+    row 0 = 450 x7 then 42.., row 1 = 13 13 170..): that row must stop there and be padded, the other row continues,
+    exactly as HF's unfinished_sequences bookkeeping does."""
+    fix = _fix("tiny_a")
+    cfg = fix["config"]
+    ref_ids = fix["fp32_lora"]["greedy_ids"]
+    eos = int(ref_ids[row, step])
+    assert eos not in ref_ids[row, :step].tolist() and eos not in ref_ids[1 - row].tolist()
+    pad = 1
+    ora = rebuild(fix, True)
+    b = fix["batch"]
+    gb = {k: v for k, v in b.items() if k != "labels"}
+    want = ora.generate(**gb, max_new_tokens=cfg["gen_tokens"], do_sample=False, eos_token_id=eos, pad_token_id=pad)
+    m = build(fix, backend, True)
+    d = to_dev(b, backend)
+    d.pop("labels")
+    got = m.generate(**d, max_new_tokens=cfg["gen_tokens"], do_sample=False, eos_token_id=eos, pad_token_id=pad,
+                     check_every=1, decode_impl=decode_impl)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    g = got.cpu()
+    # the reference's own switch to this token is a near-tie (row 0: 450 -> 42), so the bf16 path may reach it one step
+    # earlier or later (margins are checked in test_greedy_decode_and_logps); the bookkeeping must hold wherever it lands
+    hits = (g[row] == eos).nonzero().flatten().tolist()
+    assert len(hits) == 1 and abs(hits[0] - step) <= 2, (hits, g[row].tolist())
+    assert (g[row, hits[0] + 1:] == pad).all() and (g[row, :hits[0]] != pad).all()
+    assert eos not in g[1 - row].tolist() and pad not in g[1 - row].tolist()
+    assert int((g[1 - row] != want[1 - row]).sum()) <= 2
