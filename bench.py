@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: 2.5 PF dense; 5 PF is 2:1 sparse)
 SD, TEXT_LEN, NDNA, G, C = 1024, 128, 2, 8, 256
+LORA_DROPOUT = 0.05          # reason.py:266 / train_dna_qwen.py:1038
 
 
 def flops_per_sample():
@@ -59,7 +60,7 @@ def cpu_baseline(max_seconds: float = 60.0):
     for mdl in (text, dna):
         for p in mdl.parameters():
             p.data.uniform_(-0.03, 0.03, generator=g) if p.dim() >= 2 else p.data.fill_(1.0)
-    O.apply_lora(text, r=32, alpha=64.0)
+    O.apply_lora(text, r=32, alpha=64.0, dropout=LORA_DROPOUT)      # reason.py:266 lora_dropout; active in the policy pass (train mode)
     for n, p in text.named_parameters():
         if "lora_" in n:
             p.data = p.data.to(torch.bfloat16)
@@ -139,6 +140,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="issue the rollout's decode steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-shared-decode", action="store_true", help="per-copy prompt K/V in the decode attention")
     ap.add_argument("--completion-len", type=int, default=C)
+    ap.add_argument("--lora-dropout", type=float, default=LORA_DROPOUT, help="PEFT lora_dropout of the policy pass (reference: 0.05)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the oracle timing leg and print its JSON")
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -164,7 +166,8 @@ def main():
     model = DNALLMModel(configs.qwen3_config(), configs.nt_v2_config(), device=dev)
     model.text_model.init_weights(0.02, seed=1)          # random-init weights of the real architectures (same on every rank)
     model.dna_model.init_weights(0.02, seed=2)
-    model.text_model.apply_lora(r=32, alpha=64.0, dropout=0.0, arena=model.arena)
+    model.text_model.apply_lora(r=32, alpha=64.0, dropout=args.lora_dropout, arena=model.arena)
+    model.train()                                        # HF Trainer.training_step: the policy forward / backward runs in train mode
     gen = torch.Generator().manual_seed(7)
     for n, p in model.text_model.named_parameters():     # non-zero LoRA B so the adapter path carries signal
         if "lora_B" in n:
@@ -208,9 +211,9 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "GRPO step cfg-3: NT-v2-500M encoder + Qwen3-1.7B (LoRA r=32 all linears + dna_projection), "
+            "config": {"workload": "GRPO step cfg-3: NT-v2-500M encoder + Qwen3-1.7B (LoRA r=32 dropout %g all linears + dna_projection), "
                                    "1 prompt x G=8 per GPU, P=2180, C=%d sampled tokens (T=0.6, top-k 20, top-p 0.95), "
-                                   "ref logps + policy fwd/bwd + AdamW; random-init weights" % args.completion_len,
+                                   "ref logps + policy fwd/bwd + AdamW; random-init weights" % (args.lora_dropout, args.completion_len),
                        "global_batch": world * G, "prompt_len": 2180, "completion_len": args.completion_len, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": prof["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": prof["tflops"] / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(),

@@ -1,0 +1,209 @@
+// k_lora.hip — the LoRA branch under training-mode dropout (PEFT: y += (alpha/r) * B(A(dropout(x))), lora_dropout = 0.05,
+// train_dna_qwen.py:155-167, reason.py:266,376-388).  PEFT gives every target module its own nn.Dropout, so the q / k / v
+// (and gate / up) adapters that share an input x see INDEPENDENT masks; the fused projections here therefore carry one
+// mask stream per 32-column rank block.  Masks are never stored: keep(seed, m, k) is a counter-based hash of the element
+// index, recomputed wherever the masked operand is needed —
+//   lora_down_drop   t[m, r]   = s * sum_k keep_j(m,k)/(1-p) x[m,k] A[r,k]            (forward, replaces the x A^T GEMM)
+//   lora_up_drop     dxl[m, k] = sum_j keep_j(m,k)/(1-p) sum_{r in j} dts[m,r] A[r,k]  (backward, the branch's input gradient)
+//   wgrad_tn (DROP)  dA[r, k] += sum_m dts[m,r] keep_j(m,k)/(1-p) x[m,k]               (k_wgrad.hip)
+// with j = r / 32.  torch's dropout scales in fp32 and rounds once to bf16; so does drop_apply8.
+#include "bra_device.h"
+#include "bra_api_internal.h"
+#include "bra_dropout.h"
+
+namespace bra {
+
+struct LoraDownArgs {
+    const bf16_t* x; long ldx;      // [M, K]
+    const bf16_t* A; long lda;      // [R, K]
+    bf16_t* t; long ldt;            // [M, R]
+    int M, K, R;
+    float alpha;
+    DropCfg d;
+};
+
+// workgroup = 64 rows of x (2 waves x 32) against all R = 32 RB adapter rows; K in steps of 64 through LDS
+template <int RB>
+__global__ __launch_bounds__(128) void lora_down_drop_kernel(LoraDownArgs g) {
+    constexpr int XP = 64 + 8;
+    __shared__ bf16_t xs[2][64 * XP];
+    __shared__ bf16_t as[2][32 * RB * XP];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int m0 = (int)blockIdx.x * 64;
+    const int nstep = (g.K + 63) / 64;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    u32x4 rx[4], ra[2 * RB];
+    auto issue = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 128 * i, row = c >> 3, k = 64 * s + 8 * (c & 7);
+            int m = m0 + row; m = m < g.M ? m : g.M - 1;
+            const u32x4 v = ld16(g.x + (long)m * g.ldx + (k < g.K ? k : 0));
+            rx[i] = k < g.K ? v : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * RB; ++i) {
+            const int c = tid + 128 * i, row = c >> 3, k = 64 * s + 8 * (c & 7);
+            const u32x4 v = ld16(g.A + (long)(row < g.R ? row : g.R - 1) * g.lda + (k < g.K ? k : 0));
+            ra[i] = (k < g.K && row < g.R) ? v : zero4;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int c = tid + 128 * i; st16(&xs[buf][(c >> 3) * XP + 8 * (c & 7)], rx[i]); }
+#pragma unroll
+        for (int i = 0; i < 2 * RB; ++i) { const int c = tid + 128 * i; st16(&as[buf][(c >> 3) * XP + 8 * (c & 7)], ra[i]); }
+    };
+    f32x16 acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[rb][q] = 0.f;
+    issue(0); commit(0);
+    __syncthreads();
+    const int mrow = m0 + 32 * wave + (lane & 31);               // this lane's row of x (A-operand row)
+    for (int s = 0; s < nstep; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstep) issue(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const u32x4 xf = ld16(&xs[buf][(32 * wave + (lane & 31)) * XP + 16 * kk + 8 * h]);
+            const uint32_t e0 = (uint32_t)mrow * (uint32_t)g.K + (uint32_t)(64 * s + 16 * kk + 8 * h);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const u32x4 af = drop_apply8(xf, g.d.seed[rb], e0, g.d.thr16, g.d.inv_keep);
+                const u32x4 bf = ld16(&as[buf][(32 * rb + (lane & 31)) * XP + 16 * kk + 8 * h]);
+                acc[rb] = mfma_32x32x16(af, bf, acc[rb]);
+            }
+        }
+        if (s + 1 < nstep) commit(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int r = 32 * rb + (lane & 31);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (m < g.M && r < g.R) g.t[(long)m * g.ldt + r] = f2bf(g.alpha * acc[rb][q]);
+        }
+    }
+}
+
+struct LoraUpArgs {
+    const bf16_t* dts; long ldd;    // [M, R]
+    const bf16_t* AT; long ldat;    // [K, R]  (A transposed: row = input feature k)
+    bf16_t* out; long ldo;          // [M, K]
+    int M, K, R;
+    int k_chunk;                    // columns per workgroup (multiple of 32)
+    DropCfg d;
+};
+
+// wave = 32 rows of dts, walks 32-column tiles of the output; rank-32 product per target, masked, summed over targets
+template <int RB>
+__global__ __launch_bounds__(256) void lora_up_drop_kernel(LoraUpArgs g) {
+    const int lane = lane_id(), wave = (int)threadIdx.x >> 6, h = lane >> 5;
+    const int m_base = ((int)blockIdx.x * 4 + wave) * 32;
+    if (m_base >= g.M) return;
+    int mr = m_base + (lane & 31); mr = mr < g.M ? mr : g.M - 1;
+    u32x4 df[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) df[rb][c] = ld16(g.dts + (long)mr * g.ldd + 32 * rb + 16 * c + 8 * h);
+    const int k_lo = (int)blockIdx.y * g.k_chunk;
+    int k_hi = k_lo + g.k_chunk; k_hi = k_hi < g.K ? k_hi : g.K;
+    for (int k0 = k_lo; k0 < k_hi; k0 += 32) {
+        const int kc = k0 + (lane & 31);
+        const int kr = kc < g.K ? kc : g.K - 1;
+        u32x4 af[RB][2];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) af[rb][c] = ld16(g.AT + (long)kr * g.ldat + 32 * rb + 16 * c + 8 * h);
+        float o[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o[q] = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            acc = mfma_32x32x16(df[rb][0], af[rb][0], acc);
+            acc = mfma_32x32x16(df[rb][1], af[rb][1], acc);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m_base + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const uint32_t idx = (uint32_t)m * (uint32_t)g.K + (uint32_t)kr;
+                o[q] += drop_keep1(g.d.seed[rb], idx, g.d.thr16) ? acc[q] : 0.f;
+            }
+        }
+        if (kc < g.K) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m_base + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (m < g.M) g.out[(long)m * g.ldo + kc] = f2bf(o[q] * g.d.inv_keep);
+            }
+        }
+    }
+}
+
+// mask image for tests / for injecting the same masks into the oracle: out[m, k] = keep(seed, m, k) as 0 / 1 bytes
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* out, long n, uint32_t seed, uint32_t thr16) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = drop_keep1(seed, (uint32_t)i, thr16) ? 1 : 0;
+}
+
+}  // namespace bra
+
+using namespace bra;
+
+static DropCfg make_cfg(float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3) {
+    DropCfg d;
+    d.thr16 = drop_threshold(p);
+    d.inv_keep = 1.f / (1.f - p);
+    d.seed[0] = s0; d.seed[1] = s1; d.seed[2] = s2; d.seed[3] = s3;
+    return d;
+}
+
+extern "C" int bra_lora_down_drop(const void* x, long ldx, const void* A, long lda, void* t, long ldt, int M, int K, int R,
+                                  float alpha, float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, void* stream) {
+    if (M == 0) return 0;
+    if (!x || !A || !t || M < 0 || K <= 0 || K % 8 || ldx % 8 || lda % 8 || (R != 32 && R != 64 && R != 128)) return BRA_ERR_ARG;
+    if (!(p >= 0.f && p < 1.f) || (long)M * K >= (1l << 32)) return BRA_ERR_ARG;
+    LoraDownArgs g = {(const bf16_t*)x, ldx, (const bf16_t*)A, lda, (bf16_t*)t, ldt, M, K, R, alpha, make_cfg(p, s0, s1, s2, s3)};
+    const dim3 grid((M + 63) / 64);
+    bra_stream_t st = (bra_stream_t)stream;
+    if (R == 32) BRA_LAUNCH((lora_down_drop_kernel<1>), grid, dim3(128), 0, st, g);
+    else if (R == 64) BRA_LAUNCH((lora_down_drop_kernel<2>), grid, dim3(128), 0, st, g);
+    else BRA_LAUNCH((lora_down_drop_kernel<4>), grid, dim3(128), 0, st, g);
+    return BRA_LAUNCH_STATUS();
+}
+
+extern "C" int bra_lora_up_drop(const void* dts, long ldd, const void* AT, long ldat, void* out, long ldo, int M, int K, int R,
+                                float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, void* stream) {
+    if (M == 0) return 0;
+    if (!dts || !AT || !out || M < 0 || K <= 0 || ldd % 8 || ldat % 8 || (R != 32 && R != 64 && R != 128)) return BRA_ERR_ARG;
+    if (!(p >= 0.f && p < 1.f) || (long)M * K >= (1l << 32)) return BRA_ERR_ARG;
+    const int mblk = (M + 127) / 128;
+    int splits = (1024 + mblk - 1) / mblk;                       // enough workgroups to fill the chip
+    int k_chunk = ((K + splits - 1) / splits + 31) / 32 * 32;
+    k_chunk = k_chunk < 128 ? 128 : k_chunk;
+    LoraUpArgs g = {(const bf16_t*)dts, ldd, (const bf16_t*)AT, ldat, (bf16_t*)out, ldo, M, K, R, k_chunk, make_cfg(p, s0, s1, s2, s3)};
+    const dim3 grid(mblk, (K + k_chunk - 1) / k_chunk);
+    bra_stream_t st = (bra_stream_t)stream;
+    if (R == 32) BRA_LAUNCH((lora_up_drop_kernel<1>), grid, dim3(256), 0, st, g);
+    else if (R == 64) BRA_LAUNCH((lora_up_drop_kernel<2>), grid, dim3(256), 0, st, g);
+    else BRA_LAUNCH((lora_up_drop_kernel<4>), grid, dim3(256), 0, st, g);
+    return BRA_LAUNCH_STATUS();
+}
+
+extern "C" int bra_dropout_mask(void* out, int M, int K, float p, unsigned seed, void* stream) {
+    if (M <= 0 || K <= 0) return 0;
+    if (!out || !(p >= 0.f && p < 1.f) || (long)M * K >= (1l << 32)) return BRA_ERR_ARG;
+    const long n = (long)M * K;
+    long grid = (n + 255) / 256; grid = grid > 4096 ? 4096 : grid;
+    BRA_LAUNCH(dropout_mask_kernel, dim3((unsigned)grid), dim3(256), 0, (bra_stream_t)stream, (uint8_t*)out, n, (uint32_t)seed,
+               drop_threshold(p));
+    return BRA_LAUNCH_STATUS();
+}

@@ -9,6 +9,7 @@
 // streaming Y once from HBM (≈16 FLOP per byte).
 #include "bra_device.h"
 #include "bra_api_internal.h"
+#include "bra_dropout.h"
 
 namespace bra {
 
@@ -19,12 +20,13 @@ struct WgradArgs {
     int M, N, R;
     int m_chunk;                    // rows of m per workgroup (multiple of 32)
     float alpha;
+    DropCfg d;                      // DROP: Y is used as keep_rb(m, n) / (1 - p) * Y[m, n], one mask stream per rank block
 };
 
 constexpr int WG_YP = 128 + 8;      // LDS row pitch of the Y tile (elements): 272 bytes, odd multiple of 16
 
 // one workgroup: 128 columns of Y x all R, over m in [blockIdx.y * m_chunk, + m_chunk); 4 waves x 32 columns
-template <int RB>
+template <int RB, int DROP>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
     __shared__ bf16_t ys[2][32 * WG_YP];
     constexpr int WG_TP = 32 * RB + 8, TPT = RB >= 2 ? RB / 2 : 1;      // T tile pitch; 16-byte chunks per thread
@@ -88,9 +90,22 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 a[j] = (uint32_t)ys[buf][(mb + 2 * j) * WG_YP + ncol] | ((uint32_t)ys[buf][(mb + 2 * j + 1) * WG_YP + ncol] << 16);
-            const u32x4 af = {a[0], a[1], a[2], a[3]};
+            const u32x4 af0 = {a[0], a[1], a[2], a[3]};
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
+                u32x4 af = af0;
+                if (DROP) {
+                    // the lane's 8 elements run down a column of Y: indices (m_g + i) * N + n_g, one hash each
+                    const uint32_t n_g = (uint32_t)(n0 + ncol);
+                    const uint32_t m_g = (uint32_t)(m_lo + 32 * s + mb);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t i0 = (m_g + 2 * j) * (uint32_t)g.N + n_g, i1 = i0 + (uint32_t)g.N;
+                        const float lo = drop_keep1(g.d.seed[rb], i0, g.d.thr16) ? bf_lo(a[j]) * g.d.inv_keep : 0.f;
+                        const float hi = drop_keep1(g.d.seed[rb], i1, g.d.thr16) ? bf_hi(a[j]) * g.d.inv_keep : 0.f;
+                        af[j] = pack_bf2(lo, hi);
+                    }
+                }
                 const int rc = rb * 32 + (lane & 31);
                 uint32_t b[4];
 #pragma unroll
@@ -121,22 +136,45 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
 
 using namespace bra;
 
+static int wgrad_launch(WgradArgs& g, int m_chunk, bool drop, void* stream) {
+    if (m_chunk <= 0) {
+        // enough workgroups to fill the chip twice, at least 256 rows each
+        const int ntile = (g.N + 127) / 128;
+        int splits = (512 + ntile - 1) / ntile;
+        m_chunk = (g.M + splits - 1) / splits;
+        m_chunk = m_chunk < 256 ? 256 : m_chunk;
+    }
+    g.m_chunk = (m_chunk + 31) / 32 * 32;
+    const dim3 grid((g.N + 127) / 128, (g.M + g.m_chunk - 1) / g.m_chunk);
+    bra_stream_t st = (bra_stream_t)stream;
+#define BRA_WG(RB_)                                                                          \
+    do {                                                                                     \
+        if (drop) BRA_LAUNCH((wgrad_tn_kernel<RB_, 1>), grid, dim3(256), 0, st, g);          \
+        else BRA_LAUNCH((wgrad_tn_kernel<RB_, 0>), grid, dim3(256), 0, st, g);               \
+    } while (0)
+    if (g.R == 32) BRA_WG(1); else if (g.R == 64) BRA_WG(2); else BRA_WG(4);
+#undef BRA_WG
+    return BRA_LAUNCH_STATUS();
+}
+
 extern "C" int bra_wgrad_tn(const void* Y, long ldy, const void* T, long ldt, float* C, long c_sn, long c_sr, int M, int N,
                             int R, float alpha, int m_chunk, void* stream) {
     if (M == 0 || N == 0) return 0;
     if (!Y || !T || !C || M < 0 || N < 0 || N % 8 || ldy % 8 || ldt % 8 || (R != 32 && R != 64 && R != 128)) return BRA_ERR_ARG;
-    if (m_chunk <= 0) {
-        // enough workgroups to fill the chip twice, at least 256 rows each
-        const int ntile = (N + 127) / 128;
-        int splits = (512 + ntile - 1) / ntile;
-        m_chunk = (M + splits - 1) / splits;
-        m_chunk = m_chunk < 256 ? 256 : m_chunk;
-    }
-    m_chunk = (m_chunk + 31) / 32 * 32;
-    WgradArgs g = {(const bf16_t*)Y, ldy, (const bf16_t*)T, ldt, C, c_sn, c_sr, M, N, R, m_chunk, alpha};
-    const dim3 grid((N + 127) / 128, (M + m_chunk - 1) / m_chunk);
-    if (R == 32) BRA_LAUNCH((wgrad_tn_kernel<1>), grid, dim3(256), 0, (bra_stream_t)stream, g);
-    else if (R == 64) BRA_LAUNCH((wgrad_tn_kernel<2>), grid, dim3(256), 0, (bra_stream_t)stream, g);
-    else BRA_LAUNCH((wgrad_tn_kernel<4>), grid, dim3(256), 0, (bra_stream_t)stream, g);
-    return BRA_LAUNCH_STATUS();
+    WgradArgs g = {(const bf16_t*)Y, ldy, (const bf16_t*)T, ldt, C, c_sn, c_sr, M, N, R, 0, alpha, {}};
+    return wgrad_launch(g, m_chunk, false, stream);
+}
+
+// the same with Y masked per rank block: dA of a LoRA branch whose input went through dropout (k_lora.hip)
+extern "C" int bra_wgrad_tn_drop(const void* Y, long ldy, const void* T, long ldt, float* C, long c_sn, long c_sr, int M,
+                                 int N, int R, float alpha, int m_chunk, float p, unsigned s0, unsigned s1, unsigned s2,
+                                 unsigned s3, void* stream) {
+    if (M == 0 || N == 0) return 0;
+    if (!Y || !T || !C || M < 0 || N < 0 || N % 8 || ldy % 8 || ldt % 8 || (R != 32 && R != 64 && R != 128)) return BRA_ERR_ARG;
+    if (!(p >= 0.f && p < 1.f) || (long)M * N >= (1l << 32)) return BRA_ERR_ARG;
+    WgradArgs g = {(const bf16_t*)Y, ldy, (const bf16_t*)T, ldt, C, c_sn, c_sr, M, N, R, 0, alpha, {}};
+    g.d.thr16 = drop_threshold(p);
+    g.d.inv_keep = 1.f / (1.f - p);
+    g.d.seed[0] = s0; g.d.seed[1] = s1; g.d.seed[2] = s2; g.d.seed[3] = s3;
+    return wgrad_launch(g, m_chunk, true, stream);
 }

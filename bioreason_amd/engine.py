@@ -110,6 +110,27 @@ class SeqMeta:
     kmask: Optional[torch.Tensor]     # uint8 [B, S] or None
     lora_on: bool = True
     max_pos: int = 0                  # largest rotary position + 1 (0 -> S)
+    drop_p: float = 0.0               # LoRA dropout probability of this pass (training mode only) ...
+    drop_seed: int = 0                # ... and the 32-bit seed its mask streams derive from
+
+
+def _mix32(a: int, b: int) -> int:
+    h = (a * 0x9E3779B1 + b * 0x85EBCA6B + 0x165667B1) & 0xFFFFFFFF
+    h ^= h >> 15
+    h = (h * 0x2C1B3C6D) & 0xFFFFFFFF
+    h ^= h >> 12
+    h = (h * 0x297A2D39) & 0xFFFFFFFF
+    h ^= h >> 15
+    return h
+
+
+LORA_GROUP_INDEX = {"qkv": 0, "o": 1, "gu": 2, "d": 3}
+
+
+def lora_drop_seeds(pass_seed: int, layer: int, group: str, n_targets: int):
+    """mask-stream seeds of the targets of one fused projection (PEFT: one nn.Dropout per target module)"""
+    base = (layer * 4 + LORA_GROUP_INDEX[group]) * 4
+    return [_mix32(pass_seed, base + j) for j in range(n_targets)]
 
 
 class QwenEngine:
@@ -151,24 +172,39 @@ class QwenEngine:
             self.ET = ops.transpose2d(self.E)
 
     @staticmethod
-    def _lora_fwd(x2d, W, G: Optional[LoraGroup], on: bool, res=None, out=None):
-        """y = x W^T (+ (s x A^T) B^T) (+res); returns (y, t)"""
+    def _lora_fwd(x2d, W, G: Optional[LoraGroup], on: bool, res=None, out=None, drop=None):
+        """y = x W^T (+ (s dropout(x) A^T) B^T) (+res); returns (y, t).  drop = (p, seeds per target) in training mode"""
         if G is not None and on:
-            t = ops.gemm_nt(x2d, G.A, alpha=G.scaling)
+            if drop is not None:
+                t = ops.lora_down_drop(x2d, G.A, G.scaling, drop[0], drop[1])
+            else:
+                t = ops.gemm_nt(x2d, G.A, alpha=G.scaling)
             return ops.gemm_nt(x2d, W, a2=t, b2=G.B, res=res, out=out), t
         return ops.gemm_nt(x2d, W, res=res, out=out), None
 
     @staticmethod
-    def _lora_bwd(dy, WT, G: Optional[LoraGroup], on: bool, x2d, t):
-        """dx = dy W (+ s (dy B) A); accumulates dA, dB into the arena."""
+    def _lora_bwd(dy, WT, G: Optional[LoraGroup], on: bool, x2d, t, drop=None):
+        """dx = dy W (+ dropout'(s (dy B) A)); accumulates dA, dB into the arena."""
         if G is not None and on:
             dts = ops.gemm_nt(dy, G.BT, alpha=G.scaling)                 # [T, r_pad] = s * dy B
-            dx = ops.gemm_nt(dy, WT, a2=dts, b2=G.AT)
+            if drop is not None:
+                dxl = ops.lora_up_drop(dts, G.AT, drop[0], drop[1])      # the branch's input gradient, masked per target
+                dx = ops.gemm_nt(dy, WT, res=dxl)
+            else:
+                dx = ops.gemm_nt(dy, WT, a2=dts, b2=G.AT)
             # weight gradients straight from the row-major activations (k_wgrad.hip): no transposed copies in HBM
             ops.wgrad_tn(dy, t, G.B_grad)                                # dB [N, r] += dy^T t      (t already holds s)
-            ops.wgrad_tn(x2d, dts, G.A_grad, transposed_out=True)        # dA [r, K] += (s dy B)^T x
+            ops.wgrad_tn(x2d, dts, G.A_grad, transposed_out=True, drop=drop)   # dA [r, K] += (s dy B)^T dropout(x)
             return dx
         return ops.gemm_nt(dy, WT)
+
+    def _drop(self, m: "SeqMeta", li: int, group: str):
+        G = self.layers[li].lora[group]
+        if G is None or not m.lora_on or m.drop_p <= 0.0:
+            return None
+        if G.r != 32:
+            raise NotImplementedError("LoRA dropout needs r = 32 (one mask stream per 32-column rank block)")
+        return (m.drop_p, lora_drop_seeds(m.drop_seed, li, group, len(G.n_sizes)))
 
     # ------------------------------------------------------------------ one decoder layer
     def layer_fwd(self, li: int, x: torch.Tensor, m: SeqMeta, save: bool, kv_out=None):
@@ -178,7 +214,7 @@ class QwenEngine:
         B, S, T = m.B, m.S, m.B * m.S
         cosT, sinT = self.rope(m.max_pos or m.S)
         xn = ops.rmsnorm_fwd(x, L.ln1, self.eps)
-        qkv, t1 = self._lora_fwd(xn, L.Wqkv, L.lora["qkv"], m.lora_on)
+        qkv, t1 = self._lora_fwd(xn, L.Wqkv, L.lora["qkv"], m.lora_on, drop=self._drop(m, li, "qkv"))
         q = torch.empty((B, S, self.Hq, self.hd), dtype=BF16, device=x.device)
         if kv_out is None:
             k = torch.empty((B, S, self.Hkv, self.hd), dtype=BF16, device=x.device)
@@ -195,11 +231,11 @@ class QwenEngine:
             kv_out[3].append(vt)                                          # the prompt's V^T image, kept for shared-prefix decode
         o, lse = ops.attn_fwd(q, k, vt, m.kmask, True, self.scale, need_lse=save)
         o2 = o.view(T, self.Nq)
-        h, t2 = self._lora_fwd(o2, L.Wo, L.lora["o"], m.lora_on, res=x)
+        h, t2 = self._lora_fwd(o2, L.Wo, L.lora["o"], m.lora_on, res=x, drop=self._drop(m, li, "o"))
         hn = ops.rmsnorm_fwd(h, L.ln2, self.eps)
-        gu, t3 = self._lora_fwd(hn, L.Wgu, L.lora["gu"], m.lora_on)
+        gu, t3 = self._lora_fwd(hn, L.Wgu, L.lora["gu"], m.lora_on, drop=self._drop(m, li, "gu"))
         act = ops.swiglu_fwd(gu)
-        y, t4 = self._lora_fwd(act, L.Wd, L.lora["d"], m.lora_on, res=h)
+        y, t4 = self._lora_fwd(act, L.Wd, L.lora["d"], m.lora_on, res=h, drop=self._drop(m, li, "d"))
         saved = (x, xn, t1, qkv, q, k, v, o, lse, t2, h, hn, t3, gu, act, t4) if save else None
         return y, saved
 
@@ -209,14 +245,14 @@ class QwenEngine:
         B, S, T = m.B, m.S, m.B * m.S
         cosT, sinT = self.rope(m.max_pos or m.S)
         on = m.lora_on
-        dact = self._lora_bwd(dy, L.WdT, L.lora["d"], on, act, t4)
+        dact = self._lora_bwd(dy, L.WdT, L.lora["d"], on, act, t4, drop=self._drop(m, li, "d"))
         dgu = ops.swiglu_bwd(gu, dact)
-        dhn = self._lora_bwd(dgu, L.WguT, L.lora["gu"], on, hn, t3)
+        dhn = self._lora_bwd(dgu, L.WguT, L.lora["gu"], on, hn, t3, drop=self._drop(m, li, "gu"))
         dh = ops.rmsnorm_bwd(dhn, h, L.ln2, self.eps, dres=dy)             # + residual branch
-        do = self._lora_bwd(dh, L.WoT, L.lora["o"], on, o.view(T, self.Nq), t2)
+        do = self._lora_bwd(dh, L.WoT, L.lora["o"], on, o.view(T, self.Nq), t2, drop=self._drop(m, li, "o"))
         dq, dk, dv = ops.attn_bwd(q, k, v, o, do.view(B, S, self.Hq, self.hd), lse, m.kmask, True, self.scale)
         dqkv = ops.qk_norm_rope_bwd(qkv, L.qn, L.kn, cosT, sinT, m.pos, S, self.Hq, self.Hkv, self.hd, self.eps, 1.0, dq, dk, dv)
-        dxn = self._lora_bwd(dqkv, L.WqkvT, L.lora["qkv"], on, xn, t1)
+        dxn = self._lora_bwd(dqkv, L.WqkvT, L.lora["qkv"], on, xn, t1, drop=self._drop(m, li, "qkv"))
         return ops.rmsnorm_bwd(dxn, x, L.ln1, self.eps, dres=dh)
 
     # ------------------------------------------------------------------ stack

@@ -273,8 +273,11 @@ class Qwen3ForCausalLM(nn.Module):
                    arena: Optional[TrainableArena] = None, init_seed: int = 0):
         """PEFT get_peft_model(text_model, LoraConfig(r, lora_alpha, lora_dropout, target_modules,
         init_lora_weights="gaussian")) on the text model (train_dna_qwen.py:155-167)."""
-        if dropout != 0.0:
-            raise NotImplementedError("lora_dropout > 0 is not implemented in the HIP path yet (DESIGN.md, gaps)")
+        if dropout < 0.0 or dropout >= 1.0:
+            raise ValueError("lora_dropout must be in [0, 1)")
+        if dropout > 0.0 and r != 32:
+            raise NotImplementedError("lora_dropout > 0 needs r = 32 in the HIP path (one mask stream per 32-column rank block)")
+        self.lora_dropout_p = float(dropout)      # active in training mode with adapters enabled (nn.Dropout of PEFT's LoraLayer)
         dev = self.device
         self.arena = arena or self.arena or TrainableArena(dev)
         self.ensure_packed()
@@ -328,6 +331,11 @@ class Qwen3ForCausalLM(nn.Module):
             self._lora_enabled = prev
 
     # ---- forward --------------------------------------------------------------------------------------------
+    def set_dropout_seed(self, seed: int) -> None:
+        """base seed of the LoRA dropout masks (per-pass seeds derive from it and a call counter, which is reset)"""
+        self._dropout_seed = int(seed) & 0xFFFFFFFF
+        self._dropout_calls = 0
+
     def hidden_states(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor],
                       position_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[B,S,H] embeddings -> final-normed hidden states [B*S, H] (differentiable)."""
@@ -344,6 +352,13 @@ class Qwen3ForCausalLM(nn.Module):
             max_pos = self.config.max_position_embeddings
         kmask = None if attention_mask is None else attention_mask.to(torch.uint8).contiguous()
         meta = SeqMeta(B=B, S=S, pos=pos, kmask=kmask, lora_on=self._lora_enabled, max_pos=max_pos)
+        p_drop = getattr(self, "lora_dropout_p", 0.0)
+        if p_drop > 0.0 and self.training and self._lora_enabled:
+            # a fresh set of masks per forward pass, as nn.Dropout draws; the backward of THIS pass regenerates them from
+            # the seed kept in `meta` (counter-based hash, no stored masks)
+            self._dropout_calls = getattr(self, "_dropout_calls", 0) + 1
+            meta.drop_p = p_drop
+            meta.drop_seed = (getattr(self, "_dropout_seed", 0x5EED) * 0x9E3779B1 + self._dropout_calls * 0x85EBCA6B) & 0xFFFFFFFF
         x = inputs_embeds.reshape(B * S, H)
         if x.dtype != BF16:
             x = x.to(BF16)

@@ -121,13 +121,48 @@ def gemm_nt_splitk(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: f
 
 
 def wgrad_tn(y: torch.Tensor, t: torch.Tensor, out: torch.Tensor, transposed_out: bool = False, alpha: float = 1.0,
-             m_chunk: int = 0) -> torch.Tensor:
-    """out += alpha * y^T t from row-major y [M, N], t [M, R]: out [N, R], or [R, N] with transposed_out"""
+             m_chunk: int = 0, drop=None) -> torch.Tensor:
+    """out += alpha * y^T t from row-major y [M, N], t [M, R]: out [N, R], or [R, N] with transposed_out.
+    drop = (p, seeds): y is used as dropout_rb(y), one mask stream per 32 columns of t."""
     M, N = y.shape
     R = t.shape[1]
     assert t.shape[0] == M and out.dtype == torch.float32 and out.shape == ((R, N) if transposed_out else (N, R))
     c_sn, c_sr = (1, _ld(out)) if transposed_out else (_ld(out), 1)
+    if drop is not None:
+        get_lib().call("bra_wgrad_tn_drop", y, _ld(y), t, _ld(t), out, c_sn, c_sr, M, N, R, alpha, m_chunk, drop[0],
+                       *_seeds4(drop[1]), current_stream(y))
+        return out
     get_lib().call("bra_wgrad_tn", y, _ld(y), t, _ld(t), out, c_sn, c_sr, M, N, R, alpha, m_chunk, current_stream(y))
+    return out
+
+
+def _seeds4(seeds):
+    s = [int(x) & 0xFFFFFFFF for x in seeds] + [0, 0, 0, 0]
+    return s[:4]
+
+
+def dropout_mask(M: int, K: int, p: float, seed: int, device) -> torch.Tensor:
+    """keep mask (uint8 [M, K]) of one dropout stream — the mask the LoRA kernels regenerate on the fly"""
+    out = torch.empty((M, K), dtype=torch.uint8, device=device)
+    get_lib().call("bra_dropout_mask", out, M, K, p, int(seed) & 0xFFFFFFFF, current_stream(out))
+    return out
+
+
+def lora_down_drop(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, seeds) -> torch.Tensor:
+    """t [M, R] = alpha * dropout_j(x) A^T with one mask stream per 32 rows of A (PEFT: per target module)"""
+    M, K = x.shape
+    R = A.shape[0]
+    t = torch.empty((M, R), dtype=BF16, device=x.device)
+    get_lib().call("bra_lora_down_drop", x, _ld(x), A, _ld(A), t, _ld(t), M, K, R, alpha, p, *_seeds4(seeds), current_stream(x))
+    return t
+
+
+def lora_up_drop(dts: torch.Tensor, AT: torch.Tensor, p: float, seeds) -> torch.Tensor:
+    """[M, K] = sum_j dropout_j'(dts[:, block j] A[block j, :]): input gradient of the LoRA branch (AT = A^T [K, R])"""
+    M, R = dts.shape
+    K = AT.shape[0]
+    out = torch.empty((M, K), dtype=BF16, device=dts.device)
+    get_lib().call("bra_lora_up_drop", dts, _ld(dts), AT, _ld(AT), out, _ld(out), M, K, R, p, *_seeds4(seeds), current_stream(dts))
     return out
 
 

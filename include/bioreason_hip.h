@@ -57,6 +57,22 @@ int bra_gemm_bf16_nt_splitk(const void* A, long lda, const void* B, long ldb, vo
 int bra_wgrad_tn(const void* Y, long ldy, const void* T, long ldt, float* C, long c_sn, long c_sr, int M, int N, int R,
                  float alpha, int m_chunk, void* stream);
 
+/* LoRA branch under training-mode dropout (k_lora.hip; PEFT: y += (alpha/r) B(A(dropout(x))), lora_dropout 0.05,
+ * reason.py:266,376-388).  Every 32-column rank block (= target module of a fused projection) has its own mask stream
+ * s0..s3, as PEFT gives every target its own nn.Dropout; keep(seed, m, k) is a hash of the element index m*K + k, so no
+ * mask is stored.  R in {32, 64, 128}; M*K < 2^32.
+ *   bra_lora_down_drop: t[M,R] = alpha * (drop_j(x) A^T)              x [M,K], A [R,K]
+ *   bra_lora_up_drop:   out[M,K] = sum_j drop_j'( dts[:, j] A[j, :] )  dts [M,R], AT [K,R]   (input gradient of the branch)
+ *   bra_wgrad_tn_drop:  bra_wgrad_tn with Y = drop_rb(Y)               (dA of the branch)
+ *   bra_dropout_mask:   out[M,K] bytes = keep(seed, m, k)              (tests: inject the same masks into the oracle) */
+int bra_lora_down_drop(const void* x, long ldx, const void* A, long lda, void* t, long ldt, int M, int K, int R, float alpha,
+                       float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, void* stream);
+int bra_lora_up_drop(const void* dts, long ldd, const void* AT, long ldat, void* out, long ldo, int M, int K, int R, float p,
+                     unsigned s0, unsigned s1, unsigned s2, unsigned s3, void* stream);
+int bra_wgrad_tn_drop(const void* Y, long ldy, const void* T, long ldt, float* C, long c_sn, long c_sr, int M, int N, int R,
+                      float alpha, int m_chunk, float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, void* stream);
+int bra_dropout_mask(void* out, int M, int K, float p, unsigned seed, void* stream);
+
 /* Fused lm_head + log-softmax statistics WITHOUT materialising logits
  * (grpo_trainer.py:510-520 `_get_per_token_logps`; TF:loss/loss_utils.py:49-71 ForCausalLMLoss):
  * for every row m of H[M,K] (bf16) against E[V,K]: per 64-column chunk running max and sum-exp of the

@@ -98,3 +98,72 @@ def test_generate_eos_and_padding(backend, decode_impl, row, step):
     assert (g[row, hits[0] + 1:] == pad).all() and (g[row, :hits[0]] != pad).all()
     assert eos not in g[1 - row].tolist() and pad not in g[1 - row].tolist()
     assert int((g[1 - row] != want[1 - row]).sum()) <= 2
+
+
+class _FixedMask(torch.nn.Module):
+    """stands in for a LoraLayer's nn.Dropout with a given keep mask: x * mask / (1 - p)"""
+
+    def __init__(self, mask, p):
+        super().__init__()
+        self.mask, self.p = mask, p
+
+    def forward(self, x):
+        return x * self.mask.to(x.dtype).view(x.shape) / (1.0 - self.p)
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b"])
+def test_lora_dropout_matches_oracle_under_the_same_masks(backend, name):
+    """training-mode LoRA dropout (reason.py:266: lora_dropout 0.05; here 0.2 for signal): every target module has its own
+    mask stream, as PEFT's per-layer nn.Dropout; the masks the HIP kernels regenerate on the fly are exported and injected
+    into the oracle, whose loss, logits and LoRA / projection gradients must then agree as in test_forward_backward"""
+    from bioreason_amd import ops
+    from bioreason_amd.engine import lora_drop_seeds
+    from oracle import dna_llm_oracle as O
+    p = 0.2
+    fix = _fix(name)
+    b = fix["batch"]
+    m = build(fix, backend, False)
+    m.text_model.apply_lora(r=32, alpha=64.0, dropout=p, arena=m.arena)
+    own = dict(m.text_model.named_parameters())
+    for k, v in fix["state"]["lora"].items():
+        own[k].data.copy_(v.to(backend))
+    m.arena.pack()
+    m.train()
+    m.text_model.set_dropout_seed(123)
+    pass_seed = (123 * 0x9E3779B1 + 1 * 0x85EBCA6B) & 0xFFFFFFFF            # first forward after set_dropout_seed
+    ora = rebuild(fix, True)
+    B, S = b["input_ids"].shape
+    where = {"q_proj": ("qkv", 0, 3), "k_proj": ("qkv", 1, 3), "v_proj": ("qkv", 2, 3), "o_proj": ("o", 0, 1),
+             "gate_proj": ("gu", 0, 2), "up_proj": ("gu", 1, 2), "down_proj": ("d", 0, 1)}
+    for li, layer in enumerate(ora.text_model.model.layers):
+        for holder in (layer.self_attn, layer.mlp):
+            for nm, (grp, j, n) in where.items():
+                mod = getattr(holder, nm, None)
+                if isinstance(mod, O.LoraLinear):
+                    K = mod.base_layer.in_features
+                    seed = lora_drop_seeds(pass_seed, li, grp, n)[j]
+                    mod.dropout = _FixedMask(ops.dropout_mask(B * S, K, p, seed, backend).cpu().view(B, S, K), p)
+    want = ora(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()})
+    want.loss.backward()
+    m.arena.zero_grad()
+    got = m(**to_dev(b, backend))
+    keep = b["attention_mask"].bool()
+    tol = 2.5e-2
+    assert rel(got.logits.float().cpu()[keep], want.logits.detach()[keep]) < tol
+    assert abs(got.loss.item() - want.loss.item()) < tol * max(1.0, abs(want.loss.item()))
+    got.loss.backward()
+    assert rel(m.dna_projection.weight.grad, ora.dna_projection.weight.grad) < 3 * tol
+    l0, r0 = m.text_model.model.layers[0], ora.text_model.model.layers[0]
+    for nm, mod, ref in (("q", l0.self_attn.q_proj, r0.self_attn.q_proj), ("k", l0.self_attn.k_proj, r0.self_attn.k_proj),
+                         ("up", l0.mlp.up_proj, r0.mlp.up_proj), ("down", l0.mlp.down_proj, r0.mlp.down_proj)):
+        assert rel(mod.lora_A["default"].weight.grad, ref.lora_A["default"].weight.grad) < 3 * tol, nm
+        assert rel(mod.lora_B["default"].weight.grad, ref.lora_B["default"].weight.grad) < 3 * tol, nm
+    # the masks matter: without them the oracle's gradients are measurably different (guards against a silent no-op)
+    ora2 = rebuild(fix, True)
+    w2 = ora2(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()})
+    w2.loss.backward()
+    assert rel(r0.mlp.down_proj.lora_A["default"].weight.grad, ora2.text_model.model.layers[0].mlp.down_proj.lora_A["default"].weight.grad) > 0.1
+    # eval mode: no dropout (nn.Dropout is the identity)
+    m.eval()
+    ev = m(**to_dev(b, backend))
+    assert rel(ev.logits.float().cpu()[keep], w2.logits.detach()[keep]) < tol

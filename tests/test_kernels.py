@@ -510,3 +510,31 @@ def test_wgrad_tn(backend, M, N, R, chunk):
     out2 = torch.zeros(N, R, device=backend)
     ops.wgrad_tn(big[:, 8:8 + N], t, out2)
     assert rel(out2, big[:, 8:8 + N].float().T @ t.float()) < 1e-5
+
+
+# ----------------------------------------------------------------------------- LoRA branch under dropout
+@pytest.mark.parametrize("M,K,R", [(70, 64, 32), (130, 200, 64), (65, 136, 128)])
+def test_lora_dropout_kernels(backend, M, K, R):
+    """the three places the masked operand is needed regenerate the same masks: forward t = s * drop_j(x) A^T, input
+    gradient sum_j drop_j'(dts_j A_j), weight gradient dA += dts^T drop_j(x) — against torch with the exported masks"""
+    p, seeds = 0.25, [11, 22, 33, 44]
+    nb = R // 32
+    x, A, dts = rnd(M, K, dev=backend), rnd(R, K, dev=backend, scale=K ** -0.5), rnd(M, R, dev=backend)
+    masks = [ops.dropout_mask(M, K, p, seeds[j], backend).float().cpu() for j in range(nb)]
+    frac = torch.stack(masks).mean().item()
+    assert abs(frac - (1 - p)) < 0.03 and not torch.equal(masks[0], masks[-1]) or nb == 1
+    assert torch.equal(masks[0], ops.dropout_mask(M, K, p, seeds[0], backend).float().cpu())
+    xd = [(x.float().cpu() * mk / (1 - p)).to(BF).float() for mk in masks]           # torch: scale in fp32, round once
+    t = ops.lora_down_drop(x, A, 0.5, p, seeds)
+    want_t = torch.cat([0.5 * xd[j] @ A.float().cpu()[32 * j:32 * j + 32].T for j in range(nb)], dim=1)
+    assert rel(t, want_t.to(BF)) < 4e-3
+    up = ops.lora_up_drop(dts, A.T.contiguous(), p, seeds)
+    want_up = sum((dts.float().cpu()[:, 32 * j:32 * j + 32] @ A.float().cpu()[32 * j:32 * j + 32]) * masks[j] / (1 - p) for j in range(nb))
+    assert rel(up, want_up.to(BF)) < 4e-3
+    dA = torch.zeros(R, K, device=backend)
+    ops.wgrad_tn(x, dts, dA, transposed_out=True, drop=(p, seeds))
+    want_dA = torch.cat([dts.float().cpu()[:, 32 * j:32 * j + 32].T @ xd[j] for j in range(nb)], dim=0)
+    assert rel(dA, want_dA) < 1e-5
+    # p = 0 reproduces the plain kernels
+    t0 = ops.lora_down_drop(x, A, 0.5, 0.0, seeds)
+    assert rel(t0, (0.5 * x.float() @ A.float().T).to(BF)) < 4e-3
