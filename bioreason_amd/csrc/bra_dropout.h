@@ -18,12 +18,15 @@ __host__ __device__ inline uint32_t drop_threshold(float p) {
     return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)t);
 }
 
+// two multiply / xor-shift rounds: the second xor-shift folds the well-mixed high half into the low 16-bit field
 __device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t pair) {
-    uint32_t h = pair * 0x9E3779B1u + seed;
+    uint32_t h = (pair ^ seed) * 0x9E3779B1u;
     h ^= h >> 16; h *= 0x85ebca6bu;
-    h ^= h >> 13; h *= 0xc2b2ae35u;
-    h ^= h >> 16;
+    h ^= h >> 13;
     return h;
+}
+__device__ __forceinline__ bool drop_field(uint32_t h, uint32_t idx, uint32_t thr16) {
+    return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr16;
 }
 __device__ __forceinline__ bool drop_keep1(uint32_t seed, uint32_t idx, uint32_t thr16) {
     const uint32_t h = drop_hash(seed, idx >> 1);

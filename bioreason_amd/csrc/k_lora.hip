@@ -22,20 +22,22 @@ struct LoraDownArgs {
     DropCfg d;
 };
 
-// workgroup = 64 rows of x (2 waves x 32) against all R = 32 RB adapter rows; K in steps of 64 through LDS
+// workgroup = 32 rows of x against all R = 32 RB adapter rows; K in steps of 64 through LDS, the two waves take one half
+// of every step each (M / 32 workgroups of two waves keep every CU busy; the halves meet in LDS at the end)
 template <int RB>
 __global__ __launch_bounds__(128) void lora_down_drop_kernel(LoraDownArgs g) {
     constexpr int XP = 64 + 8;
-    __shared__ bf16_t xs[2][64 * XP];
+    __shared__ bf16_t xs[2][32 * XP];
     __shared__ bf16_t as[2][32 * RB * XP];
+    __shared__ float red[RB][64][16];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int m0 = (int)blockIdx.x * 64;
+    const int m0 = (int)blockIdx.x * 32;
     const int nstep = (g.K + 63) / 64;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    u32x4 rx[4], ra[2 * RB];
+    u32x4 rx[2], ra[2 * RB];
     auto issue = [&](int s) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const int c = tid + 128 * i, row = c >> 3, k = 64 * s + 8 * (c & 7);
             int m = m0 + row; m = m < g.M ? m : g.M - 1;
             const u32x4 v = ld16(g.x + (long)m * g.ldx + (k < g.K ? k : 0));
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(128) void lora_down_drop_kernel(LoraDownArgs g) {
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int c = tid + 128 * i; st16(&xs[buf][(c >> 3) * XP + 8 * (c & 7)], rx[i]); }
+        for (int i = 0; i < 2; ++i) { const int c = tid + 128 * i; st16(&xs[buf][(c >> 3) * XP + 8 * (c & 7)], rx[i]); }
 #pragma unroll
         for (int i = 0; i < 2 * RB; ++i) { const int c = tid + 128 * i; st16(&as[buf][(c >> 3) * XP + 8 * (c & 7)], ra[i]); }
     };
@@ -61,13 +63,14 @@ __global__ __launch_bounds__(128) void lora_down_drop_kernel(LoraDownArgs g) {
         for (int q = 0; q < 16; ++q) acc[rb][q] = 0.f;
     issue(0); commit(0);
     __syncthreads();
-    const int mrow = m0 + 32 * wave + (lane & 31);               // this lane's row of x (A-operand row)
+    const int mrow = m0 + (lane & 31);                           // this lane's row of x (A-operand row)
     for (int s = 0; s < nstep; ++s) {
         const int buf = s & 1;
         if (s + 1 < nstep) issue(s + 1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const u32x4 xf = ld16(&xs[buf][(32 * wave + (lane & 31)) * XP + 16 * kk + 8 * h]);
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int kk = 2 * wave + k2;
+            const u32x4 xf = ld16(&xs[buf][(lane & 31) * XP + 16 * kk + 8 * h]);
             const uint32_t e0 = (uint32_t)mrow * (uint32_t)g.K + (uint32_t)(64 * s + 16 * kk + 8 * h);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -79,13 +82,21 @@ __global__ __launch_bounds__(128) void lora_down_drop_kernel(LoraDownArgs g) {
         if (s + 1 < nstep) commit(buf ^ 1);
         __syncthreads();
     }
+    if (wave == 1) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) red[rb][lane][q] = acc[rb][q];
+    }
+    __syncthreads();
+    if (wave != 0) return;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int r = 32 * rb + (lane & 31);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int m = m0 + 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (m < g.M && r < g.R) g.t[(long)m * g.ldt + r] = f2bf(g.alpha * acc[rb][q]);
+            const int m = m0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (m < g.M && r < g.R) g.t[(long)m * g.ldt + r] = f2bf(g.alpha * (acc[rb][q] + red[rb][lane][q]));
         }
     }
 }
@@ -131,12 +142,20 @@ __global__ __launch_bounds__(256) void lora_up_drop_kernel(LoraUpArgs g) {
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
             acc = mfma_32x32x16(df[rb][0], af[rb][0], acc);
             acc = mfma_32x32x16(df[rb][1], af[rb][1], acc);
+            // a hash covers the column pair (k even, k odd) = this lane and lane ^ 1: each computes 8 of the 16 rows
+            const uint32_t odd = (uint32_t)kr & 1u;
+            uint32_t hh[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int i = 0; i < 8; ++i) {
+                const int q = (int)(8 * odd) + i;              // even lane: register rows 0..7, odd lane: 8..15
                 const int m = m_base + (q & 3) + 8 * (q >> 2) + 4 * h;
-                const uint32_t idx = (uint32_t)m * (uint32_t)g.K + (uint32_t)kr;
-                o[q] += drop_keep1(g.d.seed[rb], idx, g.d.thr16) ? acc[q] : 0.f;
+                const uint32_t mine = drop_hash(g.d.seed[rb], ((uint32_t)m * (uint32_t)g.K + (uint32_t)kr) >> 1);
+                const uint32_t other = wave_shfl_xor_u32(mine, 1);
+                hh[i] = odd ? other : mine;
+                hh[8 + i] = odd ? mine : other;
             }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[q] += drop_field(hh[q], (uint32_t)kr, g.d.thr16) ? acc[q] : 0.f;
         }
         if (kc < g.K) {
 #pragma unroll
@@ -172,7 +191,7 @@ extern "C" int bra_lora_down_drop(const void* x, long ldx, const void* A, long l
     if (!x || !A || !t || M < 0 || K <= 0 || K % 8 || ldx % 8 || lda % 8 || (R != 32 && R != 64 && R != 128)) return BRA_ERR_ARG;
     if (!(p >= 0.f && p < 1.f) || (long)M * K >= (1l << 32)) return BRA_ERR_ARG;
     LoraDownArgs g = {(const bf16_t*)x, ldx, (const bf16_t*)A, lda, (bf16_t*)t, ldt, M, K, R, alpha, make_cfg(p, s0, s1, s2, s3)};
-    const dim3 grid((M + 63) / 64);
+    const dim3 grid((M + 31) / 32);
     bra_stream_t st = (bra_stream_t)stream;
     if (R == 32) BRA_LAUNCH((lora_down_drop_kernel<1>), grid, dim3(128), 0, st, g);
     else if (R == 64) BRA_LAUNCH((lora_down_drop_kernel<2>), grid, dim3(128), 0, st, g);

@@ -95,14 +95,24 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
             for (int rb = 0; rb < RB; ++rb) {
                 u32x4 af = af0;
                 if (DROP) {
-                    // the lane's 8 elements run down a column of Y: indices (m_g + i) * N + n_g, one hash each
+                    // the lane's 8 elements run down a column of Y: indices (m_g + i) * N + n_g.  A hash covers the pair
+                    // (n even, n odd) = this lane and lane ^ 1, so each of the two computes half of the 8 and they swap
                     const uint32_t n_g = (uint32_t)(n0 + ncol);
                     const uint32_t m_g = (uint32_t)(m_lo + 32 * s + mb);
+                    const uint32_t odd = n_g & 1u;
+                    uint32_t hh[8];                              // hashes of rows 0..7 (compile-time indices only)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t row = m_g + 4 * odd + (uint32_t)i;      // even lane: rows 0..3, odd lane: rows 4..7
+                        const uint32_t mine = drop_hash(g.d.seed[rb], (row * (uint32_t)g.N + n_g) >> 1);
+                        const uint32_t other = wave_shfl_xor_u32(mine, 1);
+                        hh[i] = odd ? other : mine;
+                        hh[4 + i] = odd ? mine : other;
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const uint32_t i0 = (m_g + 2 * j) * (uint32_t)g.N + n_g, i1 = i0 + (uint32_t)g.N;
-                        const float lo = drop_keep1(g.d.seed[rb], i0, g.d.thr16) ? bf_lo(a[j]) * g.d.inv_keep : 0.f;
-                        const float hi = drop_keep1(g.d.seed[rb], i1, g.d.thr16) ? bf_hi(a[j]) * g.d.inv_keep : 0.f;
+                        const float lo = drop_field(hh[2 * j], n_g, g.d.thr16) ? bf_lo(a[j]) * g.d.inv_keep : 0.f;
+                        const float hi = drop_field(hh[2 * j + 1], n_g, g.d.thr16) ? bf_hi(a[j]) * g.d.inv_keep : 0.f;
                         af[j] = pack_bf2(lo, hi);
                     }
                 }
