@@ -320,6 +320,34 @@ class Qwen3ForCausalLM(nn.Module):
         self.arena.pack()
         return self
 
+    @torch.no_grad()
+    def merge_and_unload(self, reinit_seed: int = 0):
+        """PEFT `merge_and_unload()` (reason.py:441-444): W <- W + (alpha / r) B A for every target, delta rounded to the
+        weight dtype and added, as PEFT's `merge` does.  The adapter slots stay allocated (one flat arena) and restart from
+        PEFT's initial state — A gaussian, B = 0, a branch that adds nothing — which is exactly what the reference builds
+        next (`_prep_for_training` -> `get_peft_model`, reason.py:533-536)."""
+        eng = self.ensure_packed()
+        if self.arena is None:
+            return self
+        self.arena.pack()
+        gen = torch.Generator(device="cpu").manual_seed(reinit_seed)
+        for L in eng.layers:
+            for gname, wname in (("qkv", "Wqkv"), ("o", "Wo"), ("gu", "Wgu"), ("d", "Wd")):
+                G = L.lora[gname]
+                if G is None:
+                    continue
+                W = getattr(L, wname)
+                W.copy_(ops.gemm_nt(G.B, G.AT, alpha=G.scaling, res=W))           # [N, K] = s * B A + W
+                for j in range(len(G.n_sizes)):
+                    A, B, _, _ = G.target_views(j)
+                    if getattr(G, "active", None) is None or G.active[j]:
+                        A.copy_((torch.randn(A.shape, generator=gen) * (1.0 / G.r)).to(A.device))
+                    B.zero_()
+        self.arena.pack()
+        self._packed_sig = None                                                   # transposed weight images are stale
+        self.ensure_packed()
+        return self
+
     @contextlib.contextmanager
     def disable_adapter(self):
         """PEFT's `with model.disable_adapter():` — the reference policy of GRPO (grpo_trainer.py:636-640)."""
