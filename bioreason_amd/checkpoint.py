@@ -55,6 +55,9 @@ def _load_config(path: str):
 
 
 def _tokenizer(path: str):
+    # transformers 5 builds an EMPTY tokenizer for a directory that only holds config.json: require the files
+    if not any(os.path.exists(os.path.join(path, f)) for f in ("tokenizer.json", "vocab.json", "vocab.txt", "tokenizer.model")):
+        return None
     try:
         from transformers import AutoTokenizer
         return AutoTokenizer.from_pretrained(path, trust_remote_code=False, local_files_only=True)

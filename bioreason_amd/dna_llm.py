@@ -136,7 +136,10 @@ class DNALLMModel(nn.Module):
             from .checkpoint import load_pretrained_pair
             self.text_model, self.dna_model, toks = load_pretrained_pair(text_model_name, dna_model_name, cache_dir, dev)
             self.text_tokenizer, self.dna_tokenizer, self.processor = toks
-            self.dna_token_id = self.text_tokenizer.convert_tokens_to_ids("<|dna_pad|>")
+            if self.text_tokenizer is not None:
+                self.dna_token_id = self.text_tokenizer.convert_tokens_to_ids("<|dna_pad|>")
+            else:                               # weights-only directories (no tokenizer files)
+                self.dna_token_id = dna_token_id if dna_token_id is not None else 151670
         else:                                   # config objects: random init (no weights / tokenizers offline)
             self.text_model = Qwen3ForCausalLM(text_model_name, device=dev)
             self.dna_model = NTEncoderForMaskedLM(dna_model_name, device=dev)
