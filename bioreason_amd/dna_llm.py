@@ -173,12 +173,49 @@ class DNALLMModel(nn.Module):
         return self.text_model.device
 
     # ---- DNA side ------------------------------------------------------------------------------------------------------
+    def enable_dna_cache(self, max_entries: int = 4096) -> None:
+        """Keep the frozen encoder's output per distinct DNA sequence across calls: the encoder never
+        trains (dna_llm.py:121-122), so an entry is exact for as long as its weights are untouched.  Keyed by the bytes of
+        the token row and its mask; least-recently-used rows are dropped beyond `max_entries` (one row = Sd x H_dna bf16,
+        2 MB at 1024 x 1024).  Costs one device-to-host copy of the token ids per call."""
+        from collections import OrderedDict
+        self._dna_cache = OrderedDict()
+        self._dna_cache_cap = int(max_entries)
+        self.dna_cache_hits = self.dna_cache_misses = 0
+
+    def disable_dna_cache(self) -> None:
+        self._dna_cache = None
+
     @torch.no_grad()
     def encode_dna(self, dna_tokenized: Dict[str, torch.Tensor], dna_alias: Optional[List[int]] = None) -> torch.Tensor:
         """frozen encoder forward -> hidden_states[-1] as rows [n_seq * Sd, H_dna]; with `dna_alias` only the
         representative sequences are encoded and the rows are expanded."""
         ids, mask = dna_tokenized["input_ids"], dna_tokenized["attention_mask"]
         n, Sd = ids.shape
+        cache = getattr(self, "_dna_cache", None)
+        if cache is not None:
+            hi, hm = ids.to("cpu", torch.int64).contiguous(), mask.to("cpu", torch.uint8).contiguous()
+            keys = [hi[r].numpy().tobytes() + hm[r].numpy().tobytes() for r in range(n)]
+            todo = []                                                    # first row of every key not cached yet
+            seen = set()
+            for r, k in enumerate(keys):
+                if k not in cache and k not in seen:
+                    seen.add(k)
+                    todo.append(r)
+            self.dna_cache_misses += len(todo)
+            self.dna_cache_hits += n - len(todo)
+            if todo:
+                sel = torch.tensor(todo, device=ids.device)
+                enc = self.dna_model(input_ids=ids[sel], attention_mask=mask[sel]).hidden_states[-1]      # [m, Sd, H]
+                for i, r in enumerate(todo):
+                    cache[keys[r]] = enc[i].clone()
+            out = []
+            for k in keys:
+                cache.move_to_end(k)
+                out.append(cache[k])
+            while len(cache) > self._dna_cache_cap:
+                cache.popitem(last=False)
+            return torch.stack(out, 0).reshape(n * Sd, -1)
         if dna_alias is None:
             return self.dna_model(input_ids=ids, attention_mask=mask).hidden_states[-1].reshape(n * Sd, -1)
         reps = sorted(set(dna_alias))

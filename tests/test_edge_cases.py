@@ -167,3 +167,33 @@ def test_lora_dropout_matches_oracle_under_the_same_masks(backend, name):
     m.eval()
     ev = m(**to_dev(b, backend))
     assert rel(ev.logits.float().cpu()[keep], w2.logits.detach()[keep]) < tol
+
+
+def test_dna_embedding_cache_is_exact(backend):
+    """encoder outputs cached per distinct sequence reproduce the uncached forward bit for bit — the rows
+    of a batched encoder pass do not depend on which other sequences share the batch — and repeated calls hit the cache"""
+    fix = _fix("tiny_a")
+    m = build(fix, backend, False)
+    b = to_dev(fix["batch"], backend)
+    b.pop("labels")
+    want = m(**b).logits
+    m.enable_dna_cache(max_entries=8)
+    got1 = m(**b).logits
+    n = b["dna_tokenized"]["input_ids"].shape[0]
+    assert m.dna_cache_misses == n and m.dna_cache_hits == 0
+    got2 = m(**b).logits
+    assert m.dna_cache_misses == n and m.dna_cache_hits == n           # nothing recomputed
+    assert torch.equal(got1.cpu(), want.cpu()) and torch.equal(got2.cpu(), want.cpu())
+    m._dna_cache_cap = 2                                               # least-recently-used rows are dropped
+    assert torch.equal(m(**b).logits.cpu(), want.cpu()) and len(m._dna_cache) == 2
+    # a different order / subset of the same sequences is served from the cache where possible, still exact
+    keep = [i for i, s in enumerate(b["batch_idx_map"]) if s == 0]
+    sub = {k: v[keep] for k, v in b["dna_tokenized"].items()}
+    ids = b["input_ids"].clone()
+    ids[1][ids[1] == fix["config"]["dna_token_id"]] = 7
+    m.disable_dna_cache()
+    w2 = m(input_ids=ids, attention_mask=b["attention_mask"], dna_tokenized=sub, batch_idx_map=[0] * len(keep)).logits
+    m.enable_dna_cache()
+    m(**b)
+    g2 = m(input_ids=ids, attention_mask=b["attention_mask"], dna_tokenized=sub, batch_idx_map=[0] * len(keep)).logits
+    assert torch.equal(g2.cpu(), w2.cpu())
