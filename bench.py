@@ -7,16 +7,19 @@
 One "step" = one full GRPO step on one batch of synthetic DNA+prompt input per GPU (cfg-3 of SURVEY §8d):
 NT-500M encoder + Qwen3-1.7B, 1 unique prompt x G=8 rollouts per GPU, prompt P = 2180 (2 DNA sequences x 1024 NT
 tokens + 128 text tokens), 256 sampled tokens per rollout (EOS suppressed so every rollout has the full length),
-reference log-probs (adapters off), policy forward/backward (LoRA r=32 on all 7 projections + dna_projection),
-reward all-gather + group advantages, gradient all-reduce, AdamW with grad clip 1.0.  Inputs are resident in HBM
-before the timed region.  value = samples (prompt, completion pairs) per second over all ranks.
+reference log-probs (adapters off), policy forward/backward in train mode (LoRA r=32, lora_dropout 0.05 on all 7
+projections + dna_projection), reward all-gather + group advantages, gradient all-reduce, AdamW with grad clip 1.0.
+Inputs are resident in HBM before the timed region.  value = samples (prompt, completion pairs) per second over all ranks.
 
 The JSON line also carries
-  roofline     — the dominant kernel (bra gemm_nt_kernel<64, bf16>, every linear layer of encoder / prefill /
-                 log-prob / backward): algorithmic FLOPs (2*M*N*K of each large-M launch) / its duration measured
-                 with HIP events on the launch stream inside the timed steps, against 2.5 PFLOP/s dense bf16 MFMA;
-  cpu_baseline — the oracle (reference glue + installed HF Qwen3 / ESM modules, bf16) timed on the host cores for a
-                 bounded sample of the same workload.
+  roofline        — the dominant kernel, gemm_glds_kernel<*, 1> (256x128 LDS-DMA tiles; every projection / lm_head GEMM
+                    of prefill, log-prob and backward passes that fills the chip): algorithmic FLOPs 2*M*N*(K+K2) of
+                    exactly its launches / their duration measured with HIP events on the launch stream inside the timed
+                    steps, against 2.5 PFLOP/s dense bf16 MFMA; `traffic` = HBM-side bytes per launch from the committed
+                    rocprofv3 PMC passes (profiles/r1_c_pmc_gemm.json);
+  decode_roofline — the HBM view of the rollout's token loop (weights + K/V bytes per token step / measured step time);
+  cpu_baseline    — the oracle (reference glue + installed HF Qwen3 / ESM modules, bf16) timed on the host cores for a
+                    bounded sample of the same workload (separate process, after the GPU line is measured).
 """
 import argparse
 import json
