@@ -740,14 +740,31 @@ __global__ __launch_bounds__(64) void attn_decode_merge_kernel(DecodeArgs a) {
     const int hq = (int)blockIdx.x, b = (int)blockIdx.y;
     const int nchunk = a.t_ptr ? a.npc + (a.t_ptr[0] + 64) / 64 : a.nchunk;
     const long base = ((long)b * a.Hq + hq) * nchunk;
-    // lane c holds the (max, sum) pair of chunk c (+64, ...): one round of loads, then wave reductions
+    constexpr int EPL = HD / 64 > 0 ? HD / 64 : 1;
+    constexpr int PRE = 48;                          // partial rows requested before anything is known about their weights
+    const int nc = nchunk < 256 ? nchunk : 256;
+    const bool dlive = lane * EPL < HD;
+    // (1) every load of the kernel is issued here: the (max, sum) pairs and the first PRE partial rows are independent,
+    //     so the merge costs one memory round trip instead of one per batch of rows
     float mc[4], lc[4];
-    float m = kNeg;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int c = lane + 64 * r;
-        mc[r] = c < nchunk ? a.part_ml[(base + c) * 2] : kNeg;
-        lc[r] = c < nchunk ? a.part_ml[(base + c) * 2 + 1] : 0.f;
+        const int cc = c < nchunk ? c : 0;
+        mc[r] = a.part_ml[(base + cc) * 2];
+        lc[r] = a.part_ml[(base + cc) * 2 + 1];
+    }
+    float v0[PRE][EPL];
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+        const int cc = u < nc ? u : nc - 1;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v0[u][e] = a.part_o[(base + cc) * HD + (dlive ? lane * EPL : 0) + e];
+    }
+    float m = kNeg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (lane + 64 * r >= nchunk) { mc[r] = kNeg; lc[r] = 0.f; }
         m = fmaxf(m, mc[r]);
     }
     m = wave_max<64>(m);
@@ -755,12 +772,16 @@ __global__ __launch_bounds__(64) void attn_decode_merge_kernel(DecodeArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { mc[r] = exp2f(mc[r] - m); l += lc[r] * mc[r]; }     // mc now holds the chunk weight
     l = wave_sum<64>(l);
-    constexpr int EPL = HD / 64 > 0 ? HD / 64 : 1;
     float acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    const int nc = nchunk < 256 ? nchunk : 256;
-    for (int c0 = 0; c0 < nc; c0 += 8) {
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {                  // chunks 0 .. 47 live in lane u of weight register 0
+        const float w = u < nc ? wave_shfl(mc[0], u) : 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] += v0[u][e] * w;
+    }
+    for (int c0 = PRE; c0 < nc; c0 += 8) {
         float v[8][EPL], w[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -769,7 +790,7 @@ __global__ __launch_bounds__(64) void attn_decode_merge_kernel(DecodeArgs a) {
             const float wsel = (cc >> 6) == 0 ? mc[0] : ((cc >> 6) == 1 ? mc[1] : ((cc >> 6) == 2 ? mc[2] : mc[3]));
             w[u] = c < nc ? wave_shfl(wsel, cc & 63) : 0.f;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) v[u][e] = (lane * EPL < HD) ? a.part_o[(base + cc) * HD + lane * EPL + e] : 0.f;
+            for (int e = 0; e < EPL; ++e) v[u][e] = dlive ? a.part_o[(base + cc) * HD + lane * EPL + e] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -777,7 +798,7 @@ __global__ __launch_bounds__(64) void attn_decode_merge_kernel(DecodeArgs a) {
             for (int e = 0; e < EPL; ++e) acc[e] += v[u][e] * w[u];
     }
     const float inv = l > 0.f ? 1.f / l : 0.f;
-    if (lane * EPL < HD)
+    if (dlive)
 #pragma unroll
         for (int e = 0; e < EPL; ++e) a.o[((long)b * a.Hq + hq) * HD + lane * EPL + e] = f2bf(acc[e] * inv);
 }

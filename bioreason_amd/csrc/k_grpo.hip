@@ -75,7 +75,9 @@ __global__ __launch_bounds__(256) void topk_slices_kernel(const float* logits, l
 
 // temperature / top-p / draw over the k survivors (value-descending), executed by one thread
 // (HF: TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper, multinomial — TF:generation/logits_process.py, utils.py:2905-2925)
-__device__ inline void sample_pick(const float* top_v, const int* top_i, int k, int row, float temperature, float top_p,
+// `p` = k floats of LDS scratch (a per-thread array indexed at run time would live in scratch memory: every access a
+// round trip through the memory system, in a single-thread serial section)
+__device__ inline void sample_pick(float* p, const float* top_v, const int* top_i, int k, int row, float temperature, float top_p,
                                    int do_sample, uint32_t seed, const int* step_ptr, uint8_t* finished, int pad_id, int eos_id,
                                    int* out_ids, float* out_logp, int* tokens_out, long ldt) {
     int choice = top_i[0];
@@ -83,7 +85,6 @@ __device__ inline void sample_pick(const float* top_v, const int* top_i, int k, 
     if (do_sample) {
         // temperature, softmax over the top-k survivors
         const float inv_t = 1.f / temperature;
-        float p[64];
         const float mx = top_v[0] * inv_t;
         float z = 0.f;
         for (int j = 0; j < k; ++j) { p[j] = __expf(top_v[j] * inv_t - mx); z += p[j]; }
@@ -154,8 +155,9 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ld
         last_v = top_v[round];
         last_i = top_i[round];
     }
+    __shared__ float pick_ws[64];
     if (tid == 0)
-        sample_pick(top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr, finished, pad_id, eos_id, out_ids,
+        sample_pick(pick_ws, top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr, finished, pad_id, eos_id, out_ids,
                     out_logp, tokens_out, ldt);
 }
 
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(64) void sample_merge_kernel(const float* cand_v, c
     __shared__ float top_v[64];
     __shared__ int top_i[64];
     __shared__ int s_choice;
+    __shared__ float pick_ws[64];
     float* sv = reinterpret_cast<float*>(smem);
     int* si = reinterpret_cast<int*>(smem) + kSlices * k;
     const int row = (int)blockIdx.x, lane = lane_id();
@@ -214,8 +217,8 @@ __global__ __launch_bounds__(64) void sample_merge_kernel(const float* cand_v, c
     }
     __syncthreads();
     if (lane == 0) {
-        sample_pick(top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr, finished, pad_id, eos_id, out_ids,
-                    out_logp, tokens_out, ldt);
+        sample_pick(pick_ws, top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr, finished, pad_id, eos_id,
+                    out_ids, out_logp, tokens_out, ldt);
         s_choice = out_ids[row];
     }
     __syncthreads();
