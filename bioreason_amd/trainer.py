@@ -64,6 +64,8 @@ class GRPOStepRunner:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.step_idx = 0
+        if hasattr(model.text_model, "set_dropout_seed"):          # every rank draws its own LoRA dropout masks, as separate
+            model.text_model.set_dropout_seed(cfg.seed * 1000003 + self.rank)   # processes with their own RNG streams do
         self.timers: Dict[str, float] = {}
         self.rollout_profile: Dict[str, float] = {}      # filled by step(timing=True): phases inside generate(), ms
 
