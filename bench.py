@@ -227,6 +227,8 @@ def main():
                                    "prefill, ref, policy forward and backward passes that fills the chip)",
                          "launches": prof["launches"], "avg_launch_ms": prof["avg_launch_ms"]},
             "decode_roofline": decode_roofline(model, runner.rollout_profile, args.completion_len),
+            "rollout_issue": {"mode": "graph" if getattr(model.text_model.engine, "_rollout_use_graph", False) else "eager",
+                              "probe_host_vs_device_ms_per_token": getattr(model.text_model.engine, "_rollout_probe_ms", None)},
             "step_tflops": value / world * flops_per_sample() / 1e12,
             "step_frac_of_mfma_peak": value / world * flops_per_sample() / 1e12 / PEAK_BF16_TFLOPS,
             "phases_ms": {k: round(v, 2) for k, v in runner.timers.items()},

@@ -412,6 +412,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             e1.synchronize()
             want_graph = host_s > 0.8 * e0.elapsed_time(e1) * 1e-3
             eng._rollout_use_graph = want_graph
+            eng._rollout_probe_ms = (host_s * 1e3 / 8, e0.elapsed_time(e1) / 8)      # host issue vs device time per step
             if profile is not None:
                 profile["auto_host_ms_per_step"] = host_s * 1e3 / 8
                 profile["auto_gpu_ms_per_step"] = e0.elapsed_time(e1) / 8
