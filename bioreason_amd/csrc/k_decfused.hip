@@ -10,6 +10,11 @@
 //   dec_gemm              down_proj + residual
 // Weight loads are issued in explicit batches of 8 x 16 B per lane ahead of their MFMAs (the compiler otherwise
 // interleaves them with the consumers and keeps only 2-8 in flight).
+// The dec_gemm kernels of this file are the FIRST generation: the step functions use k_decgemm.hip's dec_gemm2 for
+// M <= 8 rows (norm statistics as epilogue partials, all weight bytes requested up front) and fall back to these for
+// 9..16 rows or hidden sizes with more than 256 column workgroups.  The attention kernels here are current:
+// dec_attn_both = dec_attn_shared (one MFMA pass over the prompt K / V^T shared by the rollouts of a prompt) +
+// dec_attn_partial (per-sequence completion keys) in one launch.
 #include "bra_device.h"
 #include "bra_api_internal.h"
 

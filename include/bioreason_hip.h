@@ -198,7 +198,7 @@ int bra_qwen_decode_step_fused(const void* layers_host, int L, int B, int H, int
 
 /* shared-prefix step: B = R * copies sequences grouped by prompt; layer records additionally carry kp (prompt K
  * [R,Hkv,P,hd]) and vtp (prompt V^T [R,Hkv,hd,vt_pitch]); kc / vc are the per-sequence COMPLETION caches [B,Hkv,C,hd]
- * and t the number of completion tokens already cached.  7 launches per layer. */
+ * and t the number of completion tokens already cached.  6 launches per layer (qkv, attention, merge, o, gate/up + SwiGLU, down). */
 int bra_qwen_decode_step_shared(const void* layers_host, int L, int R, int copies, int H, int Hq, int Hkv, int hd, int F,
                                 int P, long vt_pitch, int C, int V, float eps, float scale, const void* E,
                                 const void* norm_w, const float* cosT, const float* sinT, const int* tok, const int* pos,
