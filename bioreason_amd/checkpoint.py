@@ -97,7 +97,11 @@ def load_pretrained_pair(text_model_name, dna_model_name, cache_dir, device):
     if tt is not None:                                                # dna_llm.py:68-73
         tt.pad_token = tt.eos_token
         tt.add_special_tokens({"additional_special_tokens": NEW_TOKENS})
-    return text, dna, (tt, dt, None)
+    processor = None
+    if tt is not None and dt is not None:                             # dna_llm.py:100: DLProcessor(tokenizer, dna_tokenizer)
+        from .processing import DLProcessor
+        processor = DLProcessor(tokenizer=tt, dna_tokenizer=dt)
+    return text, dna, (tt, dt, processor)
 
 
 # ----------------------------------------------------------------------------------------------- reference key names
