@@ -78,3 +78,28 @@ def test_equals_reference_class(toks):
     for k in ("input_ids", "attention_mask"):
         assert torch.equal(want["dna_tokenized"][k], got["dna_tokenized"][k])
     assert ref.model_input_names == DLProcessor(tokenizer=text_tok, dna_tokenizer=dna_tok).model_input_names
+
+
+def test_dna_module_answers_and_input_preparation(toks):
+    """nucleotide_module.py:16-262: the adapter's answers, and prepare_model_inputs == a direct processor call"""
+    from bioreason_amd.dna_modules import DNABaseModule, NucleotideDNAModule
+    from bioreason_amd.dna_llm import DNALLMModel
+    text_tok, dna_tok = toks
+    mod = NucleotideDNAModule()
+    assert isinstance(mod, DNABaseModule) and mod.get_dnallm_key() == "qwen" and mod.is_embeds_input()
+    assert mod.get_model_class("DNALLM-qwen", {}) is DNALLMModel and mod.get_processing_class() is DLProcessor
+    with pytest.raises(ValueError):
+        mod.get_model_class("other", {})
+    assert mod.get_custom_multimodal_keywords() == ["dna_tokenized", "batch_idx_map"] and mod.get_dnallm_modules_keywords() == ["dna"]
+    assert mod.get_custom_processing_keywords() == [("dna_tokenizer", "max_length")] and mod.get_non_generate_params() == []
+    proc = DLProcessor(tokenizer=text_tok, dna_tokenizer=dna_tok)
+
+    class M:
+        max_length_text, max_length_dna = 64, 6
+    got = mod.prepare_model_inputs(proc, M(), list(TEXTS), [list(s) for s in DNA])
+    want = _call(proc)
+    assert torch.equal(got["input_ids"], want["input_ids"]) and got["batch_idx_map"] == want["batch_idx_map"]
+    assert mod.prepare_prompt(proc, [{"prompt": "hello world"}]) == ["hello world"]
+    ok = "<think>x</think> <answer>{\"box\": [1, 2, 3, 4]}</answer>"
+    assert NucleotideDNAModule.format_reward_rec([[{"content": ok}], [{"content": "<think>x</think>"}]]) == [1.0, 0.0]
+    assert NucleotideDNAModule.select_reward_func("format", "rec") is NucleotideDNAModule.format_reward_rec
