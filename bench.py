@@ -1,53 +1,129 @@
 #!/usr/bin/env python
-"""bench.py — GRPO training-step throughput of the HIP DNA-LLM path (BASELINE.json's metric).
+"""bench.py — throughput of the HIP DNA-LLM hot path (BASELINE.json's metric: GRPO training-step samples/sec).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W            # N > 1 self-launches one process per GPU (RCCL)
+    python bench.py --mode sft                               # BASELINE config 2 (train_dna_qwen.py SFT step), secondary line
+    python bench.py --eos-uniform 64 256                     # SURVEY §8d straggler run (rollout lengths U[64, 256])
+    python bench.py --prompts-per-gpu 2                      # secondary lines: sh_reason.sh's per_device_train_batch_size
 
-One "step" = one full GRPO step on one batch of synthetic DNA+prompt input per GPU (cfg-3 of SURVEY §8d):
+GRPO "step" (default, cfg-3 of SURVEY §8d) = one full GRPO step on one batch of synthetic DNA+prompt input per GPU:
 NT-500M encoder + Qwen3-1.7B, 1 unique prompt x G=8 rollouts per GPU, prompt P = 2180 (2 DNA sequences x 1024 NT
 tokens + 128 text tokens), 256 sampled tokens per rollout (EOS suppressed so every rollout has the full length),
 reference log-probs (adapters off), policy forward/backward in train mode (LoRA r=32, lora_dropout 0.05 on all 7
 projections + dna_projection), reward all-gather + group advantages, gradient all-reduce, AdamW with grad clip 1.0.
-Inputs are resident in HBM before the timed region.  value = samples (prompt, completion pairs) per second over all ranks.
+SFT "step" (cfg-2) = forward (full-row lm_head logits + shifted CE on the last 64 positions) / backward / all-reduce /
+AdamW over B=8 distinct samples of the same shape.
+Inputs are resident in HBM before the timed region.  value = samples per second over all ranks.
 
 The JSON line also carries
-  roofline        — the dominant kernel, gemm_glds_kernel<*, 1> (256x128 LDS-DMA tiles; every projection / lm_head GEMM
+  roofline        — the dominant kernel family, gemm_glds_kernel (LDS-DMA MFMA tiles; every projection / lm_head GEMM
                     of prefill, log-prob and backward passes that fills the chip): algorithmic FLOPs 2*M*N*(K+K2) of
                     exactly its launches / their duration measured with HIP events on the launch stream inside the timed
                     steps, against 2.5 PFLOP/s dense bf16 MFMA; `traffic` = HBM-side bytes per launch from the committed
-                    rocprofv3 PMC passes (profiles/r1_c_pmc_gemm.json);
+                    rocprofv3 PMC passes — printed only when the profile was collected from the kernel sources that are
+                    running (sha256 of csrc/k_gemm.hip + bra_device.h recorded in the profile), else null;
   decode_roofline — the HBM view of the rollout's token loop (weights + K/V bytes per token step / measured step time);
   cpu_baseline    — the oracle (reference glue + installed HF Qwen3 / ESM modules, bf16) timed on the host cores for a
                     bounded sample of the same workload (separate process, after the GPU line is measured).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: 2.5 PF dense; 5 PF is 2:1 sparse)
+PEAK_HBM_GBS = 8000.0
 SD, TEXT_LEN, NDNA, G, C = 1024, 128, 2, 8, 256
 LORA_DROPOUT = 0.05          # reason.py:266 / train_dna_qwen.py:1038
+SFT_LABEL_TAIL = 64
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r2_pmc_gemm.json")
 
 
-def flops_per_sample():
-    """BASELINE.md §3 (algorithmic, encoder counted once per sample as in the reference's own accounting)"""
+# ---------------------------------------------------------------------------------------------- accounting
+def flops_per_sample_reference():
+    """BASELINE.md §3 (algorithmic, the reference's own accounting: every row runs the full prompt)"""
     return 34.1e12
 
 
-def cpu_baseline(max_seconds: float = 60.0):
-    """The oracle on the host cores, bounded: ONE sample of the cfg-3 workload at full model size —
-    encoder fwd (2 x 1024), prefill P=2180, 2 of the 256 decode steps (extrapolated x128), reference log-probs
-    forward and policy forward+backward over P+C.  bf16, sdpa, all cores."""
+def executed_flops(world_local_prompts: int, P: int, Cn: int, mode: str):
+    """FLOPs this implementation actually executes per step and GPU (shared prompts are run once): encoder once per distinct
+    sequence, prefill / reference prompt once per distinct prompt, policy forward + backward for every row."""
+    d_e, f_e, L_e = 1024, 4096, 29
+    d, f, L, q, kv, V = 2048, 6144, 28, 2048, 1024, 151936
+
+    def lin(tokens):
+        return tokens * L * (2 * d * q + 4 * d * kv + 2 * q * d + 6 * d * f)
+
+    def attn(S, rows=1.0):
+        return rows * L * 4 * q * S * (S + 1) / 2
+
+    enc_seq = SD * L_e * (8 * d_e * d_e + 6 * d_e * f_e) + L_e * 4 * SD * SD * d_e
+    R = world_local_prompts
+    if mode == "sft":
+        B = R
+        fwd = lin(B * P) + attn(P, B) + 2 * d * V * B * P
+        bwd = lin(B * P) + 2.5 * attn(P, B) + 2 * 2 * d * V * B * SFT_LABEL_TAIL
+        return NDNA * B * enc_seq + fwd + bwd
+    B = R * G
+    S = P + Cn
+    enc = NDNA * R * enc_seq
+    prefill = lin(R * P) + attn(P, R) + 2 * d * V * R
+    decode = Cn * (lin(B) + 2 * d * V * B) + B * L * 4 * q * (Cn * P + Cn * (Cn + 1) / 2)
+    ref = lin(R * P + B * Cn) + attn(P, R) + B * L * 4 * q * (Cn * P + Cn * (Cn + 1) / 2) + 2 * d * V * B * Cn
+    pol_f = lin(B * S) + attn(S, B) + 2 * d * V * B * Cn
+    pol_b = lin(B * S) + 2.5 * attn(S, B) + 2 * 2 * d * V * B * Cn
+    return enc + prefill + decode + ref + pol_f + pol_b
+
+
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for f in ("k_gemm.hip", "bra_device.h"):
+        with open(os.path.join(ROOT, "bioreason_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic():
+    """(HBM bytes per launch of the dominant kernel, note) from the committed rocprofv3 PMC summary (counters cannot be read
+    from inside the timed process); traffic is None unless the summary was collected from the kernel sources now running"""
+    try:
+        with open(PMC_PROFILE) as fh:
+            d = json.load(fh)
+    except Exception:
+        return None, "no PMC summary committed for this round (profiles/r2_pmc_gemm.json)"
+    if d.get("kernel_source_sha") != kernel_source_sha():
+        return None, "profiles/r2_pmc_gemm.json was collected from different kernel sources (sha %s, running %s): not reported" % (
+            d.get("kernel_source_sha"), kernel_source_sha())
+    return float(d["traffic_bytes_per_launch"]), ("HBM-side bytes per launch, rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + "
+                                                  "WRITE_SIZE, separate passes) on this command: profiles/r2_pmc_gemm.json")
+
+
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(mode: str = "grpo"):
+    """The oracle on the host cores, bounded: ONE sample of the workload at full model size, bf16, sdpa, all cores
+    (<= 64 threads), 1 warm-up pass + 3 timed passes of every leg, medians reported.
+    GRPO: encoder fwd (2 x 1024) + prefill P=2180 + decode steps (per-step time measured over 4 steps, x255) +
+    reference log-probs forward + policy forward/backward over P+C.  SFT: forward + backward of one sample."""
+    import torch
     from oracle import dna_llm_oracle as O
+    from oracle import grpo_math as GM
     ncores = min(os.cpu_count() or 1, int(os.environ.get("BENCH_CPU_THREADS", "64")))
     torch.set_num_threads(ncores)
     t_build = time.time()
@@ -72,66 +148,107 @@ def cpu_baseline(max_seconds: float = 60.0):
     b = synth_prompt_batch(B=1, n_unique=1, Sd=SD, text_len=TEXT_LEN, n_dna=NDNA, seed=42)
     mm = {"dna_tokenized": b["dna_tokenized"], "batch_idx_map": b["batch_idx_map"]}
     build_s = time.time() - t_build
-    from oracle import grpo_math as GM
-    t0 = time.time()
-    nd = 2
-    gen = model.generate(input_ids=b["input_ids"], attention_mask=b["attention_mask"], **mm, max_new_tokens=nd + 1,
-                         do_sample=True, temperature=0.6, top_k=20, top_p=0.95, pad_token_id=0)
-    t_roll_short = time.time() - t0
-    # time one extra decode step pair to extrapolate: second call with 2*nd+1 tokens
-    t0 = time.time()
-    model.generate(input_ids=b["input_ids"], attention_mask=b["attention_mask"], **mm, max_new_tokens=2 * nd + 1,
-                   do_sample=True, temperature=0.6, top_k=20, top_p=0.95, pad_token_id=0)
-    t_roll_long = time.time() - t0
-    per_step = max((t_roll_long - t_roll_short) / nd, 0.0)
-    t_rollout = t_roll_short + per_step * (C - 1 - nd)
+    budget_s = float(os.environ.get("BENCH_CPU_BUDGET", "150"))
+    t_start = time.time()
+
+    def med(fn, n=3):
+        """1 warm-up + up to n timed passes (fewer if the leg alone would blow the wall-clock budget)"""
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.time()
+            fn()
+            ts.append(time.time() - t0)
+            if time.time() - t_start > budget_s:
+                break
+        ts.sort()
+        return ts[len(ts) // 2], len(ts)
+
+    common = {"unit": "samples/s", "cores": ncores, "cpu_model": cpu_model_name(), "kind": "port"}
+    if mode == "sft":
+        labels = torch.full_like(b["input_ids"], -100)
+        labels[:, -SFT_LABEL_TAIL:] = b["input_ids"][:, -SFT_LABEL_TAIL:]
+
+        def sft_step():
+            for p in model.parameters():
+                p.grad = None
+            out = model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=labels, **mm)
+            out.loss.backward()
+
+        t_s, n_s = med(sft_step)
+        return dict(common, value=1.0 / t_s,
+                    sample=f"1 sample of the cfg-2 SFT step at full model size (bf16, sdpa): forward + backward {t_s:.1f}s "
+                           f"(median of {n_s} after 1 warm-up); model build {build_s:.0f}s not counted")
+    gen_kw = dict(do_sample=True, temperature=0.6, top_k=20, top_p=0.95, pad_token_id=0)
+
+    def roll(n):
+        return lambda: model.generate(input_ids=b["input_ids"], attention_mask=b["attention_mask"], **mm, max_new_tokens=n, **gen_kw)
+
+    t_r1, n1 = med(roll(1))               # encoder + prefill + first draw
+    t_r5, n5 = med(roll(5), n=2)          # + 4 decode steps
+    per_step = max((t_r5 - t_r1) / 4, 0.0)
+    t_rollout = t_r1 + per_step * (C - 1)
     comp = torch.randint(0, 151643, (1, C), generator=g)
     ids = torch.cat([b["input_ids"], comp], 1)
     mask = torch.ones_like(ids)
-    t0 = time.time()
-    O.set_adapters(text, False)
-    with torch.no_grad():
-        ref_lp = GM.per_token_logps(model, ids, mask, **mm)[:, -C:]
-    O.set_adapters(text, True)
-    t_ref = time.time() - t0
-    t0 = time.time()
-    lp = GM.per_token_logps(model, ids, mask, **mm)[:, -C:]
-    loss, _, _ = GM.grpo_loss(lp.float(), None, ref_lp.float(), torch.ones(1), torch.ones(1, C), 0.2, 0.2, 0.04)
-    loss.backward()
-    t_pol = time.time() - t0
+
+    def ref_pass():
+        O.set_adapters(text, False)
+        with torch.no_grad():
+            out = GM.per_token_logps(model, ids, mask, **mm)[:, -C:]
+        O.set_adapters(text, True)
+        return out
+
+    t_ref, n_ref = med(ref_pass, n=2)
+    ref_lp = ref_pass()
+
+    def pol_pass():
+        for p in model.parameters():
+            p.grad = None
+        lp = GM.per_token_logps(model, ids, mask, **mm)[:, -C:]
+        loss, _, _ = GM.grpo_loss(lp.float(), None, ref_lp.float(), torch.ones(1), torch.ones(1, C), 0.2, 0.2, 0.04)
+        loss.backward()
+
+    t_pol, n_pol = med(pol_pass, n=2)
     total = t_rollout + t_ref + t_pol
-    return {"value": 1.0 / total, "unit": "samples/s", "cores": ncores, "kind": "port",
-            "sample": f"1 sample of the cfg-3 workload at full model size (bf16, sdpa): rollout {t_rollout:.1f}s "
-                      f"(prefill + {nd} measured decode steps, extrapolated to {C}), ref logps {t_ref:.1f}s, "
-                      f"policy fwd+bwd {t_pol:.1f}s; model build {build_s:.0f}s not counted"}
+    return dict(common, value=1.0 / total,
+                sample=f"1 sample of the cfg-3 workload at full model size (bf16, sdpa), medians after 1 warm-up: rollout "
+                       f"{t_rollout:.1f}s (encoder + prefill {t_r1:.1f}s [{n1} runs] + {per_step * 1e3:.0f} ms/decode step measured over "
+                       f"4 steps [{n5} runs] x {C - 1}), ref logps {t_ref:.1f}s [{n_ref}], policy fwd+bwd {t_pol:.1f}s [{n_pol}]; "
+                       f"model build {build_s:.0f}s not counted")
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (counters cannot be read from
-    inside the timed process); None when the summary is absent"""
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c_pmc_gemm.json")) as fh:
-            return float(json.load(fh)["traffic_bytes_per_launch"])
-    except Exception:
-        return None
-
-
-def decode_roofline(model, rollout_profile, C):
+# ---------------------------------------------------------------------------------------------- GPU legs
+def decode_roofline(model, rollout_profile, Cn, n_prompts):
     """HBM roofline of the rollout's token loop (the largest phase of the step; every kernel in it is a weight / KV
     stream): algorithmic bytes of one decode step = merged bf16 projection weights + tied lm_head + the K/V rows the
     step attends to (prompt rows once per prompt, completion rows per sequence, averaged over the C steps), divided by
-    the measured time per step (host-synchronised wall time of the replayed hipGraph loop in the instrumented step)."""
+    the measured time per step (host-synchronised wall time of the token loop in the instrumented step)."""
     e = model.text_model.engine
     w_bytes = 2 * (e.L * ((e.Nq + 2 * e.Nkv) * e.H + e.H * e.Nq + 3 * e.F * e.H) + e.V * e.H)
-    kv_bytes = e.L * 2 * e.Nkv * 2 * (1 * 2180 + G * (C / 2.0))
+    kv_bytes = e.L * 2 * e.Nkv * 2 * (n_prompts * 2180 + n_prompts * G * (Cn / 2.0))
     ms = rollout_profile.get("decode_loop")
-    if not ms or C < 3:
+    steps = rollout_profile.get("decode_steps", Cn - 1)
+    if not ms or steps < 2:
         return None
-    per_step_ms = ms / (C - 1)
+    per_step_ms = ms / steps
     ach = (w_bytes + kv_bytes) / (per_step_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+    return {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
             "bytes_per_step": w_bytes + kv_bytes, "ms_per_token_step": per_step_ms,
-            "kernels": "dec_gemm2_kernel<...> x4 + dec_attn_both + attn_decode_merge per layer, lm_head, sampler"}
+            "kernels": "decode projections + shared-prefix attention per layer, lm_head, sampler"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: re-exec under torch.distributed.run, one process per GPU,
+    the way the reference launches its trainers from one command (sh_reason.sh:38 `deepspeed --num_gpus=...`)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -139,6 +256,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=["grpo", "sft"], default="grpo")
+    ap.add_argument("--prompts-per-gpu", type=int, default=1, help="distinct prompts per GPU (x G=8 rollouts each); headline = 1")
+    ap.add_argument("--eos-uniform", type=int, nargs=2, metavar=("LO", "HI"), default=None,
+                    help="straggler run (SURVEY §8d): every rollout ends at a length drawn from U[LO, HI]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the rollout's decode steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-shared-decode", action="store_true", help="per-copy prompt K/V in the decode attention")
@@ -147,14 +268,20 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the oracle timing leg and print its JSON")
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline()), flush=True)
+        print(json.dumps(cpu_baseline(args.mode)), flush=True)
         return
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
 
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() < max(1, min(world, local + 1)):
+        raise SystemExit(f"rank {rank}: needs GPU {local}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -164,7 +291,7 @@ def main():
     from bioreason_amd import configs, ops
     from bioreason_amd.dna_llm import DNALLMModel
     from bioreason_amd.synth import synth_prompt_batch
-    from bioreason_amd.trainer import GRPOConfig, GRPOStepRunner
+    from bioreason_amd.trainer import GRPOConfig, GRPOStepRunner, SFTStepRunner
 
     model = DNALLMModel(configs.qwen3_config(), configs.nt_v2_config(), device=dev)
     model.text_model.init_weights(0.02, seed=1)          # random-init weights of the real architectures (same on every rank)
@@ -176,22 +303,49 @@ def main():
         if "lora_B" in n:
             p.data.copy_((torch.randn(p.shape, generator=gen) * 0.01).to(dev))
     model.arena.pack()
-    cfg = GRPOConfig(num_generations=G, max_completion_length=args.completion_len, eos_token_id=None, seed=42,
-                     rollout_graph=False if args.no_graph else None, rollout_shared_prefix=not args.no_shared_decode)
-    runner = GRPOStepRunner(model, cfg)
-    batch = synth_prompt_batch(B=G, n_unique=1, Sd=SD, text_len=TEXT_LEN, n_dna=NDNA, dna_token_id=model.dna_token_id,
-                               device=dev, seed=42 + rank)
+    R = args.prompts_per_gpu
+    Cn = args.completion_len
+    if args.mode == "sft":
+        B = 8 * R
+        batch = synth_prompt_batch(B=B, n_unique=B, Sd=SD, text_len=TEXT_LEN, n_dna=NDNA, dna_token_id=model.dna_token_id,
+                                   device=dev, seed=23 + rank)              # seed 23: train_dna_qwen.py:1024
+        batch.pop("dna_alias"), batch.pop("prompt_alias")
+        labels = torch.full_like(batch["input_ids"], -100)
+        labels[:, -SFT_LABEL_TAIL:] = batch["input_ids"][:, -SFT_LABEL_TAIL:]
+        batch["labels"] = labels
+        runner = SFTStepRunner(model, learning_rate=1e-4, weight_decay=0.01)
+        samples_per_step = B
+    else:
+        B = G * R
+        eos_id = 151645 if args.eos_uniform else None
+        cfg = GRPOConfig(num_generations=G, max_completion_length=Cn, eos_token_id=eos_id, pad_token_id=151643 if eos_id else None,
+                         seed=42, rollout_graph=False if args.no_graph else None, rollout_shared_prefix=not args.no_shared_decode)
+        runner = GRPOStepRunner(model, cfg)
+        batch = synth_prompt_batch(B=B, n_unique=R, Sd=SD, text_len=TEXT_LEN, n_dna=NDNA, dna_token_id=model.dna_token_id,
+                                   device=dev, seed=42 + rank)
+        if args.eos_uniform:
+            lo, hi = args.eos_uniform
+            gs = torch.Generator().manual_seed(1000 + rank)
+            # one schedule per step, drawn up front (length L = index of the EOS token + 1)
+            scheds = [(torch.randint(lo, hi + 1, (B,), generator=gs) - 1).to(torch.int32).to(dev)
+                      for _ in range(args.warmup + args.steps + 1)]
+        samples_per_step = B
 
-    for _ in range(args.warmup):
-        runner.step(batch)
+    def one_step(i, timing=False):
+        if args.mode == "grpo" and args.eos_uniform:
+            batch["eos_schedule"] = scheds[min(i, len(scheds) - 1)]
+        return runner.step(batch, timing=timing) if timing else runner.step(batch)
+
+    for i in range(args.warmup):
+        one_step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     ops.GEMM_PROFILE = ops.GemmProfile(dominant_only=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = runner.step(batch)
+    for i in range(args.steps):
+        out = one_step(args.warmup + i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -203,49 +357,66 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # phase breakdown (one extra, untimed, instrumented step)
-    runner.step(batch, timing=True)
+    one_step(args.warmup + args.steps, timing=True)
     loss = float(out["loss_t"].item())
 
     if rank == 0:
-        samples = world * G * args.steps
+        samples = world * samples_per_step * args.steps
         value = samples / elapsed
+        traffic, traffic_note = pmc_traffic() if (args.mode == "grpo" and R == 1 and not args.eos_uniform and Cn == C) else (None, "PMC passes exist for the headline configuration only")
+        ex = executed_flops(R, 2180, Cn, args.mode)
+        if args.mode == "sft":
+            metric = "SFT samples/sec (NT-500M+Qwen3-1.7B, DNA 2x1024, seq 2180, batch 8)"
+            workload = ("SFT step cfg-2: NT-v2-500M encoder + Qwen3-1.7B (LoRA r=32 dropout %g all linears + dna_projection), B=%d distinct "
+                        "samples per GPU, P=2180, labels on the last %d positions, full-row lm_head logits + shifted CE, backward, "
+                        "AdamW; random-init weights" % (args.lora_dropout, B, SFT_LABEL_TAIL))
+        else:
+            metric = "GRPO samples/sec (NT-500M+Qwen3-1.7B, DNA 2x1024, prompt 2180, gen 256)"
+            workload = ("GRPO step cfg-3: NT-v2-500M encoder + Qwen3-1.7B (LoRA r=32 dropout %g all linears + dna_projection), "
+                        "%d prompt x G=8 per GPU, P=2180, C=%d sampled tokens (T=0.6, top-k 20, top-p 0.95)%s, "
+                        "ref logps + policy fwd/bwd + AdamW; random-init weights"
+                        % (args.lora_dropout, R, Cn, (", EOS drawn at U[%d, %d] (straggler run)" % tuple(args.eos_uniform)) if args.eos_uniform else ""))
         line = {
-            "metric": "GRPO samples/sec (NT-500M+Qwen3-1.7B, DNA 2x1024, prompt 2180, gen 256)",
+            "metric": metric,
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "GRPO step cfg-3: NT-v2-500M encoder + Qwen3-1.7B (LoRA r=32 dropout %g all linears + dna_projection), "
-                                   "1 prompt x G=8 per GPU, P=2180, C=%d sampled tokens (T=0.6, top-k 20, top-p 0.95), "
-                                   "ref logps + policy fwd/bwd + AdamW; random-init weights" % (args.lora_dropout, args.completion_len),
-                       "global_batch": world * G, "prompt_len": 2180, "completion_len": args.completion_len, "parallelism": f"dp{world}"},
+            "config": {"workload": workload, "global_batch": world * samples_per_step, "prompt_len": 2180,
+                       "completion_len": Cn if args.mode == "grpo" else 0, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": prof["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": prof["tflops"] / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(),
-                         "traffic_note": "HBM-side bytes per launch, rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + "
-                                         "WRITE_SIZE), collected offline: profiles/r1_c_pmc_gemm.json",
+                         "frac": prof["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "flops_per_launch": prof["flops_per_launch"], "algorithmic_bytes_per_launch": prof["bytes_per_launch"],
-                         "kernel": "gemm_glds_kernel<*, 1> (256x128 LDS-DMA tiles: every projection / lm_head GEMM of the "
+                         "kernel": "gemm_glds_kernel<...> (LDS-DMA MFMA tiles: every projection / lm_head GEMM of the "
                                    "prefill, ref, policy forward and backward passes that fills the chip)",
-                         "launches": prof["launches"], "avg_launch_ms": prof["avg_launch_ms"]},
-            "decode_roofline": decode_roofline(model, runner.rollout_profile, args.completion_len),
-            "rollout_issue": {"mode": "graph" if getattr(model.text_model.engine, "_rollout_use_graph", False) else "eager",
-                              "probe_host_vs_device_ms_per_token": getattr(model.text_model.engine, "_rollout_probe_ms", None)},
-            "step_tflops": value / world * flops_per_sample() / 1e12,
-            "step_frac_of_mfma_peak": value / world * flops_per_sample() / 1e12 / PEAK_BF16_TFLOPS,
+                         "launches": prof["launches"], "avg_launch_ms": prof["avg_launch_ms"],
+                         "kernel_source_sha": kernel_source_sha()},
+            "executed_tflop_per_step": ex / 1e12,
+            "step_tflops_executed": ex / 1e12 / (elapsed / args.steps),
+            "step_frac_of_mfma_peak_executed": ex / 1e12 / (elapsed / args.steps) / PEAK_BF16_TFLOPS,
             "phases_ms": {k: round(v, 2) for k, v in runner.timers.items()},
             "loss": loss,
         }
+        if args.mode == "grpo":
+            line["decode_roofline"] = decode_roofline(model, runner.rollout_profile, Cn, R)
+            line["rollout_issue"] = {"mode": "graph" if getattr(model.text_model.engine, "_rollout_use_graph", False) else "eager",
+                                     "probe_host_vs_device_ms_per_token": getattr(model.text_model.engine, "_rollout_probe_ms", None)}
+            # the reference's accounting (every row re-runs its full prompt and the encoder): an upper bound on executed work
+            line["step_tflops_reference_accounting"] = value / world * flops_per_sample_reference() / 1e12
+            line["step_frac_of_mfma_peak_reference_accounting"] = value / world * flops_per_sample_reference() / 1e12 / PEAK_BF16_TFLOPS
+            if "metrics_t" in out:
+                line["metrics"] = {k: float(v) for k, v in zip(runner.metric_names, out["metrics_t"].tolist())}
         if not args.no_cpu_baseline and world == 1:
             try:   # separate process, hard wall-clock bound: the GPU number must be reported whatever the host does
-                import subprocess
                 env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True,
-                                   text=True, timeout=float(os.environ.get("BENCH_CPU_TIMEOUT", "420")), env=env)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--mode", args.mode],
+                                   capture_output=True, text=True, timeout=float(os.environ.get("BENCH_CPU_TIMEOUT", "420")), env=env)
                 line["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception as e:
                 line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"not measured: {type(e).__name__}"}
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

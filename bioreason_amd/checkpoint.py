@@ -95,7 +95,9 @@ def load_pretrained_pair(text_model_name, dna_model_name, cache_dir, device):
                            "(NT-v2 key names could not be verified offline: SURVEY §8c)")
     tt, dt = _tokenizer(text_model_name), _tokenizer(dna_model_name)
     if tt is not None:                                                # dna_llm.py:68-73
+        from .chat_template import CHAT_TEMPLATE
         tt.pad_token = tt.eos_token
+        tt.chat_template = CHAT_TEMPLATE                              # dna_llm.py:69: {"type": "dna"} items -> placeholders
         tt.add_special_tokens({"additional_special_tokens": NEW_TOKENS})
     processor = None
     if tt is not None and dt is not None:                             # dna_llm.py:100: DLProcessor(tokenizer, dna_tokenizer)
@@ -188,7 +190,22 @@ def _infer_lora_r(tensors) -> Optional[int]:
     return None
 
 
-def load_sft_checkpoint(model, path: str, lora_alpha: float = 64.0, lora_dropout: float = 0.05) -> Tuple[list, list]:
+def _torch_load(path: str, trust_checkpoint: bool):
+    """weights_only first; genuine Lightning / DeepSpeed files also pickle non-tensor objects (hyper-parameter Namespaces,
+    callback and optimiser state) that the safe unpickler refuses — those need the caller's explicit `trust_checkpoint=True`
+    (arbitrary-code unpickling, exactly what the reference's `torch.load(path)` does, reason.py:449)."""
+    import pickle
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError, AttributeError) as e:
+        if not trust_checkpoint:
+            raise RuntimeError(f"bioreason_amd: '{path}' holds pickled objects besides tensors (a Lightning / DeepSpeed checkpoint). "
+                               "Pass trust_checkpoint=True to load it with the full unpickler if you trust the file.") from e
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def load_sft_checkpoint(model, path: str, lora_alpha: float = 64.0, lora_dropout: float = 0.05,
+                        trust_checkpoint: bool = False) -> Tuple[list, list]:
     """reason.py:422-540.  Directory = PEFT adapter (adapter_config.json + adapter_model.*): adapters are loaded and merged
     into the base weights.  File = torch.save'd dict in one of the three layouts; LoRA keys present -> adapters are created
     (if absent) and filled; absent -> base weights are loaded and fresh adapters are left to the caller."""
@@ -205,6 +222,12 @@ def load_sft_checkpoint(model, path: str, lora_alpha: float = 64.0, lora_dropout
         if not any("lora_" in k for k in model.text_model.state_dict()):
             kw = {"target_modules": tuple(ac["target_modules"])} if ac.get("target_modules") else {}
             model.text_model.apply_lora(r=r, alpha=alpha, dropout=float(ac.get("lora_dropout", 0.0)), arena=model.arena, **kw)
+        else:                                                         # the merge below uses the existing groups' r / alpha
+            for L in model.text_model.ensure_packed().layers:
+                for G in L.lora.values():
+                    if G is not None and (G.r != r or abs(G.scaling - alpha / r) > 1e-9):
+                        raise ValueError(f"adapter_config.json says r={r}, lora_alpha={alpha} but the model's adapters were "
+                                         f"created with r={G.r}, scaling={G.scaling}")
         # PEFT saves `base_model.model.<hf name>.lora_A.weight` (adapter name elided)
         renamed = {}
         for k, v in tensors.items():
@@ -213,7 +236,7 @@ def load_sft_checkpoint(model, path: str, lora_alpha: float = 64.0, lora_dropout
         res = load_state_dict_tensors(model, renamed)
         model.text_model.merge_and_unload()                           # reason.py:441-444
         return res
-    ck = torch.load(path, map_location="cpu", weights_only=True)
+    ck = _torch_load(path, trust_checkpoint)
     if "state_dict" in ck:
         tensors = ck["state_dict"]
     elif "module" in ck:

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void topk_slices_kernel(const float* logits, l
 // `p` = k floats of LDS scratch (a per-thread array indexed at run time would live in scratch memory: every access a
 // round trip through the memory system, in a single-thread serial section)
 __device__ inline void sample_pick(float* p, const float* top_v, const int* top_i, int k, int row, float temperature, float top_p,
-                                   int do_sample, uint32_t seed, const int* step_ptr, uint8_t* finished, int pad_id, int eos_id,
+                                   int do_sample, uint32_t seed, const int* step_ptr, uint8_t* finished, int pad_id, int eos_id, int eos_id2,
                                    int* out_ids, float* out_logp, int* tokens_out, long ldt) {
     int choice = top_i[0];
     float lp = 0.f;
@@ -111,14 +111,14 @@ __device__ inline void sample_pick(float* p, const float* top_v, const int* top_
     out_ids[row] = choice;
     if (out_logp) out_logp[row] = lp;
     if (tokens_out) tokens_out[(long)row * ldt + (step_ptr ? step_ptr[0] : 0)] = choice;
-    if (finished && eos_id >= 0 && choice == eos_id) finished[row] = 1;   // unfinished &= (token != eos)
+    if (finished && ((eos_id >= 0 && choice == eos_id) || (eos_id2 >= 0 && choice == eos_id2))) finished[row] = 1;   // unfinished &= (token != eos)
 }
 
 template <int NT>
 __global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ldl, int V, const int* cand_idx, float temperature,
                                                     int top_k, float top_p, int do_sample, uint32_t seed,
                                                     const int* step_ptr, uint8_t* finished, int pad_id,
-                                                    int eos_id, int* out_ids, float* out_logp, int* tokens_out,
+                                                    int eos_id, int eos_id2, int* out_ids, float* out_logp, int* tokens_out,
                                                     long ldt) {
     __shared__ float s_val[NT / 64];
     __shared__ int s_idx[NT / 64];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ld
     }
     __shared__ float pick_ws[64];
     if (tid == 0)
-        sample_pick(pick_ws, top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr, finished, pad_id, eos_id, out_ids,
+        sample_pick(pick_ws, top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr, finished, pad_id, eos_id, eos_id2, out_ids,
                     out_logp, tokens_out, ldt);
 }
 
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ld
 // RMSNorm statistic (bra_row_sumsq layout), which is what the next launch of the token loop consumes.
 __global__ __launch_bounds__(64) void sample_merge_kernel(const float* cand_v, const int* cand_i, int k, float temperature,
                                                           float top_p, int do_sample, uint32_t seed, const int* step_ptr,
-                                                          uint8_t* finished, int pad_id, int eos_id, int* out_ids,
+                                                          uint8_t* finished, int pad_id, int eos_id, int eos_id2, int* out_ids,
                                                           float* out_logp, int* tokens_out, long ldt, const bf16_t* E,
                                                           long lde, int H, bf16_t* x, long ldx, float* ss, int nss) {
     BRA_DYN_SMEM(smem);                           // values [64][k] | indices [64][k]
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void sample_merge_kernel(const float* cand_v, c
     }
     __syncthreads();
     if (lane == 0) {
-        sample_pick(pick_ws, top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr, finished, pad_id, eos_id,
+        sample_pick(pick_ws, top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr, finished, pad_id, eos_id, eos_id2,
                     out_ids, out_logp, tokens_out, ldt);
         s_choice = out_ids[row];
     }
@@ -235,6 +235,14 @@ __global__ __launch_bounds__(64) void sample_merge_kernel(const float* cand_v, c
     }
     acc = wave_sum<64>(acc);
     if (ss) for (int c = lane; c < nss; c += 64) ss[(long)row * nss + c] = c == 0 ? acc : 0.f;
+}
+
+// synthetic EOS schedule (bench / tests: random-init weights never emit EOS on their own): row b's logit of `token` is
+// raised above everything else at the step its schedule names, so the sampler — greedy or warped — draws it there.
+__global__ __launch_bounds__(64) void force_token_kernel(float* logits, long ldl, int B, int token, const int* step_ptr,
+                                                         const int* at) {
+    const int b = (int)threadIdx.x;
+    if (b < B && at[b] == step_ptr[0]) logits[(long)b * ldl + token] = 1.0e30f;
 }
 
 // counters of the replayed token loop: pos[0 .. n) += 1 (rotary positions), a[0] += 1, b[0] += 1 (step index, cache length)
@@ -339,12 +347,13 @@ extern "C" int bra_sample_ws_floats(int B, int top_k) {     // workspace size in
 // row's RMSNorm statistic (bra_row_sumsq layout) — the first two launches of the next decode step.  Needs the two-stage
 // path (ws given, 4096 <= V <= 64 * 4096); returns BRA_ERR_UNSUPPORTED otherwise.
 extern "C" int bra_sample_embed(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p,
-                                int do_sample, unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id,
+                                int do_sample, unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id, int eos_id2,
                                 int* out_ids, float* out_logp, int* tokens_out, long ldt, void* ws, const void* E, long lde,
                                 int H, void* x, long ldx, float* ss, int nss, void* stream) {
     if (B == 0) return 0;
     if (!logits || !out_ids || V <= 0 || (do_sample && temperature <= 0.f)) return BRA_ERR_ARG;
     if (!(ws && V <= kSlices * 4096 && V >= 4096)) return BRA_ERR_UNSUPPORTED;
+    if (do_sample && (top_k <= 0 || top_k > 64)) return BRA_ERR_UNSUPPORTED;   // the warpers run over <= 64 survivors
     if (E && (!x || H % 8 || lde % 8 || ldx % 8)) return BRA_ERR_ARG;
     const int k = do_sample ? (top_k > 0 ? (top_k < 64 ? top_k : 64) : 64) : 1;
     float* cv = (float*)ws;
@@ -353,21 +362,30 @@ extern "C" int bra_sample_embed(const float* logits, long ldl, int B, int V, flo
     int r = BRA_LAUNCH_STATUS();
     if (r) return r;
     BRA_LAUNCH(sample_merge_kernel, dim3(B), dim3(64), (size_t)kSlices * k * 8, stream, (const float*)cv, (const int*)ci, k,
-               temperature, top_p, do_sample, (uint32_t)seed, step_ptr, (uint8_t*)finished, pad_id, eos_id, out_ids, out_logp,
+               temperature, top_p, do_sample, (uint32_t)seed, step_ptr, (uint8_t*)finished, pad_id, eos_id, eos_id2, out_ids, out_logp,
                tokens_out, ldt, (const bf16_t*)E, lde, H, (bf16_t*)x, ldx, ss, nss);
     return BRA_LAUNCH_STATUS();
 }
 
 extern "C" int bra_sample(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p,
-                          int do_sample, unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id,
+                          int do_sample, unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id, int eos_id2,
                           int* out_ids, float* out_logp, int* tokens_out, long ldt, void* ws, void* stream) {
     if (B == 0) return 0;
     if (!logits || !out_ids || V <= 0 || (do_sample && temperature <= 0.f)) return BRA_ERR_ARG;
+    if (do_sample && (top_k <= 0 || top_k > 64)) return BRA_ERR_UNSUPPORTED;       // the warpers run over <= 64 survivors
     if (ws && V <= kSlices * 4096 && V >= 4096)
         return bra_sample_embed(logits, ldl, B, V, temperature, top_k, top_p, do_sample, seed, step_ptr, finished, pad_id,
-                                eos_id, out_ids, out_logp, tokens_out, ldt, ws, nullptr, 0, 0, nullptr, 0, nullptr, 0, stream);
+                                eos_id, eos_id2, out_ids, out_logp, tokens_out, ldt, ws, nullptr, 0, 0, nullptr, 0, nullptr, 0, stream);
     BRA_LAUNCH((sample_kernel<1024>), dim3(B), dim3(1024), 0, stream, logits, ldl, V, (const int*)nullptr, temperature, top_k, top_p,
-               do_sample, (uint32_t)seed, step_ptr, (uint8_t*)finished, pad_id, eos_id, out_ids, out_logp, tokens_out, ldt);
+               do_sample, (uint32_t)seed, step_ptr, (uint8_t*)finished, pad_id, eos_id, eos_id2, out_ids, out_logp, tokens_out, ldt);
+    return BRA_LAUNCH_STATUS();
+}
+
+extern "C" int bra_force_token(float* logits, long ldl, int B, int V, int token, const int* step_ptr, const int* at,
+                               void* stream) {
+    if (B == 0) return 0;
+    if (!logits || !step_ptr || !at || token < 0 || token >= V || B > 64) return BRA_ERR_ARG;
+    BRA_LAUNCH(force_token_kernel, dim3(1), dim3(64), 0, stream, logits, ldl, B, token, step_ptr, at);
     return BRA_LAUNCH_STATUS();
 }
 

@@ -151,6 +151,7 @@ class QwenEngine:
         self.ET: Optional[torch.Tensor] = None
         self._rope = None
         self._rope_len = 0
+        self.layer_done_hook = None          # called with the layer index when a layer's backward (its LoRA grads) is complete
 
     # ------------------------------------------------------------------ helpers
     def rope(self, npos: int):
@@ -271,6 +272,8 @@ class QwenEngine:
         for li in reversed(range(self.L)):
             dx = self.layer_bwd(li, dx, tape[li], m)
             tape[li] = None
+            if self.layer_done_hook is not None:
+                self.layer_done_hook(li)
         return dx
 
 

@@ -258,13 +258,17 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
              check_every: int = 16, return_full_length: bool = False,
              force_tokens: Optional[torch.Tensor] = None, native_step: bool = True,
              decode_impl: str = "fused", prompt_alias=None, use_graph: Optional[bool] = None,
-             shared_prefix_decode: bool = True, profile: Optional[dict] = None) -> torch.Tensor:
+             shared_prefix_decode: bool = True, profile: Optional[dict] = None,
+             eos_schedule: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`force_tokens` [B, max_new_tokens] (optional): teacher forcing — the model's own choice is still recorded
     in the output, but the given token is fed back (used to compare decodes position by position).
     `use_graph`: True = sample + decode step + counter update are captured once in a hipGraph and replayed per token
     (a step is ~180 dependent launches of a few microseconds each; a slow host issuing them one by one makes the
     rollout launch-bound); False = eager issue; None (default) = measured once per engine: eager unless the host
-    cannot stay ahead of the device."""
+    cannot stay ahead of the device.
+    `eos_token_id` may be an int or a list of up to two ids (HF stops a row on any listed id; Qwen3's generation_config
+    lists two); the first one is the pad default.  `eos_schedule` int32 [B] (benchmarks / tests with random-init weights):
+    row b is made to draw the first EOS id at step eos_schedule[b]."""
     eng = model.ensure_packed()
     B, P, H = inputs_embeds.shape
     dev = inputs_embeds.device
@@ -280,9 +284,16 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             profile[name] = profile.get(name, 0.0) + (now - _t0[0]) * 1e3
             _t0[0] = now
 
+    eos2 = -1
     if isinstance(eos_token_id, (list, tuple)):
-        eos_token_id = eos_token_id[0]
+        ids_ = list(dict.fromkeys(int(e) for e in eos_token_id))
+        if len(ids_) > 2:
+            raise NotImplementedError("at most two eos_token_id values are supported by the device-side sampler")
+        eos2 = ids_[1] if len(ids_) > 1 else -1
+        eos_token_id = ids_[0] if ids_ else None
     eos = -1 if eos_token_id is None else int(eos_token_id)
+    if eos_schedule is not None:
+        assert eos >= 0 and eos_schedule.dtype == torch.int32 and eos_schedule.numel() == inputs_embeds.shape[0]
     pad = int(pad_token_id) if pad_token_id is not None else (eos if eos >= 0 else 0)
     Smax = P + max_new_tokens
     am = attention_mask.to(torch.long)
@@ -347,8 +358,10 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
                   and B <= 8)
 
     def sample_():
+        if eos_schedule is not None:
+            ops.force_token(logits, eos, step_t, eos_schedule)
         ops.sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished if eos >= 0 else None, pad,
-                   cur, None, eos_id=eos, tokens_out=tokens, ws=sample_ws,
+                   cur, None, eos_id=eos, eos_id2=eos2, tokens_out=tokens, ws=sample_ws,
                    embed=(eng.E, dstate.x, dstate.ss_ws[0]) if fuse_embed else None)
 
     def advance_(t_grid: int):
@@ -445,7 +458,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     out = tokens[:, :n_done]
     if eos >= 0 and not return_full_length and force_tokens is None:
         # HF stops right after the step in which the last row finished: trim the all-pad tail we may have produced
-        is_eos = out == eos
+        is_eos = (out == eos) | (out == eos2) if eos2 >= 0 else out == eos
         has = is_eos.any(dim=1)
         first = torch.where(has, is_eos.int().argmax(dim=1), torch.full_like(has, out.shape[1] - 1, dtype=torch.long))
         out = out[:, : int(first.max().item()) + 1]

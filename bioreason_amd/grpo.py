@@ -73,19 +73,11 @@ def group_advantages(rewards_per_func: torch.Tensor, num_generations: int, rank:
 
 
 def repeat_sampler_indices(num_samples: int, mini_repeat_count: int, batch_size: int = 1, repeat_count: int = 1, seed: int = 0) -> List[int]:
-    """RepeatRandomSampler (grpo_trainer.py:72-119): every rank draws the same permutation, each prompt index is
-    emitted `mini_repeat_count` (= G) times consecutively; the launcher then shards the stream across ranks."""
-    g = torch.Generator().manual_seed(seed)
-    perm = torch.randperm(num_samples, generator=g).tolist()
-    chunks = [perm[i:i + batch_size] for i in range(0, len(perm), batch_size)]
-    out: List[int] = []
-    for chunk in chunks:
-        if len(chunk) != batch_size:
-            continue
-        for _ in range(repeat_count):
-            for index in chunk:
-                out.extend([index] * mini_repeat_count)
-    return out
+    """the index stream of `RepeatRandomSampler` (grpo_trainer.py:72-119; class in grpo_trainer.py of this package): every
+    rank draws the same permutation, each prompt index is emitted `mini_repeat_count` (= G) times consecutively; the launcher
+    then shards the stream across ranks."""
+    from .grpo_trainer import RepeatRandomSampler
+    return list(RepeatRandomSampler(range(num_samples), mini_repeat_count, batch_size, repeat_count, seed))
 
 
 @torch.no_grad()

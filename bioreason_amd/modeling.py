@@ -331,6 +331,7 @@ class Qwen3ForCausalLM(nn.Module):
             return self
         self.arena.pack()
         gen = torch.Generator(device="cpu").manual_seed(reinit_seed)
+        merged = {}
         for L in eng.layers:
             for gname, wname in (("qkv", "Wqkv"), ("o", "Wo"), ("gu", "Wgu"), ("d", "Wd")):
                 G = L.lora[gname]
@@ -338,12 +339,29 @@ class Qwen3ForCausalLM(nn.Module):
                     continue
                 W = getattr(L, wname)
                 W.copy_(ops.gemm_nt(G.B, G.AT, alpha=G.scaling, res=W))           # [N, K] = s * B A + W
+                merged[(id(L), wname)] = W
                 for j in range(len(G.n_sizes)):
                     A, B, _, _ = G.target_views(j)
                     if getattr(G, "active", None) is None or G.active[j]:
                         A.copy_((torch.randn(A.shape, generator=gen) * (1.0 / G.r)).to(A.device))
                     B.zero_()
         self.arena.pack()
+        # the packed images alias the parameters only when those are bf16; otherwise write the merge back into the
+        # parameters themselves so the repack below (and any later one) starts from the merged weights
+        for l, L in zip(self.model.layers, eng.layers):
+            a, m = l.self_attn, l.mlp
+            for wname, mods in (("Wqkv", (a.q_proj, a.k_proj, a.v_proj)), ("Wo", (a.o_proj,)), ("Wgu", (m.gate_proj, m.up_proj)),
+                                ("Wd", (m.down_proj,))):
+                W = merged.get((id(L), wname))
+                if W is None:
+                    continue
+                off = 0
+                for mod in mods:
+                    p = _unwrap(mod).weight
+                    n = p.shape[0]
+                    if p.dtype != BF16:
+                        p.data.copy_(W[off:off + n].to(p.dtype))
+                    off += n
         self._packed_sig = None                                                   # transposed weight images are stale
         self.ensure_packed()
         return self

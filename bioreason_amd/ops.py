@@ -369,10 +369,13 @@ def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- GRPO / optimiser
 def sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished, pad_id, out_ids, out_logp=None,
-           eos_id=-1, tokens_out=None, ws=None, embed=None):
+           eos_id=-1, tokens_out=None, ws=None, embed=None, eos_id2=-1):
     """`embed` = (E [V, H], x [B, H], ss [8, nss] or None): the drawing wave also writes x[b] = E[token] and the RMSNorm
     statistic of that row (two-stage path only: V >= 4096)."""
     B, V = logits.shape
+    if do_sample and not (1 <= top_k <= 64):
+        raise NotImplementedError("sampling needs 1 <= top_k <= 64 on the HIP path: temperature / top-p / multinomial run over "
+                                  "at most 64 survivors (HF's top_k=0 'disabled' is not supported; GRPO uses top_k=20)")
     if ws is None and V >= 4096:
         k = min(top_k, 64) if top_k > 0 else 64
         ws = torch.empty((2 * B * 64 * k,), dtype=torch.float32, device=logits.device)
@@ -380,12 +383,18 @@ def sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished,
     if embed is not None:
         E, x, ss = embed
         get_lib().call("bra_sample_embed", logits, _ld(logits), B, V, temperature, top_k, top_p, int(do_sample),
-                       seed & 0xFFFFFFFF, step_t, finished, pad_id, eos_id, out_ids, out_logp, tokens_out, ldt, ws, E, _ld(E),
+                       seed & 0xFFFFFFFF, step_t, finished, pad_id, eos_id, eos_id2, out_ids, out_logp, tokens_out, ldt, ws, E, _ld(E),
                        E.shape[1], x, _ld(x), ss, ss.shape[-1] if ss is not None else 0, current_stream(logits))
         return out_ids
     get_lib().call("bra_sample", logits, _ld(logits), B, V, temperature, top_k, top_p, int(do_sample), seed & 0xFFFFFFFF,
-                   step_t, finished, pad_id, eos_id, out_ids, out_logp, tokens_out, ldt, ws, current_stream(logits))
+                   step_t, finished, pad_id, eos_id, eos_id2, out_ids, out_logp, tokens_out, ldt, ws, current_stream(logits))
     return out_ids
+
+
+def force_token(logits: torch.Tensor, token: int, step_t: torch.Tensor, at: torch.Tensor):
+    """logits[b, token] = +big where at[b] == step_t[0] (synthetic EOS schedule of the straggler bench / tests)"""
+    B, V = logits.shape
+    get_lib().call("bra_force_token", logits, _ld(logits), B, V, int(token), step_t, at, current_stream(logits))
 
 
 def advance_counters(pos: torch.Tensor, a: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None):

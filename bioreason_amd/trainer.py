@@ -1,15 +1,24 @@
-"""One GRPO training step on the HIP DNA-LLM, data-parallel over the GPUs of a node.
+"""Training steps on the HIP DNA-LLM, data-parallel over the GPUs of a node.
 
-Mirrors DNALLMGRPOTrainer.compute_loss / _generate_and_score_completions (grpo_trainer.py:535-814) for
-num_iterations == 1 (the reference's default):
-    rollout (generate)  ->  EOS mask  ->  reference log-probs (adapters disabled, :636-640)  ->  rewards
+`GRPOStepRunner` mirrors DNALLMGRPOTrainer.compute_loss / _generate_and_score_completions (grpo_trainer.py:535-814):
+    rollout (generate)  ->  EOS mask  ->  [old policy log-probs when num_iterations > 1, :620-626]
+    ->  reference log-probs (adapters disabled, :636-640)  ->  rewards
     ->  all-gather of rewards over ranks (:679)  ->  group advantages, local slice (:682-699)
     ->  policy log-probs (:777-779)  ->  clipped objective + beta*KL (:786-807)  ->  backward
-    ->  gradient all-reduce  ->  AdamW (+ grad clip).
+    ->  gradient all-reduce  ->  AdamW (+ grad clip),
+with the reference's rollout buffering: one buffered rollout per gradient-accumulation slot, regenerated every
+`num_iterations` optimiser steps (:757-762).
+`SFTStepRunner` is the train_dna_qwen.py step (:179-213 `_step` -> outputs.loss, AdamW :393-397).
+
 Parallelism: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).  The path has exactly two
-exchange steps, both on tiny or single-bucket payloads: the reward all-gather (one packed [B_local, F] fp32
-message) and ONE all-reduce over the flat gradient arena (≈148 MB fp32 for Qwen3-1.7B r=32).  No model sharding:
-NT-500M + Qwen3-1.7B + KV cache + activations use < 60 GB of the 288 GB HBM.
+exchange steps, both on tiny or single-bucket payloads:
+  * ONE all-gather of a packed [B_local, F + 1] fp32 record per rollout (rewards per function + completion length —
+    the reference issues `accelerator.gather` once plus four `gather_for_metrics`, :679-716);
+  * the all-reduce of the flat gradient arena (≈148 MB fp32 for Qwen3-1.7B r=32), cut into a few layer-aligned
+    buckets that are issued from inside the backward as soon as their layers are done (overlap with the rest of the
+    backward); the per-rank scalars of compute_loss's metrics (loss, KL, clip ratio, :803-812) ride in a spare slot of
+    the first bucket instead of three more collectives.
+No model sharding: NT-500M + Qwen3-1.7B + KV cache + activations use < 60 GB of the 288 GB HBM.
 """
 from __future__ import annotations
 
@@ -20,6 +29,8 @@ import torch
 import torch.distributed as dist
 
 from . import grpo
+
+METRIC_SLOT = "__dp_metrics__"
 
 
 @dataclass
@@ -33,6 +44,8 @@ class GRPOConfig:
     beta: float = 0.04
     epsilon: float = 0.2
     epsilon_high: Optional[float] = None
+    num_iterations: int = 1
+    gradient_accumulation_steps: int = 1
     learning_rate: float = 1e-5
     weight_decay: float = 0.0
     adam_beta1: float = 0.9
@@ -42,15 +55,16 @@ class GRPOConfig:
     eos_token_id: Optional[int] = None
     pad_token_id: Optional[int] = None
     seed: int = 42
-    # execution knobs of the rollout (no effect on the arithmetic): hipGraph replay of the token loop, and decode
-    # attention over one shared copy of each prompt's K/V
+    # execution knobs (no effect on the arithmetic): hipGraph replay of the token loop, decode attention over one shared
+    # copy of each prompt's K/V, number of gradient buckets overlapped with the backward
     rollout_graph: Optional[bool] = None
     rollout_shared_prefix: bool = True
+    grad_buckets: int = 4
 
 
 def token_stat_rewards(completion_ids: torch.Tensor, completion_mask: torch.Tensor) -> torch.Tensor:
-    """Stand-in reward functions for synthetic runs (the reference's are CPU regexes over decoded text,
-    reason.py:193-230, and there is no tokenizer offline): two cheap statistics of the sampled ids -> [B, 2] fp32."""
+    """Stand-in reward functions for synthetic runs without a tokenizer: two cheap statistics of the sampled ids ->
+    [B, 2] fp32 (the reference's are CPU regexes over decoded text, reason.py:193-230; see `text_reward_fn`)."""
     m = completion_mask.float()
     n = m.sum(1).clamp(min=1)
     r0 = ((completion_ids % 7 == 0).float() * m).sum(1) / n * 2.0
@@ -58,21 +72,88 @@ def token_stat_rewards(completion_ids: torch.Tensor, completion_mask: torch.Tens
     return torch.stack([r0, r1], dim=1)
 
 
-class GRPOStepRunner:
-    def __init__(self, model, cfg: GRPOConfig, reward_fn: Callable = token_stat_rewards):
-        self.model, self.cfg, self.reward_fn = model, cfg, reward_fn
+def text_reward_fn(processing_class, reward_funcs: List[Callable], prompts=None, extra: Optional[Dict[str, list]] = None) -> Callable:
+    """The reference's reward hop (grpo_trainer.py:643-676): completion ids -> host -> batch_decode -> python reward
+    functions on conversational completions -> [B, F] fp32 back on the device."""
+    def fn(completion_ids: torch.Tensor, completion_mask: torch.Tensor) -> torch.Tensor:
+        texts = processing_class.batch_decode(completion_ids.cpu(), skip_special_tokens=True)
+        completions = [[{"role": "assistant", "content": t}] for t in texts]
+        cols = [f(prompts=prompts, completions=completions, **(extra or {})) for f in reward_funcs]
+        return torch.tensor(cols, dtype=torch.float32).t().contiguous().to(completion_ids.device)
+    return fn
+
+
+# =============================================================================================== data-parallel plumbing
+class _DataParallelStep:
+    """Gradient reduction + optimiser shared by the GRPO and SFT steps: layer-aligned buckets of the flat gradient arena are
+    all-reduced asynchronously from inside the backward (engine.layer_done_hook), the tail bucket (first layers + the
+    projection, whose gradients arrive last) after it; AdamW + global-norm clip is one fused launch."""
+
+    def __init__(self, model, n_buckets: int = 4):
+        self.model = model
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.step_idx = 0
-        if hasattr(model.text_model, "set_dropout_seed"):          # every rank draws its own LoRA dropout masks, as separate
-            model.text_model.set_dropout_seed(cfg.seed * 1000003 + self.rank)   # processes with their own RNG streams do
         self.timers: Dict[str, float] = {}
-        self.rollout_profile: Dict[str, float] = {}      # filled by step(timing=True): phases inside generate(), ms
+        self._handles: List = []
+        self._cuts: Dict[int, tuple] = {}
+        self._n_buckets = max(1, int(n_buckets))
+        arena = model.arena
+        if self.world > 1 and METRIC_SLOT not in arena._shapes:
+            arena.add(METRIC_SLOT, 1, 64)            # mask stays 0: excluded from the norm and from the update
+            arena.commit()
+            arena.pack()
+        self._plan_buckets()
 
-    def step(self, batch: Dict, timing: bool = False) -> Dict[str, float]:
-        m, c = self.model, self.cfg
-        dev = batch["input_ids"].device
-        ev = None
+    def _plan_buckets(self):
+        """bucket k = the arena range of a run of consecutive decoder layers, issued when the LOWEST layer of the run has
+        finished its backward (layers finish from the top down); everything below the last cut goes after the backward"""
+        a = self.model.arena
+        eng = self.model.text_model.ensure_packed()
+        L = eng.L
+        starts = []
+        for li in range(L):
+            offs = [a._offsets[k] for k in a._offsets if k.startswith(f"text.layers.{li}.")]
+            starts.append(min(offs) if offs else None)
+        self._cuts = {}
+        if self.world == 1 or any(s is None for s in starts) or sorted(starts) != starts:
+            return
+        nb = min(self._n_buckets, L)
+        hi = a.numel
+        for k in range(nb - 1):
+            lo_layer = L - (k + 1) * L // nb
+            if lo_layer <= 0:
+                break
+            lo = starts[lo_layer]
+            if lo < hi:
+                self._cuts[lo_layer] = (lo, hi)
+                hi = lo
+        self._tail_hi = hi
+
+    def _layer_done(self, li: int):
+        cut = self._cuts.get(li)
+        if cut is not None:
+            self._handles.append(dist.all_reduce(self.model.arena.grads[cut[0]:cut[1]], async_op=True))
+
+    def begin_backward(self):
+        self._handles = []
+        eng = self.model.text_model.engine
+        eng.layer_done_hook = self._layer_done if (self.world > 1 and self._cuts) else None
+
+    def reduce_gradients(self) -> float:
+        """finish the data-parallel sum; returns the factor that turns the sum into DDP's mean"""
+        if self.world == 1:
+            return 1.0
+        eng = self.model.text_model.engine
+        eng.layer_done_hook = None
+        g = self.model.arena.grads
+        hi = self._tail_hi if self._cuts else g.numel()
+        self._handles.append(dist.all_reduce(g[:hi], async_op=True))
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        return 1.0 / self.world
+
+    def _marks(self, timing: bool, dev):
         marks: List = []
 
         def mark(name):
@@ -80,27 +161,57 @@ class GRPOStepRunner:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 marks.append((name, e))
+        return marks, mark
 
-        if timing:
-            self.rollout_profile.clear()
+    def _close_marks(self, marks):
+        if marks:
+            torch.cuda.synchronize()
+            for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+                self.timers[n1] = self.timers.get(n1, 0.0) + e0.elapsed_time(e1)
+
+
+# =============================================================================================== GRPO
+class GRPOStepRunner(_DataParallelStep):
+    metric_names = ["completion_length", "reward", "reward_std", "loss", "kl", "clip_ratio"]
+
+    def __init__(self, model, cfg: GRPOConfig, reward_fn: Callable = token_stat_rewards):
+        super().__init__(model, cfg.grad_buckets)
+        self.cfg, self.reward_fn = cfg, reward_fn
+        self.global_step = 0                # optimiser steps (HF: self.state.global_step)
+        self._step = 0                      # forward/backward passes, incl. those inside an accumulation cycle (:395)
+        self.step_idx = 0                   # rollouts generated (seeds the sampler)
+        self._buffered_inputs: List[Optional[Dict]] = [None] * max(1, cfg.gradient_accumulation_steps)
+        if hasattr(model.text_model, "set_dropout_seed"):          # every rank draws its own LoRA dropout masks, as separate
+            model.text_model.set_dropout_seed(cfg.seed * 1000003 + self.rank)   # processes with their own RNG streams do
+        self.rollout_profile: Dict[str, float] = {}      # filled by step(timing=True): phases inside generate(), ms
+
+    # ---- _generate_and_score_completions (:535-749) ---------------------------------------------------------------
+    def generate_and_score(self, batch: Dict, timing: bool = False, mark=lambda n: None) -> Dict:
+        m, c = self.model, self.cfg
+        dev = batch["input_ids"].device
         mm = {"dna_tokenized": batch["dna_tokenized"], "batch_idx_map": batch["batch_idx_map"], "dna_alias": batch.get("dna_alias")}
         prompt_ids, prompt_mask = batch["input_ids"], batch["attention_mask"]
         B = prompt_ids.shape[0]
-        mark("start")
-        # ---- rollout (unwrapped_model.generate, :579-596): only completion ids come back
+        sched = batch.get("eos_schedule")
+        # rollout (unwrapped_model.generate, :579-596): only completion ids come back
         completion_ids = m.generate(input_ids=prompt_ids, attention_mask=prompt_mask, **mm,
                                     max_new_tokens=c.max_completion_length, do_sample=True, temperature=c.temperature,
                                     top_k=c.top_k, top_p=c.top_p, eos_token_id=c.eos_token_id, pad_token_id=c.pad_token_id,
-                                    seed=c.seed + 1000003 * self.step_idx + self.rank, return_full_length=True,
+                                    seed=c.seed + 1000003 * self.step_idx + self.rank, return_full_length=sched is None,
                                     prompt_alias=batch.get("prompt_alias"), use_graph=c.rollout_graph,
-                                    shared_prefix_decode=c.rollout_shared_prefix,
+                                    shared_prefix_decode=c.rollout_shared_prefix, eos_schedule=sched,
                                     profile=self.rollout_profile if timing else None)
+        self.step_idx += 1
         mark("rollout")
         if c.eos_token_id is not None:
             cmask = grpo.completion_mask(completion_ids, c.eos_token_id)
         else:
             cmask = torch.ones(completion_ids.shape, dtype=torch.int32, device=dev)
-        # ---- reference policy = the same network with adapters disabled (:636-640)
+        old_lp = None
+        if c.num_iterations > 1:            # :620-626 — the sampling policy's log-probs, adapters ON, no grad
+            with torch.no_grad():
+                old_lp = grpo.per_token_logps(m, prompt_ids, prompt_mask, completion_ids, cmask, **mm).detach()
+        # reference policy = the same network with adapters disabled (:636-640)
         ref_lp = None
         if c.beta != 0.0:
             with torch.no_grad(), m.text_model.disable_adapter():
@@ -110,37 +221,109 @@ class GRPOStepRunner:
                 else:
                     ref_lp = grpo.per_token_logps(m, prompt_ids, prompt_mask, completion_ids, cmask, **mm)
         mark("ref_logps")
-        # ---- rewards, all-gather over ranks, group statistics, local slice (:651-699)
-        rewards = self.reward_fn(completion_ids, cmask).float().contiguous()
+        # rewards (+ completion length) -> ONE all-gather -> group statistics -> local slice (:651-699, 703-716)
+        rewards = self.reward_fn(completion_ids, cmask).float()
+        packed = torch.cat([rewards, cmask.sum(1, keepdim=True).float()], dim=1).contiguous()
         if self.world > 1:
-            gathered = [torch.empty_like(rewards) for _ in range(self.world)]
-            dist.all_gather(gathered, rewards)
-            all_rewards = torch.cat(gathered, dim=0)
+            gathered = [torch.empty_like(packed) for _ in range(self.world)]
+            dist.all_gather(gathered, packed)
+            packed_all = torch.cat(gathered, dim=0)
         else:
-            all_rewards = rewards
+            packed_all = packed
+        F = rewards.shape[1]
+        all_rewards = packed_all[:, :F].contiguous()
         adv, gmean, gstd = grpo.group_advantages(all_rewards, c.num_generations, self.rank, B)
+        roll_metrics = torch.stack([packed_all[:, F].mean(), all_rewards.sum(1).mean(), gstd.mean()])
         mark("rewards")
-        # ---- policy forward / loss / backward (:777-814)
-        m.arena.zero_grad()
-        lp = grpo.per_token_logps(m, prompt_ids, prompt_mask, completion_ids, cmask, **mm)
+        return {"prompt_ids": prompt_ids, "prompt_mask": prompt_mask, "completion_ids": completion_ids, "completion_mask": cmask,
+                "old_per_token_logps": old_lp, "ref_per_token_logps": ref_lp, "advantages": adv, "multimodal_inputs": mm,
+                "rewards_per_func": all_rewards.mean(0), "roll_metrics": roll_metrics}
+
+    # ---- compute_loss (:751-814) ----------------------------------------------------------------------------------
+    def compute_loss(self, inputs: Dict):
+        m, c = self.model, self.cfg
+        lp = grpo.per_token_logps(m, inputs["prompt_ids"], inputs["prompt_mask"], inputs["completion_ids"],
+                                  inputs["completion_mask"], **inputs["multimodal_inputs"])
         eps_hi = c.epsilon_high if c.epsilon_high is not None else c.epsilon
-        loss, stats = grpo.grpo_loss(lp, None, ref_lp, adv, cmask, c.epsilon, eps_hi, c.beta)
-        mark("policy_fwd")
-        loss.backward()
-        mark("policy_bwd")
-        # ---- gradient reduction: one flat bucket (DDP averages)
-        if self.world > 1:
-            dist.all_reduce(m.arena.grads)
-            scale = 1.0 / self.world
+        old = inputs["old_per_token_logps"] if c.num_iterations > 1 else None          # :786
+        return grpo.grpo_loss(lp, old, inputs["ref_per_token_logps"], inputs["advantages"], inputs["completion_mask"],
+                              c.epsilon, eps_hi, c.beta)
+
+    def step(self, batch: Dict, timing: bool = False) -> Dict[str, torch.Tensor]:
+        """one HF `training_step`: one forward/backward over one micro-batch; the optimiser runs when the accumulation cycle
+        closes.  `batch` is ignored (the buffered rollout is reused) on the passes the reference reuses it (:757-762)."""
+        m, c = self.model, self.cfg
+        dev = batch["input_ids"].device
+        marks, mark = self._marks(timing, dev)
+        if timing:
+            self.rollout_profile.clear()
+            self.timers.clear()
+        ga = max(1, c.gradient_accumulation_steps)
+        slot = self._step % ga
+        mark("start")
+        if self.global_step % c.num_iterations == 0:
+            inputs = self.generate_and_score(batch, timing, mark)
+            self._buffered_inputs[slot] = inputs
         else:
-            scale = 1.0
-        m.arena.adamw_step(c.learning_rate, (c.adam_beta1, c.adam_beta2), c.adam_epsilon, c.weight_decay,
-                           max_grad_norm=c.max_grad_norm, grad_scale=scale)
+            inputs = self._buffered_inputs[slot]
+        self._step += 1
+        if slot == 0:
+            m.arena.zero_grad()
+        if slot == ga - 1:
+            self.begin_backward()
+        loss, stats = self.compute_loss(inputs)
+        mark("policy_fwd")
+        if self.world > 1:                  # loss / KL / clip ratio of this rank ride in the gradient bucket's spare slot
+            m.arena.grad(METRIC_SLOT).view(-1)[:3].add_(stats / ga)
+        (loss / ga if ga > 1 else loss).backward()
+        mark("policy_bwd")
+        out = {"loss_t": loss.detach(), "stats_t": stats, "reward_mean_t": inputs["roll_metrics"][1]}
+        if slot == ga - 1:
+            scale = self.reduce_gradients()
+            if self.world > 1:
+                local3 = m.arena.grad(METRIC_SLOT).view(-1)[:3] * scale
+            else:
+                local3 = stats
+            m.arena.adamw_step(c.learning_rate, (c.adam_beta1, c.adam_beta2), c.adam_epsilon, c.weight_decay,
+                               max_grad_norm=c.max_grad_norm, grad_scale=scale)
+            self.global_step += 1
+            out["metrics_t"] = torch.cat([inputs["roll_metrics"], local3.detach().clone()])
+            out["rewards_per_func_t"] = inputs["rewards_per_func"]
         mark("optimizer")
-        self.step_idx += 1
-        out = {"loss_t": loss.detach(), "stats_t": stats, "reward_mean_t": all_rewards.sum(1).mean()}
-        if timing and marks:
-            torch.cuda.synchronize()
-            for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
-                self.timers[n1] = e0.elapsed_time(e1)
+        if timing:
+            self._close_marks(marks)
         return out
+
+
+# =============================================================================================== SFT
+class SFTStepRunner(_DataParallelStep):
+    """train_dna_qwen.py:179-213 + :393-397: forward (loss + full-row logits, `outputs.logits` being part of the model
+    contract), backward, DDP-mean of the gradients, AdamW.  One call = one optimiser step over one local batch."""
+
+    def __init__(self, model, learning_rate: float = 1e-4, weight_decay: float = 0.01, max_grad_norm: float = 1.0,
+                 n_buckets: int = 4, return_logits: bool = True):
+        super().__init__(model, n_buckets)
+        self.lr, self.wd, self.max_grad_norm, self.return_logits = learning_rate, weight_decay, max_grad_norm, return_logits
+        if hasattr(model.text_model, "set_dropout_seed"):
+            model.text_model.set_dropout_seed(23 * 1000003 + self.rank)
+
+    def step(self, batch: Dict, timing: bool = False) -> Dict[str, torch.Tensor]:
+        m = self.model
+        dev = batch["input_ids"].device
+        marks, mark = self._marks(timing, dev)
+        if timing:
+            self.timers.clear()
+        mark("start")
+        m.arena.zero_grad()
+        self.begin_backward()
+        out = m(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], dna_tokenized=batch["dna_tokenized"],
+                batch_idx_map=batch["batch_idx_map"], labels=batch["labels"], return_logits=self.return_logits)
+        mark("forward")
+        out.loss.backward()
+        mark("backward")
+        scale = self.reduce_gradients()
+        m.arena.adamw_step(self.lr, (0.9, 0.999), 1e-8, self.wd, max_grad_norm=self.max_grad_norm, grad_scale=scale)
+        mark("optimizer")
+        if timing:
+            self._close_marks(marks)
+        return {"loss_t": out.loss.detach()}

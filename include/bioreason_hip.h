@@ -243,9 +243,12 @@ int bra_adamw(float* p, const float* g, float* m, float* v, const void* mask, lo
  * (TF:generation/logits_process.py:238,473,542; TF:generation/utils.py:2897-2925; grpo_trainer.py:384-391) */
 /* finished[B] (bytes, in/out): a finished row emits pad_id; a row that emits eos_id becomes finished
  * (HF: next = next*unfinished + pad*(1-unfinished); unfinished &= next != eos).  tokens_out[row*ldt + *step_ptr]
- * receives the token (the [B, C] completion matrix), step_ptr is a device int so a replayed launch advances. */
+ * receives the token (the [B, C] completion matrix), step_ptr is a device int so a replayed launch advances.
+ * eos_id2: a second stop token (HF accepts a list; Qwen3's generation_config has two), -1 = none.
+ * do_sample with top_k outside 1..64 is BRA_ERR_UNSUPPORTED: the temperature / top-p / multinomial stage runs over at
+ * most 64 survivors (HF's top_k = 0 "disabled" would need a full-vocabulary sort). */
 int bra_sample(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p,
-               int do_sample, unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id,
+               int do_sample, unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id, int eos_id2,
                int* out_ids, float* out_logp, int* tokens_out, long ldt, void* ws, void* stream);
 /* ws (optional, bra_sample_ws_floats(B, top_k) 4-byte words): enables the two-stage top-k (64 vocabulary slices
  * per row in parallel, then a merge) instead of one workgroup per row scanning the vocabulary k times */
@@ -255,9 +258,12 @@ int bra_sample_ws_floats(int B, int top_k);
  * the first projection (`embed_done`).  E may be null (sampling only).  BRA_ERR_UNSUPPORTED without ws / outside
  * 4096 <= V <= 262144. */
 int bra_sample_embed(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p, int do_sample,
-                     unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id, int* out_ids,
+                     unsigned seed, const int* step_ptr, void* finished, int pad_id, int eos_id, int eos_id2, int* out_ids,
                      float* out_logp, int* tokens_out, long ldt, void* ws, const void* E, long lde, int H, void* x, long ldx,
                      float* ss, int nss, void* stream);
+/* synthetic EOS schedule for benchmarks / tests with random-init weights (SURVEY 8d "straggler run"): logits[b, token]
+ * is raised above every other entry when *step_ptr == at[b], so row b draws `token` at that step.  B <= 64. */
+int bra_force_token(float* logits, long ldl, int B, int V, int token, const int* step_ptr, const int* at, void* stream);
 /* counters of the replayed token loop: pos[0..n) += 1, a[0] += 1, b[0] += 1 (a, b optional) */
 int bra_advance_counters(int* pos, int n, int* a, int* b, void* stream);
 /* completion mask up to and including the first EOS (grpo_trainer.py:605-609) */

@@ -49,8 +49,17 @@ def _worker(rank, world, port, emu_path, q):
     dist.all_gather(params, m.arena.params)
     grads = [torch.empty_like(m.arena.grads) for _ in range(world)]
     dist.all_gather(grads, m.arena.grads)
+    got_adv = runner._buffered_inputs[0]["advantages"]
+    # the packed metric record: every rank must hold the same global means (completion length, reward, group std,
+    # and loss / KL / clip ratio averaged over ranks through the gradient bucket's spare slot)
+    mets = [torch.empty_like(out["metrics_t"]) for _ in range(world)]
+    dist.all_gather(mets, out["metrics_t"])
+    losses = [torch.empty_like(out["loss_t"].reshape(1)) for _ in range(world)]
+    dist.all_gather(losses, out["loss_t"].reshape(1))
+    want_loss = float(torch.cat(losses).mean())
     q.put((rank, bool(torch.equal(params[0], params[1])), bool(torch.equal(grads[0], grads[1])),
-           float((m.arena.params - p0).abs().max()), float(out["loss_t"]), want_adv.tolist()))
+           float((m.arena.params - p0).abs().max()), float(out["loss_t"]), want_adv.tolist(), got_adv.tolist(),
+           bool(torch.equal(mets[0], mets[1])), out["metrics_t"].tolist(), want_loss, float(allr.mean()), len(runner._cuts)))
     dist.destroy_process_group()
 
 
@@ -65,8 +74,15 @@ def test_grpo_step_two_ranks(emu_lib_path):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, same_p, same_g, moved, loss, adv in res:
+    for rank, same_p, same_g, moved, loss, want_adv, got_adv, same_m, mets, want_loss, want_reward, ncuts in res:
         assert same_p, "replicas diverged after the optimiser step"
         assert same_g, "gradient bucket differs across ranks after the all-reduce"
         assert moved > 0, "parameters did not move"
         assert loss == loss
+        # the advantages every rank trains on = its slice of the statistics of the GATHERED rewards (grpo_trainer.py:679-699)
+        assert torch.allclose(torch.tensor(got_adv), torch.tensor(want_adv), atol=1e-5), (rank, got_adv, want_adv)
+        assert same_m, "metric record differs across ranks"
+        # metric_names = completion_length, reward, reward_std, loss, kl, clip_ratio
+        assert abs(mets[0] - 4.0) < 1e-6 and abs(mets[1] - want_reward) < 1e-5
+        assert abs(mets[3] - want_loss) < 1e-5 * max(1.0, abs(want_loss))
+        assert ncuts >= 1, "the gradient reduction was not cut into overlapped buckets"
