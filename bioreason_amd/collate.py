@@ -48,3 +48,23 @@ def assistant_label_mask(input_ids: torch.Tensor, assistant_marker_ids: Sequence
     labels = torch.where(open_, ids, torch.full_like(ids, -100))
     labels = torch.where(ids == int(pad_token_id), torch.full_like(ids, -100), labels)      # kegg.py:321-322
     return labels.to(torch.long)
+
+
+def qwen_dna_collate_fn(examples, processor, max_length_text: int, max_length_dna: int, return_answer_in_batch: bool = False):
+    """`qwen_dna_collate_fn` of the reference (bioreason/dataset/kegg.py:223-333): chat template over each example's
+    conversation -> DLProcessor (left padding) -> labels on the assistant sections only (`assistant_label_mask`) [-> answers].
+    trl's `maybe_apply_chat_template` is restated for the one shape the reference feeds it (a {"prompt": messages} example):
+    `apply_chat_template(messages, tokenize=False)` with the processor's template."""
+    tok = processor.tokenizer
+    kw = {"chat_template": processor.chat_template} if getattr(processor, "chat_template", None) is not None else {}
+    prompts_text = [ex["prompt"] if isinstance(ex["prompt"], str) else tok.apply_chat_template(ex["prompt"], tokenize=False, **kw)
+                    for ex in examples]
+    batch = processor(text=prompts_text, batch_dna_sequences=[ex["dna_sequences"] for ex in examples], return_tensors="pt",
+                      padding=True, padding_side="left", add_special_tokens=False, max_length_text=max_length_text,
+                      max_length_dna=max_length_dna)
+    start_ids = tok.encode("<|im_start|>assistant\n", add_special_tokens=False)
+    end_ids = tok.encode("<|im_end|>", add_special_tokens=False)
+    batch["labels"] = assistant_label_mask(batch["input_ids"], start_ids, end_ids, tok.pad_token_id)
+    if return_answer_in_batch:
+        batch["answer"] = [ex["answer"].strip() for ex in examples]
+    return batch

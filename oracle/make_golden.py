@@ -126,7 +126,11 @@ def run_all(model, batch, cfg, lora: bool):
                                      pad_token_id=cfg["eos_token_id"], output_scores=True, return_dict_in_generate=True)
     assert torch.equal(full.sequences, gen)
     out["greedy_scores"] = torch.stack([s.float() for s in full.scores], dim=1).clone()
-    # GRPO: prompt + completion, log-probs of the completion, loss (grpo_trainer.py:598-640, 777-814)
+    # GRPO: prompt + completion, log-probs of the completion, loss (grpo_trainer.py:598-640, 777-814).  The completion is a
+    # FIXED seeded token matrix (with an EOS inside row 0), not the greedy decode: greedy tokens of a random-init model have
+    # probability ~1 (log-probs ~0, a degenerate comparison) and the bf16 run would follow its own, different, tokens
+    gen = completion_of(cfg)
+    out["completion"] = gen.clone()
     C = gen.shape[1]
     cmask = G.completion_mask(gen, cfg["eos_token_id"])
     pc_ids = torch.cat([b["input_ids"], gen], dim=1)
@@ -153,6 +157,33 @@ def run_all(model, batch, cfg, lora: bool):
         l0 = model.text_model.model.layers[0]
         out["grpo_grad_l0_q_A"] = l0.self_attn.q_proj.lora_A["default"].weight.grad.detach().float().clone()
         out["grpo_grad_l0_q_B"] = l0.self_attn.q_proj.lora_B["default"].weight.grad.detach().float().clone()
+    return out
+
+
+def completion_of(cfg):
+    g = torch.Generator().manual_seed(77)
+    B = cfg["batch"]["B"]
+    comp = torch.randint(8, cfg["dna_token_id"] - 4, (B, cfg["gen_tokens"]), generator=g)
+    comp[0, cfg["gen_tokens"] // 2] = cfg["eos_token_id"]          # row 0 ends half-way: masked tail
+    return comp
+
+
+def run_bf16(ref, batch, cfg, lora: bool):
+    """the reference class itself with every parameter in bf16 (weights are bf16-representable, so the round trip back to
+    fp32 is exact); the per-step score tensor is dropped (the fp32 one is the decode test's tie oracle)"""
+    def rotary_buffers():
+        return [(m, m.inv_freq) for m in ref.modules() if isinstance(getattr(m, "inv_freq", None), torch.Tensor)]
+
+    keep = [(m, b.clone()) for m, b in rotary_buffers()]      # from_pretrained(torch_dtype=bf16) leaves inv_freq in fp32:
+    ref.to(torch.bfloat16)                                    # a blanket .to() would round it (and not restore it)
+    for m, b in keep:
+        m.inv_freq = b.clone()
+    out = run_all(ref, batch, cfg, lora=lora)
+    out.pop("greedy_scores")
+    ref.to(torch.float32)
+    for m, b in keep:
+        m.inv_freq = b.clone()
+    ref.zero_grad(set_to_none=True)
     return out
 
 
@@ -193,6 +224,7 @@ def main():
             except ValueError:
                 pass
         fix["fp32"] = r0
+        fix["bf16"] = run_bf16(ref, batch, cfg, lora=False)
         # --- LoRA (PEFT formula restated; B non-zero so that it matters)
         O.apply_lora(text, r=32, alpha=64.0, dropout=0.0)
         g = torch.Generator().manual_seed(5)
@@ -209,12 +241,10 @@ def main():
         for k in r1:
             assert torch.equal(r1[k], o1[k]), f"{name}: restatement differs from the reference in {k} (LoRA)"
         fix["fp32_lora"] = r1
-        # --- the same model in bf16 (what the reference runs on a GPU: torch_dtype=bfloat16, grpo_trainer.py:221)
-        ref.to(torch.bfloat16)
-        with torch.no_grad():
-            fw = ref(**{k: v for k, v in clone_batch(batch).items()})
-        fix["bf16_lora"] = {"logits": fw.logits.float().clone(), "loss": fw.loss.float().clone()}
-        ref.to(torch.float32)
+        # --- the same model in bf16 (what the reference runs on a GPU: torch_dtype=bfloat16, grpo_trainer.py:221):
+        # EVERY quantity the parity tests compare, so each tolerance can be stated as a multiple of the reference's own
+        # bf16-vs-fp32 distance on that quantity
+        fix["bf16_lora"] = run_bf16(ref, batch, cfg, lora=True)
         path = os.path.join(ROOT, "tests", "golden", f"{name}.pt")
         if "--check-only" in sys.argv:      # tests/test_oracle.py: restatement == reference, nothing written
             print(name, "restatement equals the reference class bit for bit")

@@ -432,6 +432,116 @@ def test_sampler_greedy_and_topk(backend):
     assert pos.tolist() == [1, 2, 3, 4, 5] and a_.item() == 1 and b_.item() == 10
 
 
+def test_sampler_distribution_matches_oracle_warpers(backend):
+    """full-support check of temperature -> top-k -> top-p -> multinomial against the oracle's restatement of HF's warpers
+    (oracle.grpo_math.warp_probs, TF:generation/logits_process.py:238,473,542): support equality + a chi-square test of the
+    draw frequencies over every token of the warped distribution"""
+    from oracle.grpo_math import warp_probs
+    B, V = 4, 6000
+    g = torch.Generator().manual_seed(3)
+    logits = (torch.randn(B, V, generator=g) * 2.0)
+    logits[1] *= 0.2                                  # flat row: top-p keeps (almost) all k
+    logits[2, 123] += 6.0                             # peaked row: top-p cuts deep
+    dl = logits.to(backend)
+    out = torch.empty(B, dtype=torch.int32, device=backend)
+    step = torch.zeros(1, dtype=torch.int32, device=backend)
+    n = 4000 if backend.type == "cuda" else 24      # the emulator run checks the support; the statistics run on the GPU
+    T, k, p = 0.6, 20, 0.95
+    want = warp_probs(logits, T, k, p)                # [B, V], zeros outside the support
+    counts = torch.zeros(B, V)
+    for s_ in range(n):
+        step.fill_(s_)
+        ops.sample(dl, T, k, p, True, 99, step, None, 0, out)
+        counts[torch.arange(B), out.cpu().long()] += 1
+    for b in range(B):
+        sup = want[b] > 0
+        assert counts[b][~sup].sum() == 0, "draw outside the oracle's support"
+        e = want[b][sup] * n
+        chi2 = (((counts[b][sup] - e) ** 2) / e).sum().item()
+        dof = int(sup.sum()) - 1
+        # chi-square upper tail: mean dof, sd sqrt(2 dof); 5 sd + small-expectation slack
+        assert chi2 <= dof + 5.0 * (2.0 * max(dof, 1)) ** 0.5 + 5.0, (b, chi2, dof)
+    with pytest.raises(NotImplementedError):          # HF's top_k = 0 ("disabled") must not silently become 64
+        ops.sample(dl, T, 0, p, True, 99, step, None, 0, out)
+
+
+def test_sampler_two_eos_ids_and_forced_token(backend):
+    """a row finishes on EITHER listed EOS id (HF accepts a list; Qwen3's generation_config has two); bra_force_token raises
+    one logit at the scheduled step only"""
+    B, V = 3, 5000
+    logits = torch.zeros(B, V, device=backend)
+    logits[0, 11] = logits[1, 22] = logits[2, 33] = 9.0
+    out = torch.empty(B, dtype=torch.int32, device=backend)
+    fin = torch.zeros(B, dtype=torch.uint8, device=backend)
+    step = torch.zeros(1, dtype=torch.int32, device=backend)
+    ops.sample(logits, 1.0, 0, 1.0, False, 0, step, fin, 0, out, eos_id=11, eos_id2=22)
+    assert out.tolist() == [11, 22, 33] and fin.tolist() == [1, 1, 0]
+    at = torch.tensor([5, 0, 7], dtype=torch.int32, device=backend)
+    ops.force_token(logits, 44, step, at)             # step 0: only row 1
+    ops.sample(logits, 1.0, 0, 1.0, False, 0, step, None, 0, out)
+    assert out.tolist() == [11, 44, 33]
+
+
+def test_process_dna_embeddings_public_method(backend):
+    """DNALLMModel.process_dna_embeddings (dna_llm.py:103-179): per batch item, the first `attention_mask.sum()` projected
+    rows of each of its sequences, concatenated — against the golden fixture's oracle weights"""
+    import os as _os
+    from test_model_parity import GOLD, build, to_dev
+    from oracle import dna_llm_oracle as O
+    fix = torch.load(_os.path.join(GOLD, "tiny_a.pt"), weights_only=False)
+    m = build(fix, backend, False)
+    b = to_dev(fix["batch"], backend)
+    got = m.process_dna_embeddings(b["dna_tokenized"], b["batch_idx_map"], b["input_ids"].shape[0])
+    cfg = fix["config"]
+    dna = O.make_nt_v2(cfg["dna"], "eager")
+    dna.load_state_dict({k: v.float() for k, v in fix["state"]["dna"].items() if "inv_freq" not in k}, strict=False)
+    text = O.make_qwen3(cfg["text"], "eager")
+    ora = O.OracleDNALLM(text, dna, cfg["dna_token_id"]).eval()
+    ora.dna_projection.load_state_dict({k: v.float() for k, v in fix["state"]["proj"].items()})
+    want = ora.process_dna_embeddings(fix["batch"]["dna_tokenized"], fix["batch"]["batch_idx_map"], b["input_ids"].shape[0])
+    assert len(got) == len(want)
+    for g_, w_ in zip(got, want):
+        assert tuple(g_.shape) == tuple(w_.shape)
+        assert rel(g_, w_.detach()) < 2e-2
+
+
+@pytest.mark.gpu
+def test_gemm_glds_at_bench_shape(hip_device):
+    """the dominant kernel at the shapes the timed step launches it with: M = 8 x 2436 rows, N = 12288 (gate/up), K = 2048 with
+    the LoRA pair K2 = 64 riding in the accumulators, and the nt = 96 K-step down projection (K = 6144); vs fp32 torch"""
+    dev = hip_device
+    for (M, N, K, K2) in [(19488, 12288, 2048, 64), (19488, 2048, 6144, 64), (2180, 4096, 2048, 128)]:
+        a, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev)
+        a2, b2 = rnd(M, K2, dev=dev), rnd(N, K2, dev=dev)
+        got = ops.gemm_nt(a, b, a2=a2, b2=b2)
+        # spot-check 64 row blocks against fp32 (the full fp32 product is 0.9 GB x 3)
+        g = torch.Generator().manual_seed(M + N)
+        rows = torch.randint(0, M, (512,), generator=g).to(dev)
+        rows[:4] = torch.tensor([0, 255, 256, M - 1], device=dev)
+        ref = a[rows].float() @ b.float().T + a2[rows].float() @ b2.float().T
+        err = rel(got[rows], ref)
+        assert err < 4e-3, (M, N, K, K2, err)        # one bf16 output rounding
+
+
+@pytest.mark.gpu
+def test_lmhead_lse_at_full_vocab(hip_device):
+    """fused lm_head + log-sum-exp + target gather at V = 151936 (1187 column tiles + the ragged tail), M = 8 x 256 rows"""
+    dev = hip_device
+    M, V, K = 2048, 151936, 2048
+    h = rnd(M, K, dev=dev)
+    E = rnd(V, K, dev=dev, scale=0.05)
+    g = torch.Generator().manual_seed(1)
+    tgt = torch.randint(0, V, (M,), generator=g).to(torch.int32).to(dev)
+    tgt[:3] = torch.tensor([0, V - 1, V - 64], dtype=torch.int32, device=dev)
+    logp, lse = ops.lmhead_logprob(h, E, tgt)
+    ref_logits = h.float() @ E.float().T
+    ref_lse = torch.logsumexp(ref_logits, -1)
+    ref_lp = ref_logits.gather(1, tgt.long()[:, None]).squeeze(1) - ref_lse
+    assert (lse - ref_lse).abs().max().item() < 2e-3 * ref_lse.abs().max().item() + 1e-3
+    assert (logp - ref_lp).abs().max().item() < 3e-2
+    assert rel(logp, ref_lp) < 2e-3
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 def test_gemm_tile_variants(backend, variant):
     """every tile variant (128/256-row tiles x register prefetch depth 1/2) against the fp32 statement"""

@@ -3,10 +3,13 @@
 greedy decode, per-token log-probs and the GRPO loss.
 
 Tolerances (stated, bf16 arithmetic):  the HIP path computes in bf16 with fp32 accumulation, like the reference on
-a GPU (torch_dtype=bfloat16, grpo_trainer.py:221).  The fixtures hold the reference's fp32 run and its own bf16
-run on the same bf16-representable weights, so the test asserts
-   rel_fro(hip, ref_fp32) <= max(2e-2, 1.5 * rel_fro(ref_bf16, ref_fp32))
-i.e. the HIP path is as close to the exact answer as the reference's own bf16 execution is.
+a GPU (torch_dtype=bfloat16, grpo_trainer.py:221).  The fixtures hold the reference's fp32 run AND its own bf16 run of
+every compared quantity on the same bf16-representable weights (all four variants: tiny_a / tiny_b, LoRA on / off), so
+each assertion reads
+   rel_fro(hip, ref_fp32) <= FACTOR * rel_fro(ref_bf16, ref_fp32)          (FACTOR = 1.25, no absolute floor)
+i.e. the HIP path is as close to the exact answer as the reference's own bf16 execution is.  The kernel-source emulator
+(backend "emu") accumulates in a different order than the device and gets the looser EMU_FACTOR; kernel credit comes from
+the "hip" parametrisation.
 Greedy decode must match the reference's token ids except where the reference's own top-2 margin is below the
 bf16 noise floor (teacher-forced re-check).
 """
@@ -20,6 +23,20 @@ from bioreason_amd.dna_llm import DNALLMModel
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 BF = torch.bfloat16
+FACTOR, EMU_FACTOR = 1.25, 1.6
+
+
+def factor_for(dev):
+    return FACTOR if dev.type == "cuda" else EMU_FACTOR
+
+
+def check_rel(name, got, want_fp32, ref_bf16, factor, sel=None):
+    got, want_fp32, ref_bf16 = got.float().cpu(), want_fp32.float(), ref_bf16.float()
+    if sel is not None:
+        got, want_fp32, ref_bf16 = got[sel], want_fp32[sel], ref_bf16[sel]
+    e_hip, e_ref = rel(got, want_fp32), rel(ref_bf16, want_fp32)
+    assert e_hip <= factor * e_ref, f"{name}: rel(hip, fp32) {e_hip:.3e} > {factor} x rel(ref_bf16, fp32) {e_ref:.3e}"
+    return e_ref
 
 
 def rel(a, b):
@@ -68,24 +85,25 @@ def to_dev(batch, dev):
 def test_forward_backward(backend, name, lora):
     fix = torch.load(os.path.join(GOLD, f"{name}.pt"), weights_only=False)
     m = build(fix, backend, lora)
-    ref = fix["fp32_lora" if lora else "fp32"]
+    ref, rbf = fix["fp32_lora" if lora else "fp32"], fix["bf16_lora" if lora else "bf16"]
     b = to_dev(fix["batch"], backend)
+    f = factor_for(backend)
     m.arena.zero_grad()
     out = m(**b)
-    noise = rel(fix["bf16_lora"]["logits"], fix["fp32_lora"]["logits"]) if lora else 1e-2
-    tol = max(2e-2, 1.5 * noise)
     # positions whose query is padding are unspecified in the reference too (all keys masked): compare the rest
     keep = b["attention_mask"].bool().cpu()
-    assert rel(out.logits.float().cpu()[keep], ref["logits"][keep]) < tol
-    assert abs(out.loss.item() - ref["loss"].item()) < tol * max(1.0, abs(ref["loss"].item()))
+    noise = check_rel("logits", out.logits, ref["logits"], rbf["logits"], f, sel=keep)
+    # a scalar's own bf16 deviation can be accidentally tiny: bound the loss by the logit noise it is a mean over
+    assert abs(out.loss.item() - ref["loss"].item()) <= f * max(abs(rbf["loss"].item() - ref["loss"].item()),
+                                                                 noise * max(1.0, abs(ref["loss"].item())))
     out.loss.backward()
-    assert rel(m.dna_projection.weight.grad, ref["grad_proj_w"]) < 3 * tol
-    assert rel(m.dna_projection.bias.grad, ref["grad_proj_b"]) < 3 * tol
+    check_rel("grad_proj_w", m.dna_projection.weight.grad, ref["grad_proj_w"], rbf["grad_proj_w"], f)
+    check_rel("grad_proj_b", m.dna_projection.bias.grad, ref["grad_proj_b"], rbf["grad_proj_b"], f)
     if lora:
         l0 = m.text_model.model.layers[0]
         for nm, mod in (("q", l0.self_attn.q_proj), ("v", l0.self_attn.v_proj), ("down", l0.mlp.down_proj)):
-            assert rel(mod.lora_A["default"].weight.grad, ref[f"grad_l0_{nm}_A"]) < 3 * tol, nm
-            assert rel(mod.lora_B["default"].weight.grad, ref[f"grad_l0_{nm}_B"]) < 3 * tol, nm
+            check_rel(f"{nm}_A", mod.lora_A["default"].weight.grad, ref[f"grad_l0_{nm}_A"], rbf[f"grad_l0_{nm}_A"], f)
+            check_rel(f"{nm}_B", mod.lora_B["default"].weight.grad, ref[f"grad_l0_{nm}_B"], rbf[f"grad_l0_{nm}_B"], f)
     assert all(p.grad is None for p in m.dna_model.parameters())
 
 
@@ -133,27 +151,38 @@ def test_greedy_decode_and_logps(backend, name):
     assert n_tie <= 2
     if n_tie == 0:
         assert torch.equal(gen.cpu(), want), (gen.cpu(), want)
-    # per-token log-probs of the reference's completion under policy and reference (adapter-off) models
+    # per-token log-probs of the fixture's fixed completion (seeded tokens with an EOS inside row 0) under the policy and
+    # the reference (adapter-off) model, GRPO loss and its gradients — each against the reference's own bf16 distance
     P = b["input_ids"].shape[1]
-    comp = want.to(backend)
+    comp = ref["completion"].to(backend)
     cmask = grpo.completion_mask(comp, cfg["eos_token_id"])
     assert torch.equal(cmask.cpu().int(), ref["completion_mask"].int())
+    assert cmask.sum().item() < cmask.numel()                     # the EOS inside row 0 masks a tail
     mm = {"dna_tokenized": b["dna_tokenized"], "batch_idx_map": b["batch_idx_map"]}
     m.arena.zero_grad()
     lp = grpo.per_token_logps(m, b["input_ids"], b["attention_mask"], comp, cmask, **mm)
     with torch.no_grad(), m.text_model.disable_adapter():
         rlp = grpo.per_token_logps(m, b["input_ids"], b["attention_mask"], comp, cmask, **mm)
     w = ref["completion_mask"].bool()
-    assert (lp.detach().cpu()[w] - ref["logps"][w]).abs().max() < 0.15
-    assert (rlp.cpu()[w] - ref["ref_logps"][w]).abs().max() < 0.15
-    # GRPO loss + gradients on the reference's own log-prob inputs geometry
+    rbf = fix["bf16_lora"]
+    f = factor_for(backend)
+    check_rel("logps", lp.detach(), ref["logps"], rbf["logps"], f, sel=w)
+    check_rel("ref_logps", rlp, ref["ref_logps"], rbf["ref_logps"], f, sel=w)
+    for got, k in ((lp.detach(), "logps"), (rlp, "ref_logps")):    # max statistics are heavier-tailed than the norms: 1.5x
+        d_ref = (rbf[k][w] - ref[k][w]).abs().max().item()
+        assert (got.cpu()[w] - ref[k][w]).abs().max().item() <= 1.5 * d_ref, k
     loss, stats = grpo.grpo_loss(lp, None, rlp, ref["grpo_adv"].to(backend), cmask, 0.2, 0.2, 0.04)
-    assert abs(loss.item() - ref["grpo_loss"].item()) < 0.05 * max(1.0, abs(ref["grpo_loss"].item()))
+    d_loss = abs(rbf["grpo_loss"].item() - ref["grpo_loss"].item())
+    # (the loss is a mean of beta * KL terms: a scalar whose own bf16 deviation can be accidentally small — floor it by the
+    # reference's log-prob noise pushed through d(loss)/d(logp) <= beta * |exp(d) - 1|)
+    lp_noise = (rbf["logps"][w] - ref["logps"][w]).abs().mean().item() + (rbf["ref_logps"][w] - ref["ref_logps"][w]).abs().mean().item()
+    kl_slope = 0.04 * (ref["ref_logps"][w] - ref["logps"][w]).abs().exp().sub(1).mean().item()
+    assert abs(loss.item() - ref["grpo_loss"].item()) <= f * max(d_loss, kl_slope * lp_noise)
     loss.backward()
     l0 = m.text_model.model.layers[0]
-    assert rel(l0.self_attn.q_proj.lora_B["default"].weight.grad, ref["grpo_grad_l0_q_B"]) < 0.1
-    assert rel(l0.self_attn.q_proj.lora_A["default"].weight.grad, ref["grpo_grad_l0_q_A"]) < 0.1
-    assert rel(m.dna_projection.weight.grad, ref["grpo_grad_proj_w"]) < 0.1
+    check_rel("grpo_q_B", l0.self_attn.q_proj.lora_B["default"].weight.grad, ref["grpo_grad_l0_q_B"], rbf["grpo_grad_l0_q_B"], f)
+    check_rel("grpo_q_A", l0.self_attn.q_proj.lora_A["default"].weight.grad, ref["grpo_grad_l0_q_A"], rbf["grpo_grad_l0_q_A"], f)
+    check_rel("grpo_proj_w", m.dna_projection.weight.grad, ref["grpo_grad_proj_w"], rbf["grpo_grad_proj_w"], f)
 
 
 def test_native_decode_step_equals_python_orchestration(backend):

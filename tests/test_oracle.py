@@ -70,3 +70,35 @@ def test_restatement_equals_reference_class():
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_golden.py"), "--check-only"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_sdpa_fp32_equals_eager_fp32():
+    """tests/test_fullsize_parity.py runs the fp32 oracle with attn_implementation="sdpa" (no [H, S, S] tensors kept for the
+    backward at S = 2212): in fp32 the two HF attention paths are the same arithmetic up to summation order"""
+    import torch
+    from oracle import dna_llm_oracle as O
+    tc = dict(vocab_size=300, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+              head_dim=16, rope_theta=1e6, max_position_embeddings=256)
+    dc = dict(vocab_size=40, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, max_position_embeddings=66)
+    outs = []
+    for impl in ("eager", "sdpa"):
+        torch.manual_seed(0)
+        text, dna = O.make_qwen3(tc, impl), O.make_nt_v2(dc, impl)
+        g = torch.Generator().manual_seed(1)
+        for mdl in (text, dna):
+            for p in mdl.parameters():
+                p.data = torch.randn(p.shape, generator=g) * (0.5 / max(p.shape[-1], 1) ** 0.5) if p.dim() >= 2 else 1.0 + 0.1 * torch.randn(p.shape, generator=g)
+        text.tie_weights()
+        m = O.OracleDNALLM(text, dna, 290)
+        for p in m.dna_projection.parameters():
+            p.data = torch.randn(p.shape, generator=g) * 0.1
+        m.eval()
+        b = O.synth_batch(seed=3, B=2, n_dna_per_sample=2, Sd=10, text_len=20, vocab_text=280, vocab_dna=40, dna_token_id=290,
+                          left_pad=[2, 0], dna_pad={1: 6}, label_tail=8)
+        out = m(**b)
+        out.loss.backward()
+        outs.append((out.logits.detach(), out.loss.detach(), m.dna_projection.weight.grad.clone()))
+    keep = b["attention_mask"].bool()
+    assert (outs[0][0][keep] - outs[1][0][keep]).abs().max() < 1e-4 * outs[0][0][keep].abs().max()
+    assert abs(outs[0][1] - outs[1][1]) < 1e-5 * abs(outs[0][1])
+    assert (outs[0][2] - outs[1][2]).abs().max() < 1e-4 * outs[0][2].abs().max()
