@@ -72,6 +72,15 @@ class KernelLibrary:
             f.argtypes = [ctypes.c_void_p if k == "ptr" else _CTYPES[k] for k, _ in args]
             self._fn[name] = f
 
+    def call_rc(self, name: str, *args) -> int:
+        """like call(), but hands BRA_ERR_UNSUPPORTED (-2) back to the caller instead of raising"""
+        try:
+            return self.call(name, *args)
+        except RuntimeError as e:
+            if "status -2" in str(e):
+                return -2
+            raise
+
     def call(self, name: str, *args) -> int:
         f = self._fn[name]
         proto = self.protos[name]

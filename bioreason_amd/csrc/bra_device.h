@@ -219,6 +219,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() {}
 __device__ __forceinline__ void raw_barrier() { bra_emu::block_sync(); }
+__device__ __forceinline__ void bare_barrier() { bra_emu::block_sync(); }
+__device__ __forceinline__ void wait_lds() {}
 __device__ __forceinline__ int uniform_i(int v) { return v; }
 #else
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -231,6 +233,9 @@ __device__ __forceinline__ void raw_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 }
+// s_barrier alone (LDS reads issued before it may still be in flight: wait_lds() after it, before their first use)
+__device__ __forceinline__ void bare_barrier() { __builtin_amdgcn_s_barrier(); }
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 

@@ -32,6 +32,14 @@ struct DecGemmArgs {
     int M, N, K;
 };
 
+#ifdef BRA_EMU
+__device__ __forceinline__ void da_stamp(unsigned long long*, int) {}
+#else
+__device__ __forceinline__ void da_stamp(unsigned long long* p, int slot) {
+    if (p && lane_id() == 0) p[slot] = __builtin_amdgcn_s_memrealtime();
+}
+#endif
+
 __device__ __forceinline__ float silu_d(float x) { return x / (1.f + __expf(-x)); }
 
 // NCOL = output columns per workgroup: 16, or 8 (upper half of the MFMA tile idle) so that N = 2048 projections
@@ -191,6 +199,7 @@ struct DecAttnArgs {
     float eps, scale;
     int chunk_off, nchunk_tot;             // slot of this call's chunks inside the partial buffers (shared-prefix split)
     const int* t_ptr;                      // optional device-side cur_len (graph replay: the launch arguments stay constant)
+    unsigned long long* probe;
 };
 
 // per-head RMSNorm (optional weight) + rotate-half RoPE of the 8-dim slice this lane owns (dims 8*dl .. 8*dl+7);
@@ -223,6 +232,8 @@ template <int HD, int G>
 __device__ __forceinline__ void dec_attn_partial_body(const DecAttnArgs& a, const int c, const int hkv, const int b) {
     constexpr int CK = 64, LPK = HD / 8, KPI = 64 / LPK, NIT = CK / KPI, GRP = NIT / 2;   // 64 positions per wave
     const int lane = lane_id();
+    unsigned long long* pr = (a.probe && c == 0 && hkv == 0 && b == 0) ? a.probe + 8 : nullptr;
+    da_stamp(pr, 0);
     int cur_len = a.cur_len, nchunk = a.nchunk, nchunk_tot = a.nchunk_tot;
     if (a.t_ptr) { cur_len = a.t_ptr[0]; nchunk = (cur_len + 64) / 64; nchunk_tot = a.chunk_off + nchunk; }
     if (c >= nchunk) return;
@@ -281,6 +292,7 @@ __device__ __forceinline__ void dec_attn_partial_body(const DecAttnArgs& a, cons
         const uint8_t mraw = a.kmask ? a.kmask[(long)b * a.Smax + (okk ? key : s_end - 1)] : (uint8_t)1;
         vbits = wave_ballot(okk && (mraw != 0 || key == cur_len));
     }
+    da_stamp(pr, 1);                                   // q / k prologue done, validity bits known
     float sco[NIT][G];
     float m[G];
 #pragma unroll
@@ -311,6 +323,7 @@ __device__ __forceinline__ void dec_attn_partial_body(const DecAttnArgs& a, cons
             }
         }
     }
+    da_stamp(pr, 2);                                   // scores
     float l[G], acc[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -359,6 +372,7 @@ __device__ __forceinline__ void dec_attn_partial_body(const DecAttnArgs& a, cons
         }
         if (lane == 0) { a.part_ml[base * 2] = m[g]; a.part_ml[base * 2 + 1] = l[g]; }
     }
+    da_stamp(pr, 3);
 }
 
 template <int HD, int G>
@@ -414,7 +428,7 @@ extern "C" int bra_dec_attn_partial(const void* qkv, long ldqkv, const void* qw,
     const int G = Hq / Hkv;
     DecAttnArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, (bf16_t*)kc, (bf16_t*)vc,
                      (const uint8_t*)kmask, part_o, part_ml, B, Hq, Hkv, Smax, cur_len, (cur_len + 1 + 63) / 64, eps, scale, chunk_off,
-                     nchunk_tot > 0 ? nchunk_tot : (cur_len + 1 + 63) / 64, t_dev};
+                     nchunk_tot > 0 ? nchunk_tot : (cur_len + 1 + 63) / 64, t_dev, nullptr};
     bra_stream_t st = (bra_stream_t)stream;
     dim3 grid((a.nchunk + 3) / 4, Hkv, B);
 #define BRA_DA(HD_, G_)                                                                         \
@@ -449,13 +463,17 @@ struct DecSharedArgs {
     int R, copies, Hq, Hkv, P, nchunk_tot;
     float eps, scale;
     const int* t_ptr;                     // optional device-side completion index t: nchunk_tot = ceil(P/64) + ceil((t+1)/64)
+    unsigned long long* probe;            // diagnostics (bra_debug_set_probe): 100 MHz stamps of one prompt-part and one completion-part wave
 };
+
 
 template <int HD, int G>
 __device__ __forceinline__ void dec_attn_shared_body(const DecSharedArgs& a, const int c, const int hkv, const int r) {
     constexpr int DS = HD / 32;           // 32-deep contraction steps over the head dim
     constexpr int DB = HD / 16;           // 16-wide output blocks over the head dim
     const int lane = lane_id();
+    unsigned long long* pr = (a.probe && c == 0 && hkv == 0 && r == 0) ? a.probe : nullptr;
+    da_stamp(pr, 0);
     const int fr = lane & 15, fq = lane >> 4;
     const int s0 = c * 64;
     const int rows = a.copies * G;                         // live query rows (<= 16)
@@ -492,9 +510,11 @@ __device__ __forceinline__ void dec_attn_shared_body(const DecSharedArgs& a, con
 #pragma unroll
         for (int i = 0; i < 8; ++i) ss += qv[s][i] * qv[s][i];
     }
+    da_stamp(pr, 1);                                   // every request issued
     ss += wave_shfl_xor(ss, 16);
     ss += wave_shfl_xor(ss, 32);
     const float rstd = rsqrtf(ss / (float)HD + a.eps);
+    da_stamp(pr, 2);                                   // q arrived
     const int p = a.pos[b];
     const float* cosr = a.cosT + (long)p * (HD / 2);
     const float* sinr = a.sinT + (long)p * (HD / 2);
@@ -521,6 +541,7 @@ __device__ __forceinline__ void dec_attn_shared_body(const DecSharedArgs& a, con
         }
         qf[s] = pack8(o);
     }
+    da_stamp(pr, 3);                                   // q normalised + rotated (pos -> cos / sin round trips)
     // ---- validity of the 64 prompt positions of this chunk
     uint64_t vbits;
     {
@@ -548,14 +569,15 @@ __device__ __forceinline__ void dec_attn_shared_body(const DecSharedArgs& a, con
     }
     m = fmaxf(m, wave_shfl_xor(m, 16));
     m = fmaxf(m, wave_shfl_xor(m, 32));
+    da_stamp(pr, 4);                                   // scores (K arrived)
     float l = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float pr = sreg[kb][j] > 0.5f * kNegD ? exp2f(sreg[kb][j] - m) : 0.f;
-            sreg[kb][j] = pr;
-            l += pr;
+            const float pe = sreg[kb][j] > 0.5f * kNegD ? exp2f(sreg[kb][j] - m) : 0.f;
+            sreg[kb][j] = pe;
+            l += pe;
         }
     l += wave_shfl_xor(l, 16);
     l += wave_shfl_xor(l, 32);
@@ -578,6 +600,7 @@ __device__ __forceinline__ void dec_attn_shared_body(const DecSharedArgs& a, con
         if (live) *reinterpret_cast<f32x4*>(a.part_o + base * HD + db * 16 + 4 * fq) = acc;   // d = 16 db + 4 fq + j
     }
     if (live && fq == 0) { a.part_ml[base * 2] = m; a.part_ml[base * 2 + 1] = l; }
+    da_stamp(pr, 5);                                   // partials issued (V^T arrived)
 }
 
 template <int HD, int G>
@@ -614,7 +637,7 @@ extern "C" int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, 
     if (vt_sd < ((P + 63) / 64) * 64 || vt_sd % 4 || kp_ss % 8) return BRA_ERR_ARG;
     DecSharedArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, cosT, sinT, pos, (const bf16_t*)kp, kp_sr, kp_sh, kp_ss,
                        (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask, part_o, part_ml, R, copies, Hq, Hkv, P,
-                       nchunk_tot, eps, scale, t_dev};
+                       nchunk_tot, eps, scale, t_dev, nullptr};
     bra_stream_t st = (bra_stream_t)stream;
     dim3 grid((P + 63) / 64, Hkv, R);
 #define BRA_DS(HD_, G_)                                                                         \
@@ -626,6 +649,9 @@ extern "C" int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, 
 #undef BRA_DS
     return BRA_ERR_UNSUPPORTED;
 }
+
+static unsigned long long* g_debug_probe = nullptr;
+extern "C" int bra_debug_set_probe(void* p) { g_debug_probe = (unsigned long long*)p; return 0; }
 
 extern "C" int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT,
                                  const float* sinT, const int* pos, const void* kp, long kp_sr, long kp_sh, long kp_ss,
@@ -640,9 +666,9 @@ extern "C" int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, co
     const int npc = (P + 63) / 64, ncc = (t + 64) / 64, ntot = npc + ncc;
     DecSharedArgs s = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, cosT, sinT, pos, (const bf16_t*)kp, kp_sr, kp_sh, kp_ss,
                        (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask, part_o, part_ml, R, copies, Hq, Hkv, P,
-                       ntot, eps, scale, t_dev};
+                       ntot, eps, scale, t_dev, g_debug_probe};
     DecAttnArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, (bf16_t*)kc,
-                     (bf16_t*)vc, nullptr, part_o, part_ml, B, Hq, Hkv, C, t, ncc, eps, scale, npc, ntot, t_dev};
+                     (bf16_t*)vc, nullptr, part_o, part_ml, B, Hq, Hkv, C, t, ncc, eps, scale, npc, ntot, t_dev, g_debug_probe};
     bra_stream_t st = (bra_stream_t)stream;
     const dim3 grid(npc * Hkv * R + ncc * Hkv * B);
 #define BRA_DB(HD_, G_)                                                                         \

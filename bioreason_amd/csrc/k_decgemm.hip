@@ -27,7 +27,19 @@ struct DecGemm2Args {
     void* out; long ldo;                // bf16 [M, N] | bf16 [M, N/2] (ACT) | f32 [M, N]
     float* ss_out; int nss_out;         // partial sums of squares of the bf16 outputs, [8][nss_out], column = workgroup
     int M, N, K;
+    int packed;                         // W is in fragment order (bra_dec_pack_weights): [tile][k-step][lane][8]
+    unsigned long long* probe;          // optional timing probe (tools/dec_overhead_probe.py): 8 stamps per probed workgroup
 };
+
+// 100 MHz wall clock (s_memrealtime); the probe is compiled in but costs one uniform branch per stamp when unused
+#ifdef BRA_EMU
+__device__ __forceinline__ void dg2_stamp(const DecGemm2Args&, int) {}
+#else
+__device__ __forceinline__ void dg2_stamp(const DecGemm2Args& g, int slot) {
+    if (g.probe && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+        g.probe[(blockIdx.x == 0 ? 0 : 8) + slot] = __builtin_amdgcn_s_memrealtime();
+}
+#endif
 
 __device__ __forceinline__ float silu_g(float x) { return x / (1.f + __expf(-x)); }
 
@@ -103,6 +115,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
     constexpr int NCOL = MODE ? 8 : 16;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
+    dg2_stamp(g, 0);
     const int nsteps = g.K / KS;
     const int ntiles = (g.N + NCOL - 1) / NCOL;
     const int lrow = MODE ? (fr & 7) : fr;                            // A row = weight row, B row = batch row
@@ -123,9 +136,14 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
 
     // NORM: lane l folds partials [per * (l & 7), per * (l & 7) + per) of row l >> 3 (per <= 32, fixed order =>
     // run-to-run identical); requested first, they are the smallest and the first thing the MFMAs need
+    // NORM == 2 ("folded"): the RMSNorm weight is already multiplied into the (packed) weights and the row factor rstd is
+    // applied to the K-reduced products in the epilogue — y = rstd * (x (W . nw)^T) — so no wave loads norm weights or
+    // statistics up front (the per-CU load path, 64 B/clk, is what bounds these kernels: the activation-side loads of
+    // NORM == 1 are 3x the weight bytes); wave 0 alone folds the statistics, behind its weight requests, into LDS.
     const int per = NORM ? g.nss_in >> 3 : 0;
     f32x4 pv[8];
-    if (NORM) {
+    __shared__ float rs_lds[8];
+    if (NORM == 1) {
         const float* pp = g.ss_in + (long)(lane >> 3) * g.nss_in + (lane & 7) * per;
 #pragma unroll
         for (int i = 0; i < 8; ++i) pv[i] = *reinterpret_cast<const f32x4*>(pp + (4 * i < per ? 4 * i : 0));
@@ -135,8 +153,9 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
     if (rounds == 1) {
         int st[NL];
 #pragma unroll
-        for (int u = 0; u < NL; ++u)      // MODE 0: a wave takes both 64-byte halves of a 128-byte line back to back
-            st[u] = MODE ? wave + NW * u : 2 * (wave + NW * (u >> 1)) + (u & 1);
+        for (int u = 0; u < NL; ++u)      // MODE 0: a wave takes both 64-byte halves of a 128-byte line back to back;
+            st[u] = g.packed ? wave * NL + u      // packed weights: NL consecutive KiB blocks per wave and tile
+                             : (MODE ? wave + NW * u : 2 * (wave + NW * (u >> 1)) + (u & 1));
         long so[NL];
 #pragma unroll
         for (int u = 0; u < NL; ++u) so[u] = (long)(st[u] < nsteps ? st[u] : nsteps - 1) * KS;
@@ -145,14 +164,37 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
         u32x4 w0[NL], w1[NL], x[NL], nv[NL];
 #pragma unroll
         for (int u = 0; u < NL; ++u) x[u] = ld16(xp + so[u]);
-        if (NORM) {
+        if (NORM == 1) {
 #pragma unroll
             for (int u = 0; u < NL; ++u) nv[u] = ld16(g.nw + koff + so[u]);
         }
+        // packed: lane l's 16 bytes of (tile, step) sit at ((tile * nsteps + step) * 64 + l) * 8 — one contiguous KiB per
+        // wave-instruction (full 128-byte lines) instead of 16 row segments of 64 bytes
+        long wo[NL];
 #pragma unroll
-        for (int u = 0; u < NL; ++u) w0[u] = ld16_nt(wp + so[u]);
+        for (int u = 0; u < NL; ++u) wo[u] = g.packed ? (long)(st[u] < nsteps ? st[u] : nsteps - 1) * 512 : so[u];
+        auto tile_base = [&](int t) -> const bf16_t* {
+            if (g.packed) return g.W + (long)t * nsteps * 512 + lane * 8;
+            int rnn = t * NCOL + lrow; rnn = rnn < g.N ? rnn : g.N - 1;
+            return g.W + (long)rnn * g.ldw + koff;
+        };
+        wp = tile_base(tile);
+#pragma unroll
+        for (int u = 0; u < NL; ++u) w0[u] = ld16_nt(wp + wo[u]);
         sched_fence();                    // every request above is in flight before the first dependent instruction
-        if (NORM) {
+        dg2_stamp(g, 1);
+        if (NORM == 2 && wave == 0) {
+            const float* pp = g.ss_in + (long)(lane >> 3) * g.nss_in + (lane & 7) * per;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(pp + (4 * i < per ? 4 * i : 0));
+                s += 4 * i < per ? (q[0] + q[1]) + (q[2] + q[3]) : 0.f;
+            }
+            s += wave_shfl_xor(s, 1); s += wave_shfl_xor(s, 2); s += wave_shfl_xor(s, 4);
+            if ((lane & 7) == 0) rs_lds[lane >> 3] = rsqrtf(s / (float)g.K + g.eps);       // visible after the tile barrier
+        }
+        if (NORM == 1) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) reg_fence(pv[i]);
             float s = 0.f;
@@ -177,10 +219,9 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
         const int G = (int)gridDim.x;
         const int nmine = (ntiles - tile + G - 1) / G;
         auto issue = [&](u32x4 (&wn)[NL], int t) {
-            int rnn = t * NCOL + lrow; rnn = rnn < g.N ? rnn : g.N - 1;
-            const bf16_t* wpn = g.W + (long)rnn * g.ldw + koff;
+            const bf16_t* wpn = tile_base(t);
 #pragma unroll
-            for (int u = 0; u < NL; ++u) wn[u] = ld16_nt(wpn + so[u]);
+            for (int u = 0; u < NL; ++u) wn[u] = ld16_nt(wpn + wo[u]);
         };
         auto compute = [&](u32x4 (&wc)[NL], int t, int it) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -189,7 +230,9 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
             float (*slab)[64][4] = red[it & 1];
 #pragma unroll
             for (int r = 0; r < 4; ++r) slab[wave][lane][r] = acc[r];
+            if (it == 0) dg2_stamp(g, 2);
             __syncthreads();
+            if (it == 0) dg2_stamp(g, 3);
             if (wave == it % NW) {
                 float v[4];
 #pragma unroll
@@ -199,8 +242,15 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
                     for (int wv = 0; wv < NW; ++wv) sum += slab[wv][lane][r];
                     v[r] = sum;
                 }
+                if (NORM == 2) {
+                    const int mrow = MODE ? (fr & 7) : fr;                   // batch row of this lane's products (both K-halves of MODE 1)
+                    const float rsf = rs_lds[mrow < g.M ? mrow : g.M - 1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= rsf;
+                }
                 dg2_epilogue<MODE, ACT, OUTF32>(g, v, t, lane, it == 0, resv);
             }
+            if (it == 0) dg2_stamp(g, 4);
         };
         int it = 0;
         for (; it + 2 < nmine; it += 2) {
@@ -231,7 +281,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
             for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; w[u] = ld16_nt(wp + (long)sc * KS); }
 #pragma unroll
             for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; x[u] = ld16(xp + (long)sc * KS); }
-            if (NORM) {
+            if (NORM == 1) {
 #pragma unroll
                 for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; nv[u] = ld16(g.nw + koff + (long)sc * KS); }
                 if (it == 0 && rd == 0) {
@@ -288,6 +338,32 @@ __global__ __launch_bounds__(256) void row_sumsq_kernel(const bf16_t* x, long ld
     for (int j = tid; j < nss; j += 256) ss[(long)r * nss + j] = j == 0 ? (part[0] + part[1]) + (part[2] + part[3]) : 0.f;
 }
 
+// W [N, K] row-major -> fragment order of dec_gemm2_kernel<MODE>: chunk ((tile * nsteps + step) * 64 + lane) holds the 8
+// elements lane (fr, fq) feeds to the MFMA of (tile, step).  One thread per 16-byte chunk, coalesced on the write side.
+template <int MODE>
+__global__ __launch_bounds__(256) void dec_pack_kernel(const bf16_t* W, long ldw, int N, int K, const bf16_t* nw, bf16_t* out) {
+    constexpr int KS = MODE ? 64 : 32, NCOL = MODE ? 8 : 16;
+    const int nsteps = K / KS;
+    const long nchunk = (long)(N / NCOL) * nsteps * 64;
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunk) return;
+    const int lane = (int)(c & 63);
+    const long ts = c >> 6;
+    const int step = (int)(ts % nsteps), tile = (int)(ts / nsteps);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int row = tile * NCOL + (MODE ? (fr & 7) : fr);
+    const int col = step * KS + (MODE ? ((fr >> 3) * 32 + fq * 8) : fq * 8);
+    u32x4 v = ld16(W + (long)row * ldw + col);
+    if (nw) {                                 // fold the RMSNorm weight of the projection's input: W[n, k] * nw[k], one rounding
+        float f[8], s[8];
+        unpack8(v, f); unpack8(ld16(nw + col), s);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] *= s[i];
+        v = pack8(f);
+    }
+    st16(out + c * 8, v);
+}
+
 template <int MODE, int NORM, int ACT, int OUTF32>
 static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     constexpr int KS = MODE ? 64 : 32;
@@ -295,6 +371,7 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     const int nw = nsteps >= 64 ? 8 : 4;
     const int spw = (nsteps + nw - 1) / nw;
     const int nl = (spw >= 12 && spw % 12 == 0) ? 12 : (spw > 4 ? 8 : 4);
+    if (NORM == 2 && (nsteps + nw * nl - 1) / (nw * nl) != 1) return BRA_ERR_UNSUPPORTED;     // folded norm: single-round path only
     const int ntiles = MODE ? g.N / 8 : (g.N + 15) / 16;
     const int gmax = nw == 8 ? 256 : 512;           // one workgroup of 8 waves (two of 4) per CU, looping over the tiles
     const dim3 grid(ntiles < gmax ? ntiles : gmax);
@@ -309,9 +386,20 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
 
 using namespace bra;
 
+extern "C" int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
+                                   const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
+                                   int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* probe, void* stream);
+
 extern "C" int bra_dec_gemm2(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
                              const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
                              int nss_out, int M, int N, int K, int act, int out_f32, void* stream) {
+    return bra_dec_gemm2_probe(x, ldx, ss_in, nss_in, norm_w, eps, W, ldw, res, ldres, out, ldo, ss_out, nss_out, M, N, K, act, out_f32,
+                               0, nullptr, stream);
+}
+
+extern "C" int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
+                                   const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
+                                   int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* probe, void* stream) {
     if (M <= 0 || M > 8 || N <= 0 || K <= 0 || K % 32 || ldx % 8 || ldw % 8 || !x || !W || !out) return BRA_ERR_ARG;
     if (act && (N % 16 || out_f32 || res || ss_out)) return BRA_ERR_ARG;
     if (out_f32 && (res || ss_out)) return BRA_ERR_ARG;
@@ -320,8 +408,15 @@ extern "C" int bra_dec_gemm2(const void* x, long ldx, const float* ss_in, int ns
     const bool diag = !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256;
     if (ss_out && nss_out < (diag ? N / 8 : (N + 15) / 16)) return BRA_ERR_ARG;
     DecGemm2Args g = {(const bf16_t*)x, ldx, ss_in, nss_in, (const bf16_t*)norm_w, eps, (const bf16_t*)W, ldw,
-                      (const bf16_t*)res, ldres, out, ldo, ss_out, nss_out, M, N, K};
+                      (const bf16_t*)res, ldres, out, ldo, ss_out, nss_out, M, N, K, packed, (unsigned long long*)probe};
+    if (packed && (N % (diag ? 8 : 16) || K % (diag ? 64 : 32))) return BRA_ERR_ARG;
     bra_stream_t st = (bra_stream_t)stream;
+    if ((packed & 2) && !(packed & 1)) return BRA_ERR_ARG;
+    if (norm_w && (packed & 2)) {            // RMSNorm weight folded into the packed weights, rstd applied in the epilogue
+        if (act) return launch_dg2<0, 2, 1, 0>(g, st);
+        if (out_f32) return launch_dg2<0, 2, 0, 1>(g, st);
+        return diag ? launch_dg2<1, 2, 0, 0>(g, st) : launch_dg2<0, 2, 0, 0>(g, st);
+    }
     if (norm_w) {
         if (act) return launch_dg2<0, 1, 1, 0>(g, st);
         if (out_f32) return launch_dg2<0, 1, 0, 1>(g, st);
@@ -330,6 +425,18 @@ extern "C" int bra_dec_gemm2(const void* x, long ldx, const float* ss_in, int ns
     if (act) return launch_dg2<0, 0, 1, 0>(g, st);
     if (out_f32) return launch_dg2<0, 0, 0, 1>(g, st);
     return diag ? launch_dg2<1, 0, 0, 0>(g, st) : launch_dg2<0, 0, 0, 0>(g, st);
+}
+
+extern "C" int bra_dec_pack_weights(const void* W, long ldw, int N, int K, int act, int out_f32, const void* norm_w, void* out,
+                                    void* stream) {
+    if (!W || !out || N <= 0 || K <= 0 || ldw % 8) return BRA_ERR_ARG;
+    const bool diag = !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256;      // bra_dec_gemm2's rule
+    if (N % (diag ? 8 : 16) || K % (diag ? 64 : 32)) return BRA_ERR_UNSUPPORTED;
+    const long nchunk = (long)N * K / 8;
+    const dim3 grid((unsigned)((nchunk + 255) / 256));
+    if (diag) BRA_LAUNCH((dec_pack_kernel<1>), grid, dim3(256), 0, (bra_stream_t)stream, (const bf16_t*)W, ldw, N, K, (const bf16_t*)norm_w, (bf16_t*)out);
+    else BRA_LAUNCH((dec_pack_kernel<0>), grid, dim3(256), 0, (bra_stream_t)stream, (const bf16_t*)W, ldw, N, K, (const bf16_t*)norm_w, (bf16_t*)out);
+    return BRA_LAUNCH_STATUS();
 }
 
 extern "C" int bra_row_sumsq(const void* x, long ldx, int M, int K, float* ss, int nss, void* stream) {

@@ -15,6 +15,10 @@ struct Layer {
     float s_qkv, s_o, s_gu, s_d;                                       // alpha / r
     void *kc, *vc;                                                     // KV cache [B, Hkv, Smax, hd]
     const void *kp, *vtp;                                              // shared prompt K [R,Hkv,P,hd] and V^T [R,Hkv,hd,pitch]
+    int flags;                                                         // bit 0: Wqkv / Wo / Wgu / Wd are fragment-packed (bra_dec_pack_weights); bit 1: ln1 / ln2 folded
+                                                                       // into Wqkv / Wgu; bit 2 (record 0): final norm folded into head_packed
+    int pad_;
+    const void* head_packed;                                           // record 0 only: fragment-packed lm_head matrix, or null
 };
 
 }  // namespace
@@ -81,22 +85,28 @@ static int sg_begin(const StepGemms& s, const void* x) {
     return s.v2 ? bra_row_sumsq(x, s.H, s.B, s.H, s.ssx, s.nss, s.stream) : 0;
 }
 static int sg_qkv(const StepGemms& s, const Layer& l, const void* x, void* qkv) {
-    if (s.v2) return bra_dec_gemm2(x, s.H, s.ssx, s.nss, l.ln1, s.eps, l.Wqkv, s.H, nullptr, 0, qkv, s.Nqkv, nullptr, 0, s.B, s.Nqkv, s.H, 0, 0, s.stream);
+    const int pk = l.flags & 3;
+    if (s.v2) return bra_dec_gemm2_probe(x, s.H, s.ssx, s.nss, l.ln1, s.eps, l.Wqkv, s.H, nullptr, 0, qkv, s.Nqkv, nullptr, 0, s.B, s.Nqkv, s.H, 0, 0, pk, nullptr, s.stream);
+    if (pk) return BRA_ERR_UNSUPPORTED;
     return bra_dec_gemm(x, s.H, l.ln1, s.eps, l.Wqkv, s.H, nullptr, 0, qkv, s.Nqkv, s.B, s.Nqkv, s.H, 0, 0, s.stream);
 }
 // h = x + o Wo^T;  act = swiglu(rmsnorm(h) Wgu^T);  x = h + act Wd^T
 static int sg_tail(const StepGemms& s, const Layer& l, const void* o, void* x, void* h, void* act) {
     int rc;
+    const int pk = l.flags & 1;
     if (s.v2) {
-        if ((rc = bra_dec_gemm2(o, s.Nq, nullptr, 0, nullptr, 0.f, l.Wo, s.Nq, x, s.H, h, s.H, s.ssh, s.nss, s.B, s.H, s.Nq, 0, 0, s.stream))) return rc;
-        if ((rc = bra_dec_gemm2(h, s.H, s.ssh, s.nss, l.ln2, s.eps, l.Wgu, s.H, nullptr, 0, act, s.F, nullptr, 0, s.B, 2 * s.F, s.H, 1, 0, s.stream))) return rc;
-        return bra_dec_gemm2(act, s.F, nullptr, 0, nullptr, 0.f, l.Wd, s.F, h, s.H, x, s.H, s.ssx, s.nss, s.B, s.H, s.F, 0, 0, s.stream);
+        if ((rc = bra_dec_gemm2_probe(o, s.Nq, nullptr, 0, nullptr, 0.f, l.Wo, s.Nq, x, s.H, h, s.H, s.ssh, s.nss, s.B, s.H, s.Nq, 0, 0, pk, nullptr, s.stream))) return rc;
+        if ((rc = bra_dec_gemm2_probe(h, s.H, s.ssh, s.nss, l.ln2, s.eps, l.Wgu, s.H, nullptr, 0, act, s.F, nullptr, 0, s.B, 2 * s.F, s.H, 1, 0, l.flags & 3, nullptr, s.stream))) return rc;
+        return bra_dec_gemm2_probe(act, s.F, nullptr, 0, nullptr, 0.f, l.Wd, s.F, h, s.H, x, s.H, s.ssx, s.nss, s.B, s.H, s.F, 0, 0, pk, nullptr, s.stream);
     }
+    if (pk) return BRA_ERR_UNSUPPORTED;
     if ((rc = bra_dec_gemm(o, s.Nq, nullptr, 0.f, l.Wo, s.Nq, x, s.H, h, s.H, s.B, s.H, s.Nq, 0, 0, s.stream))) return rc;
     if ((rc = bra_dec_gemm(h, s.H, l.ln2, s.eps, l.Wgu, s.H, nullptr, 0, act, s.F, s.B, 2 * s.F, s.H, 1, 0, s.stream))) return rc;
     return bra_dec_gemm(act, s.F, nullptr, 0.f, l.Wd, s.F, h, s.H, x, s.H, s.B, s.H, s.F, 0, 0, s.stream);
 }
-static int sg_head(const StepGemms& s, const void* x, const void* norm_w, const void* E, float* logits) {
+static int sg_head(const StepGemms& s, const void* x, const void* norm_w, const void* E, const void* Epacked, int folded, float* logits) {
+    if (s.v2 && Epacked)
+        return bra_dec_gemm2_probe(x, s.H, s.ssx, s.nss, norm_w, s.eps, Epacked, s.H, nullptr, 0, logits, s.V, nullptr, 0, s.B, s.V, s.H, 0, 1, folded ? 3 : 1, nullptr, s.stream);
     if (s.v2) return bra_dec_gemm2(x, s.H, s.ssx, s.nss, norm_w, s.eps, E, s.H, nullptr, 0, logits, s.V, nullptr, 0, s.B, s.V, s.H, 0, 1, s.stream);
     return bra_dec_gemm(x, s.H, norm_w, s.eps, E, s.H, nullptr, 0, logits, s.V, s.B, s.V, s.H, 0, 1, s.stream);
 }
@@ -128,7 +138,7 @@ extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B,
         CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, nchunk, len_dev, 0, stream));
         CK(sg_tail(sg, l, o, x, h, act));
     }
-    if (logits) CK(sg_head(sg, x, norm_w, E, logits));
+    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits));
 #undef CK
     return 0;
 }
@@ -164,7 +174,7 @@ extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R
         CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, ntot, t_dev, npc, stream));
         CK(sg_tail(sg, l, o, x, h, act));
     }
-    if (logits) CK(sg_head(sg, x, norm_w, E, logits));
+    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits));
 #undef CK
     return 0;
 }

@@ -165,6 +165,111 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
     }
 }
 
+// the same epilogues for a wave that owns MI x 4 fragments at (mw0, nw0): lane owns C[mw0 + 16 mi + fr][nw0 + 16 ni + 4 fq ..+3]
+template <int EPI, int MI>
+__device__ __forceinline__ void gemm_epilogue_w(const GemmArgs& g, f32x4 (&acc)[4][MI], int mw0, int nw0, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const float alpha = g.alpha;
+    if (EPI == EPI_LSE) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = mw0 + mi * 16 + fr;
+            const int tgt_m = (m < g.M) ? g.tgt[m] : -1;
+            float vmax = -3.0e38f;
+            float vals[16];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = nw0 + ni * 16 + fq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = round_bf(acc[ni][mi][r] * alpha);
+                    bool ok = (n + r) < g.N;
+                    vals[ni * 4 + r] = ok ? x : -3.0e38f;
+                    if (ok) vmax = fmaxf(vmax, x);
+                    if (ok && (n + r) == tgt_m) g.tgt_logit[m] = x;
+                }
+            }
+            vmax = fmaxf(vmax, wave_shfl_xor(vmax, 16));
+            vmax = fmaxf(vmax, wave_shfl_xor(vmax, 32));
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += (vals[i] > -1.0e38f) ? __expf(vals[i] - vmax) : 0.f;
+            s += wave_shfl_xor(s, 16);
+            s += wave_shfl_xor(s, 32);
+            const int chunk = nw0 >> 6;
+            if (fq == 0 && m < g.M && chunk < g.nchunk) {
+                g.part_max[(long)m * g.nchunk + chunk] = vmax;
+                g.part_sum[(long)m * g.nchunk + chunk] = s;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = mw0 + mi * 16 + fr;
+        if (m >= g.M) continue;
+        float lse_m = 0.f, coef_m = 0.f; int tgt_m = -1;
+        if (EPI == EPI_DLOGIT) { lse_m = g.lse[m]; coef_m = g.coef[m]; tgt_m = g.tgt[m]; }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = nw0 + ni * 16 + fq * 4;
+            if (n >= g.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] * alpha;
+            const bool full = (n + 3 < g.N);
+            if (EPI == EPI_BF16 || EPI == EPI_DLOGIT) {
+                if (EPI == EPI_BF16) {
+                    if (g.bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += bf2f(g.bias[n + r]);
+                    }
+                    if (g.res) {
+                        if (full && !(g.ldres & 3)) {
+                            const u32x2 rv = ld8(g.res + (long)m * g.ldres + n);
+                            v[0] = round_bf(v[0]) + bf_lo(rv.x); v[1] = round_bf(v[1]) + bf_hi(rv.x);
+                            v[2] = round_bf(v[2]) + bf_lo(rv.y); v[3] = round_bf(v[3]) + bf_hi(rv.y);
+                        } else {
+                            for (int r = 0; r < 4; ++r)
+                                if (n + r < g.N) v[r] = round_bf(v[r]) + bf2f(g.res[(long)m * g.ldres + n + r]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p = __expf(round_bf(v[r]) - lse_m);
+                        v[r] = coef_m * (((n + r) == tgt_m ? 1.f : 0.f) - p);
+                    }
+                }
+                bf16_t* cp = (bf16_t*)g.C + (long)m * g.ldc + n;
+                if (full) {
+                    u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                    st8(cp, o);
+                } else {
+                    for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = f2bf(v[r]);
+                }
+            } else if (EPI == EPI_F32) {
+                float* cp = (float*)g.C + (long)m * g.ldc + n;
+                if (g.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += bf2f(g.bias[n + r]);
+                }
+                if (full) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    if (g.accumulate) o += *reinterpret_cast<const f32x4*>(cp);
+                    *reinterpret_cast<f32x4*>(cp) = o;
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) cp[r] = g.accumulate ? cp[r] + v[r] : v[r];
+                }
+            } else {  // EPI_ATOMIC
+                float* cp = (float*)g.C + (long)m * g.ldc + n;
+                for (int r = 0; r < 4; ++r) if (n + r < g.N) atomicAdd(cp + r, v[r]);
+            }
+        }
+    }
+}
+
 // BM x 128 output tile, BM/64 x 2 waves of 64x64; PF = register prefetch depth in K-tiles (the global loads of
 // tile t+PF are in flight while tile t is multiplied; LDS stays double-buffered).
 template <int BM, int BK, int EPI, int PF>
@@ -455,6 +560,175 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------
+// 256 x 256 output tile, 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 8 x 4 fragments of v_mfma_f32_16x16x32_bf16
+// (128 accumulator registers), BK = 64.  Against the 256 x 128 kernel above: per-wave tile 128 x 64 instead of
+// 64 x 64 (24 instead of 32 fragment reads per 64 MFMAs, half the L2 -> LDS bytes per flop), and a PHASED K loop in
+// which the two wave groups of a SIMD pair (waves 0-3 / 4-7) run one barrier apart, so that one wave's 16-MFMA
+// cluster always overlaps its partner's fragment reads + LDS-DMA issue instead of both waves stalling together.
+//
+// LDS: the whole 160 KiB as a RING of ten 16 KiB half-tile slots (128 rows x 128 B each, rows XOR-swizzled on the DMA
+// source side as above).  The operand stream is, per K-tile t: B rows 0-127, B rows 128-255, A rows 0-127, A rows 128-255
+// (stream index j = 4 t + h, slot j mod 10).  Phase g = 4 t + p (p = 0..3) does
+//     fragment reads of K-tile t:  p = 0: B-sub 0 (4 reads) + A-sub 0 (8) | p = 1: B-sub 1 (4) | p = 2: A-sub 1 (8) | p = 3: none
+//     LDS-DMA issue of stream index g + 7 (2 wave-instructions per wave)
+//     s_waitcnt vmcnt(6): everything up to stream index g + 4 has landed (three half-tiles stay in flight)
+//     barrier | 16 MFMAs of quadrant (A-sub, B-sub) = (0,0) (0,1) (1,1) (1,0) | barrier
+// Hazards, by construction rather than by luck (MI355X guide: read a staged buffer one phase after the wait that retires it;
+// restage a slot >= 2 phases after its last read):  the halves of K-tile t (indices <= 4t+3) are retired by the wait of
+// phase 4t-1 and first read in phase 4t;  slot (j mod 10) is rewritten by index j+10 at phase j+3, its last reads
+// happened at phase 4t+1 (B halves) / 4t+2 (A halves), i.e. >= 2 phases earlier for every h.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 64, HALF = 128 * BK * 2, NSLOT = 10;
+    BRA_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = (int)blockIdx.x;
+    int kslice = 0;
+    if (EPI == EPI_ATOMIC) { kslice = bid / ntiles; bid -= kslice * ntiles; }
+    bid = (int)xcd_remap((unsigned)bid, (unsigned)ntiles);
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int gid = bid / per_group;
+    const int first_m = gid * GROUP;
+    const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int tile_m = first_m + (bid % per_group) % gsize;
+    const int tile_n = (bid % per_group) / gsize;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int nk1 = g.K / BK, nk2 = g.K2 / BK;
+    int kt_begin = 0, kt_end = nk1 + nk2;
+    if (EPI == EPI_ATOMIC && g.split_k > 1) {
+        int per = (kt_end + g.split_k - 1) / g.split_k;
+        kt_begin = kslice * per;
+        kt_end = kt_begin + per < kt_end ? kt_begin + per : kt_end;
+        if (kt_begin >= kt_end) return;
+    }
+    const int nt = kt_end - kt_begin;
+    const int nstream = 4 * nt;
+
+    // DMA source rows of this wave: half h, piece q (2 per half): local row 16 * wave + 8 * q + (lane >> 3)
+    const int prow = lane >> 3, lchunk = ((lane & 7) ^ (lane >> 3)) * 8;
+    int rowB[4], rowA[4];          // [half * 2 + piece], clamped (rows past M / N are computed and never stored)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int loc = (i >> 1) * 128 + wave * 16 + (i & 1) * 8 + prow;
+        int rb = n0 + loc; rowB[i] = rb < g.N ? rb : g.N - 1;
+        int ra = m0 + loc; rowA[i] = ra < g.M ? ra : g.M - 1;
+    }
+    // stream element (K-tile tt relative to kt_begin, half H) -> slot `slot`; H is a compile-time constant at every call
+    // site: phase p always issues half (p + 3) & 3, so no branch and no run-time register indexing surrounds the DMA
+    auto issue = [&](int tt, auto H, int slot) {
+        constexpr int h = decltype(H)::value;
+        if (tt >= nt) return;
+        const int kt = kt_begin + tt;
+        const bool main = kt < nk1;
+        const long kcol = (long)(main ? kt : kt - nk1) * BK + lchunk;
+        char* dst = smem + slot * HALF + wave * 2048;
+        if (h < 2) {
+            const bf16_t* Bp = (main ? g.B : g.B2) + kcol;
+            const long lb = main ? g.ldb : g.ldb2;
+            glds16(Bp + (long)rowB[h * 2] * lb, dst);
+            glds16(Bp + (long)rowB[h * 2 + 1] * lb, dst + 1024);
+        } else {
+            const bf16_t* Ap = (main ? g.A : g.A2) + kcol;
+            const long la = main ? g.lda : g.lda2;
+            glds16(Ap + (long)rowA[(h - 2) * 2] * la, dst);
+            glds16(Ap + (long)rowA[(h - 2) * 2 + 1] * la, dst + 1024);
+        }
+    };
+    auto wrap = [&](int sl) { return sl >= NSLOT ? sl - NSLOT : sl; };
+    // the wait of phase gph: stream indices <= gph + 4 have landed; issued so far = min(gph + 7, nstream - 1)
+    auto wait_phase = [&](int gph) {
+        const int fly = nstream - 5 - gph;                           // half-tiles that may stay in flight (cap 3)
+        if (fly >= 3) wait_vmcnt<6>(); else if (fly == 2) wait_vmcnt<4>(); else if (fly == 1) wait_vmcnt<2>(); else wait_vmcnt<0>();
+    };
+
+    f32x4 acc[4][8];               // acc[ni][mi]: D[n = 16 ni + 4 (lane >> 4) + r][m = 16 mi + (lane & 15)]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment byte offsets inside a half-tile slot: row = base + 16 i + fr (row & 7 = fr & 7 for every i), k-half kk
+    const int sw0 = ((fq ^ (fr & 7)) * 16), sw1 = (((4 + fq) ^ (fr & 7)) * 16);
+    const int offA = fr * 128;                                        // + (64 s + 16 i) * 128 + sw{kk}
+    const int offB = ((wc & 1) * 64 + fr) * 128;                      // + (32 s + 16 i) * 128 + sw{kk}
+    u32x4 fa[4][2], fb[2][2][2];
+    auto read_a = [&](int slotA, int s) {
+        const char* base = smem + slotA * HALF + offA + s * (64 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fa[i][0] = ld16(base + i * 2048 + sw0); fa[i][1] = ld16(base + i * 2048 + sw1); }
+    };
+    auto read_b = [&](int slotB, auto S) {
+        constexpr int s = decltype(S)::value;
+        const char* base = smem + slotB * HALF + offB + s * (32 * 128);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { fb[s][i][0] = ld16(base + i * 2048 + sw0); fb[s][i][1] = ld16(base + i * 2048 + sw1); }
+    };
+    auto mma = [&](auto SA, auto SB) {
+        constexpr int sa = decltype(SA)::value, sb = decltype(SB)::value;
+        setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int ia = 0; ia < 4; ++ia)
+                    acc[sb * 2 + ib][sa * 4 + ia] = mfma_16x16x32(fb[sb][ib][kk], fa[ia][kk], acc[sb * 2 + ib][sa * 4 + ia]);
+        setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    // prologue: stream indices 0..6 (K-tile 0 whole, K-tile 1 up to its first A half); K-tile 0 landed before phase 0
+    issue(0, I0{}, 0); issue(0, I1{}, 1); issue(0, I2{}, 2); issue(0, I3{}, 3);
+    issue(1, I0{}, 4); issue(1, I1{}, 5); issue(1, I2{}, 6);
+    wait_phase(-1);
+    bare_barrier();
+    if (wr == 1) bare_barrier();                 // the second wave group runs one barrier behind the first
+    int rbase = 0;                               // slot of (t, h = 0)
+    int gph = 0;
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+        const int sB = wrap(rbase + (wc >> 1)), sA = wrap(rbase + 2 + wr);
+        // ---- p = 0
+        read_b(sB, I0{}); sched_fence(); read_a(sA, 0);
+        issue(t + 1, I3{}, wrap(rbase + 7)); wait_phase(gph); ++gph;
+        sched_fence(); bare_barrier(); wait_lds(); sched_fence();
+        mma(I0{}, I0{});
+        sched_fence(); bare_barrier();
+        // ---- p = 1
+        read_b(sB, I1{});
+        issue(t + 2, I0{}, wrap(rbase + 8)); wait_phase(gph); ++gph;
+        sched_fence(); bare_barrier(); wait_lds(); sched_fence();
+        mma(I0{}, I1{});
+        sched_fence(); bare_barrier();
+        // ---- p = 2
+        read_a(sA, 1);
+        issue(t + 2, I1{}, wrap(rbase + 9)); wait_phase(gph); ++gph;
+        sched_fence(); bare_barrier(); wait_lds(); sched_fence();
+        mma(I1{}, I1{});
+        sched_fence(); bare_barrier();
+        // ---- p = 3
+        issue(t + 2, I2{}, rbase); wait_phase(gph); ++gph;
+        sched_fence(); bare_barrier(); sched_fence();
+        mma(I1{}, I0{});
+        sched_fence(); bare_barrier();
+        rbase = rbase + 4 >= NSLOT ? rbase + 4 - NSLOT : rbase + 4;
+    }
+    if (wr == 0) bare_barrier();                 // re-join the groups (equal barrier counts)
+
+    gemm_epilogue_w<EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane);
+}
+
+// ---------------------------------------------------------------------------
 // Skinny GEMM for decode (M <= 16 rows): y[M,N] = alpha*(x W^T + x2 W2^T) (+bias)(+res).
 // HBM-bound weight streaming: a workgroup owns 16 output columns; its 4 waves interleave over K in
 // 32-deep steps (wave w takes steps w, w+4, ...: one round of the 4 waves reads 256 contiguous bytes of
@@ -529,6 +803,7 @@ static int launch_skinny(const GemmArgs& g, int out_f32, bra_stream_t stream) {
 // tile variant: bit 0 = register prefetch depth 2, bit 1 = 256-row tiles (8 waves).  Chosen per call by
 // pick_variant(); bra_gemm_set_variant(v >= 0) pins it (tuning / A-B measurements only).
 static int g_forced_variant = -1;
+static int ring_min_fill_pct = 70;
 
 static int pick_variant(const GemmArgs& g) {
     if (g_forced_variant >= 0) return g_forced_variant;
@@ -536,6 +811,13 @@ static int pick_variant(const GemmArgs& g) {
     // large-M shape of the path (850-1130 TFLOP/s vs 640-870 for the register-staged 128x128 kernel); it needs
     // K % 64 == 0 and enough 256x128 tiles to fill the chip, otherwise the 128x128 kernel keeps more CUs busy
     const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
+    if (g.K % 64 == 0 && g.K2 % 64 == 0 && g.split_k <= 1) {
+        // 256 x 256 ring kernel: the fastest inner loop, but half as many tiles — take it when its last round of tiles
+        // still fills most of the 256 CUs
+        const long t = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+        const long rounds = (t + 255) / 256;
+        if (t >= 192 && 100 * t >= ring_min_fill_pct * rounds * 256) return 6;
+    }
     if (g.K % 64 == 0 && g.K2 % 64 == 0 && tiles256 >= 128) return 5;
     return 0;
 }
@@ -557,7 +839,7 @@ static int launch_glds(const GemmArgs& g, bra_stream_t stream) {
     int grid = tiles;
     if (EPI == EPI_ATOMIC) grid = tiles * (g.split_k > 0 ? g.split_k : 1);
     const size_t smem = 3 * (size_t)(256 + 128) * 64 * 2;
-    if (pick_variant(g) == 5) {
+    if (pick_variant(g) >= 5) {
         BRA_ALLOW_SMEM((gemm_glds_kernel<EPI, 1>), smem);
         BRA_LAUNCH((gemm_glds_kernel<EPI, 1>), dim3(grid), dim3(512), smem, stream, g);
     } else {
@@ -567,8 +849,18 @@ static int launch_glds(const GemmArgs& g, bra_stream_t stream) {
     return BRA_LAUNCH_STATUS();
 }
 
+template <int EPI>
+static int launch_ring(const GemmArgs& g, bra_stream_t stream) {
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    const size_t smem = 10 * (size_t)128 * 64 * 2;                  // the whole 160 KiB: ten half-tile slots
+    BRA_ALLOW_SMEM((gemm_ring_kernel<EPI>), smem);
+    BRA_LAUNCH((gemm_ring_kernel<EPI>), dim3(tiles), dim3(512), smem, stream, g);
+    return BRA_LAUNCH_STATUS();
+}
+
 template <int BK, int EPI>
 static int launch_gemm(const GemmArgs& g, bra_stream_t stream) {
+    if (BK == 64 && EPI != EPI_ATOMIC && pick_variant(g) == 6) return launch_ring<EPI>(g, stream);
     if (BK == 64 && pick_variant(g) >= 4) return launch_glds<EPI>(g, stream);
     switch (pick_variant(g)) {
         case 1: return launch_gemm_v<128, BK, EPI, 2>(g, stream);
@@ -598,6 +890,7 @@ static int check_common(const GemmArgs& g) {
 using namespace bra;
 
 extern "C" int bra_gemm_set_variant(int v) { bra::g_forced_variant = v; return 0; }
+extern "C" int bra_gemm_set_ring_fill(int pct) { bra::ring_min_fill_pct = pct; return 0; }
 
 extern "C" int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2,
                                 const void* B2, long ldb2, int K2, void* C, long ldc, int M, int N, int K,

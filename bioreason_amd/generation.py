@@ -53,7 +53,8 @@ class _LayerDesc(ctypes.Structure):
                                                 "B_o", "A_gu", "B_gu", "A_d", "B_d")]
                 + [(n, ctypes.c_int) for n in ("r_qkv", "r_o", "r_gu", "r_d")]
                 + [(n, ctypes.c_float) for n in ("s_qkv", "s_o", "s_gu", "s_d")]
-                + [("kc", ctypes.c_void_p), ("vc", ctypes.c_void_p), ("kp", ctypes.c_void_p), ("vtp", ctypes.c_void_p)])
+                + [("kc", ctypes.c_void_p), ("vc", ctypes.c_void_p), ("kp", ctypes.c_void_p), ("vtp", ctypes.c_void_p)]
+                + [("flags", ctypes.c_int), ("pad_", ctypes.c_int), ("head_packed", ctypes.c_void_p)])
 
 
 class DecodeState:
@@ -105,7 +106,9 @@ def rollout_weights(model):
     interleaved in blocks of 8 for the SwiGLU epilogue.  Rebuilt when the adapters or base weights changed."""
     eng: QwenEngine = model.ensure_packed()
     arena = model.arena
-    key = (model._packed_sig, model._lora_enabled, None if arena is None or arena.params is None else (arena.step_count, arena.params._version))
+    pack = os.environ.get("BRA_DEC_PACK", "1") == "1"
+    fold = pack and os.environ.get("BRA_DEC_FOLD", "1") == "1"
+    key = (model._packed_sig, model._lora_enabled, pack, fold, None if arena is None or arena.params is None else (arena.step_count, arena.params._version))
     cached = getattr(eng, "_rollout", None)
     if cached is not None and cached[0] == key:
         return cached[1]
@@ -119,10 +122,32 @@ def rollout_weights(model):
             return ops.gemm_nt(G.B, G.AT, alpha=G.scaling, res=W)
         wgu = merged(L.Wgu, L.lora["gu"])
         wgu_il = wgu.view(2, F // 8, 8, wgu.shape[1]).permute(1, 0, 2, 3).reshape(2 * F, wgu.shape[1]).contiguous()
-        out.append({"Wqkv": merged(L.Wqkv, L.lora["qkv"]), "Wo": merged(L.Wo, L.lora["o"]), "Wgu": wgu_il,
-                    "Wd": merged(L.Wd, L.lora["d"])})
+        rec = {"Wqkv": merged(L.Wqkv, L.lora["qkv"]), "Wo": merged(L.Wo, L.lora["o"]), "Wgu": wgu_il,
+               "Wd": merged(L.Wd, L.lora["d"])}
+        if pack:
+            # fragment order of the M <= 8 streaming projections: contiguous KiB per wave-instruction (k_decgemm.hip)
+            # (and, `fold`, the RMSNorm weight of the projection's input multiplied in: the kernel then applies rstd to the reduced
+            # products and loads no norm weights / statistics ahead of its MFMAs)
+            nws = {"Wqkv": L.ln1 if fold else None, "Wgu": L.ln2 if fold else None, "Wo": None, "Wd": None}
+            pk = {nm: ops.dec_pack_weights(rec[nm], act=(nm == "Wgu"), norm_w=nws[nm]) for nm in ("Wqkv", "Wo", "Wgu", "Wd")}
+            if all(v is not None for v in pk.values()):
+                rec.update({nm + "_p": v for nm, v in pk.items()})
+                rec["folded"] = fold
+        out.append(rec)
     eng._rollout = (key, out)
     return out
+
+
+def packed_head(model):
+    """fragment-packed copy of the tied lm_head / embedding matrix for the decode step's logits projection (622 MB at
+    Qwen3-1.7B); the matrix is frozen under LoRA training, so the copy is rebuilt only when its storage changes"""
+    eng: QwenEngine = model.ensure_packed()
+    fold = os.environ.get("BRA_DEC_FOLD", "1") == "1"
+    key = (eng.E.data_ptr(), eng.E._version, tuple(eng.E.shape), eng.norm_w.data_ptr(), eng.norm_w._version, fold)
+    cached = getattr(eng, "_head_packed", None)
+    if cached is None or cached[0] != key:
+        eng._head_packed = (key, ops.dec_pack_weights(eng.E, out_f32=True, norm_w=eng.norm_w if fold else None), fold)
+    return eng._head_packed[1], eng._head_packed[2]
 
 
 class FusedDecodeState:
@@ -133,12 +158,19 @@ class FusedDecodeState:
         dev = eng.device
         self.eng, self.cache, self.B = eng, cache, B
         self.rw = rollout_weights(model)
+        self.ss_ws, self.nss = _norm_stat_ws(eng, eng.device)
+        use_packed = self.ss_ws is not None and B <= 8 and all("Wqkv_p" in R for R in self.rw)
         arr = (_LayerDesc * eng.L)()
         for i, (L, R) in enumerate(zip(eng.layers, self.rw)):
             d = arr[i]
             d.ln1, d.ln2, d.qn, d.kn = L.ln1.data_ptr(), L.ln2.data_ptr(), L.qn.data_ptr(), L.kn.data_ptr()
-            d.Wqkv, d.Wo, d.Wgu, d.Wd = R["Wqkv"].data_ptr(), R["Wo"].data_ptr(), R["Wgu"].data_ptr(), R["Wd"].data_ptr()
+            _set_proj(d, R, use_packed)
             d.kc, d.vc = cache.k[i].data_ptr(), cache.v[i].data_ptr()
+        if use_packed and os.environ.get("BRA_DEC_PACK_HEAD", "1") == "1":
+            self.head_p, head_folded = packed_head(model)
+            if self.head_p is not None:
+                arr[0].head_packed = self.head_p.data_ptr()
+                arr[0].flags |= 4 if head_folded else 0
         self.arr = arr
 
         def buf(n):
@@ -149,7 +181,6 @@ class FusedDecodeState:
         self.part_o = torch.empty((B, eng.Hq, nch, eng.hd), dtype=torch.float32, device=dev)
         self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
         self.cosT, self.sinT = eng.rope(cache.Smax + 1)
-        self.ss_ws, self.nss = _norm_stat_ws(eng, eng.device)
 
     def step(self, tok, pos, kmask, cur_len: int, logits: torch.Tensor, len_dev=None, embed_done: bool = False):
         """`len_dev` (device int32 [1] holding cur_len): the kernels read the length from memory and `cur_len` only
@@ -176,13 +207,20 @@ class SharedDecodeState:
         self.kc = [torch.zeros((B, eng.Hkv, C, eng.hd), dtype=BF16, device=dev) for _ in range(eng.L)]
         self.vc = [torch.zeros((B, eng.Hkv, C, eng.hd), dtype=BF16, device=dev) for _ in range(eng.L)]
         self.vt_pitch = vtp[0].shape[-1]
+        self.ss_ws, self.nss = _norm_stat_ws(eng, dev)
+        use_packed = self.ss_ws is not None and B <= 8 and all("Wqkv_p" in Rw for Rw in self.rw)
         arr = (_LayerDesc * eng.L)()
         for i, (L, Rw) in enumerate(zip(eng.layers, self.rw)):
             d = arr[i]
             d.ln1, d.ln2, d.qn, d.kn = L.ln1.data_ptr(), L.ln2.data_ptr(), L.qn.data_ptr(), L.kn.data_ptr()
-            d.Wqkv, d.Wo, d.Wgu, d.Wd = Rw["Wqkv"].data_ptr(), Rw["Wo"].data_ptr(), Rw["Wgu"].data_ptr(), Rw["Wd"].data_ptr()
+            _set_proj(d, Rw, use_packed)
             d.kc, d.vc = self.kc[i].data_ptr(), self.vc[i].data_ptr()
             d.kp, d.vtp = self.kp[i].data_ptr(), self.vtp[i].data_ptr()
+        if use_packed and os.environ.get("BRA_DEC_PACK_HEAD", "1") == "1":
+            self.head_p, head_folded = packed_head(model)
+            if self.head_p is not None:
+                arr[0].head_packed = self.head_p.data_ptr()
+                arr[0].flags |= 4 if head_folded else 0
         self.arr = arr
 
         def buf(n):
@@ -193,7 +231,6 @@ class SharedDecodeState:
         self.part_o = torch.empty((B, eng.Hq, nch, eng.hd), dtype=torch.float32, device=dev)
         self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
         self.cosT, self.sinT = eng.rope(P + C + 1)
-        self.ss_ws, self.nss = _norm_stat_ws(eng, dev)
 
     def step(self, tok, pos, pmask, t: int, logits: torch.Tensor, t_dev=None, embed_done: bool = False):
         e = self.eng
@@ -202,6 +239,14 @@ class SharedDecodeState:
                        pos, pmask, t, t_dev, int(embed_done), self.x, self.qkv, self.o, self.h, self.act, self.ss_ws, self.nss,
                        self.part_o,
                        self.part_ml, logits, current_stream(self.x))
+
+
+def _set_proj(d, R, use_packed: bool):
+    """projection weight pointers of one layer record: the fragment-packed copies when the streaming kernels can take them"""
+    sfx = "_p" if use_packed else ""
+    d.Wqkv, d.Wo, d.Wgu, d.Wd = (R["Wqkv" + sfx].data_ptr(), R["Wo" + sfx].data_ptr(), R["Wgu" + sfx].data_ptr(),
+                                  R["Wd" + sfx].data_ptr())
+    d.flags = (1 | (2 if R.get("folded") else 0)) if use_packed else 0
 
 
 def _norm_stat_ws(eng, dev):

@@ -408,17 +408,31 @@ def row_sumsq(x: torch.Tensor, nss: int = 32) -> torch.Tensor:
     return ss
 
 
-def dec_gemm2(x, W, ss_in=None, norm_w=None, eps=1e-6, res=None, act=False, out_f32=False, want_ss=False):
-    """decode-time projection (bra_dec_gemm2): y = rmsnorm(x) W^T (+res | SwiGLU | fp32); returns (y, ss_out or None)"""
+def dec_gemm2(x, W, ss_in=None, norm_w=None, eps=1e-6, res=None, act=False, out_f32=False, want_ss=False, packed=False):
+    """decode-time projection (bra_dec_gemm2): y = rmsnorm(x) W^T (+res | SwiGLU | fp32); returns (y, ss_out or None).
+    packed: W is the fragment-ordered copy made by dec_pack_weights (same logical shape); 3 = with the norm weight folded"""
     M, K = x.shape
     N = W.shape[0]
     out = torch.empty((M, N // 2 if act else N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     nss_out = (N // 8 + 32) // 32 * 32
     ss_out = torch.zeros((8, nss_out), dtype=torch.float32, device=x.device) if want_ss else None
-    get_lib().call("bra_dec_gemm2", x, _ld(x), ss_in, ss_in.shape[1] if ss_in is not None else 0, norm_w, eps, W, _ld(W),
+    get_lib().call("bra_dec_gemm2_probe", x, _ld(x), ss_in, ss_in.shape[1] if ss_in is not None else 0, norm_w, eps, W, _ld(W),
                    res, _ld(res) if res is not None else 0, out, _ld(out), ss_out, nss_out if want_ss else 0, M, N, K,
-                   int(act), int(out_f32), current_stream(x))
+                   int(act), int(out_f32), int(packed), None, current_stream(x))
     return out, ss_out
+
+
+def dec_pack_weights(W: torch.Tensor, act: bool = False, out_f32: bool = False, norm_w: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """W [N, K] -> fragment-ordered copy for bra_dec_gemm2(packed=1); None when the shape is not a multiple of the tile.
+    norm_w [K]: the input's RMSNorm weight is folded in (stream the copy with packed=3)"""
+    N, K = W.shape
+    out = torch.empty((N, K), dtype=BF16, device=W.device)
+    rc = get_lib().call_rc("bra_dec_pack_weights", W, _ld(W), N, K, int(act), int(out_f32), norm_w, out, current_stream(W))
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError(f"bra_dec_pack_weights failed with status {rc}")
+    return out
 
 
 def eos_mask(ids32: torch.Tensor, eos_id: int):

@@ -40,9 +40,13 @@ int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, const voi
                      long ldb2, int K2, void* C, long ldc, int M, int N, int K, float alpha, const void* bias,
                      const void* res, long ldres, int out_f32, int accumulate, void* stream);
 
-/* tuning knob for A/B measurements: pins the tile variant of bra_gemm_* (bit 0 = register prefetch depth 2,
- * bit 1 = 256-row tiles); v < 0 restores the built-in per-shape choice */
+/* tuning knob for A/B measurements: pins the tile variant of bra_gemm_* (0-3: register-staged 128/256-row tiles x prefetch
+ * depth, 4/5: 256 x 128 LDS-DMA kernel without / with skewed fragment reads, 6: 256 x 256 phased ring kernel); v < 0 restores
+ * the built-in per-shape choice.  Process-wide: meant for benchmarks and tests, not for concurrent callers. */
 int bra_gemm_set_variant(int v);
+/* minimum fill (percent of 256 CUs busy, averaged over the rounds of 256 x 256 tiles) at which the per-shape choice takes the
+ * ring kernel (default 70) */
+int bra_gemm_set_ring_fill(int pct);
 
 /* C[M,N] (f32, pre-zeroed or holding a running gradient) += alpha * A[M,K] B[N,K]^T with the K range cut
  * into `split_k` slices and combined by atomics: weight gradients of LoRA A/B and dna_projection, where
@@ -172,6 +176,19 @@ int bra_dec_attn_partial(const void* qkv, long ldqkv, const void* qw, const void
 int bra_dec_gemm2(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps, const void* W,
                   long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out, int nss_out, int M, int N,
                   int K, int act, int out_f32, void* stream);
+/* bra_dec_gemm2 with `packed` weights (bit 0: fragment order, bit 1: norm weight folded; bra_dec_pack_weights) and an optional timing probe: `probe` (device, 16 x 8 bytes or null) receives 100 MHz wall-clock stamps of the first
+ * and the last workgroup — kernel entry, requests issued, products ready, barrier passed, epilogue issued (diagnostics) */
+int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps, const void* W,
+                        long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out, int nss_out, int M, int N,
+                        int K, int act, int out_f32, int packed, void* probe, void* stream);
+/* W [N, K] -> the fragment order bra_dec_gemm2 streams with `packed` = 1 (same act / out_f32 flags as the projection it feeds:
+ * they select the tile mode): every wave-instruction of the weight stream then reads one contiguous KiB of full 128-byte lines
+ * instead of 16 row segments of 64 bytes.  out: N * K bf16.  BRA_ERR_UNSUPPORTED when N, K are not tile multiples.
+ * norm_w (optional, [K]): the RMSNorm weight of the projection's INPUT is multiplied in (W[n,k] * w[k], rounded once); such a
+ * copy is streamed with packed = 3: y = rstd_row * (x W'^T), the row factor applied to the reduced products — no wave loads
+ * norm weights or statistics ahead of the MFMAs (TF:qwen3:59-64 rounds the normalised activation to bf16 instead: the two
+ * differ by bf16 rounding placement only; rollout path). */
+int bra_dec_pack_weights(const void* W, long ldw, int N, int K, int act, int out_f32, const void* norm_w, void* out, void* stream);
 int bra_row_sumsq(const void* x, long ldx, int M, int K, float* ss, int nss, void* stream);
 /* `t_dev` / `len_dev` (optional device int): when given, the attention kernels read the current length from it and
  * the host-side `cur_len` / `t` only size the grids (pass the maximum); the launch arguments are then identical for
@@ -183,6 +200,10 @@ int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, const float
                         long vt_sd, const void* pmask, float* part_o, float* part_ml, int R, int copies, int Hq, int Hkv,
                         int hd, int P, int nchunk_tot, float eps, float scale, const int* t_dev, void* stream);
 /* bra_dec_attn_shared + bra_dec_attn_partial (on the completion caches kc / vc [B, Hkv, C, hd], index t) in one launch */
+/* diagnostics: 16 x 8-byte device buffer that bra_dec_attn_both stamps with the 100 MHz wall clock (one prompt-part wave:
+ * entry, requests issued, q arrived, q rotated, scores, partials issued; one completion-part wave: entry, prologue, scores,
+ * end); null switches the probe off.  Process-wide. */
+int bra_debug_set_probe(void* p);
 int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT, const float* sinT,
                       const int* pos, const void* kp, long kp_sr, long kp_sh, long kp_ss, const void* vtp, long vt_sr,
                       long vt_sh, long vt_sd, const void* pmask, void* kc, void* vc, float* part_o, float* part_ml, int R,

@@ -465,6 +465,42 @@ def test_sampler_distribution_matches_oracle_warpers(backend):
         ops.sample(dl, T, 0, p, True, 99, step, None, 0, out)
 
 
+@pytest.mark.parametrize("M,N,K,act,f32", [(8, 2048, 2048, 0, 0), (8, 4096, 2048, 0, 0), (5, 512, 256, 1, 0), (8, 4112, 128, 0, 1),
+                                            (8, 256, 384, 0, 0), (3, 64, 64, 0, 0)])
+def test_dec_gemm2_packed_weights(backend, M, N, K, act, f32):
+    """fragment-packed weight stream (bra_dec_pack_weights) == the row-major stream: same products, the K-reduction only
+    visits the k-steps in a different wave order"""
+    if backend.type == "cpu" and N * K > 600000:
+        pytest.skip("emulator: small shapes only")
+    x, W = rnd(M, K, dev=backend), rnd(N, K, dev=backend, scale=0.1)
+    nw = (1.0 + 0.1 * torch.randn(K)).to(BF).to(backend)
+    ss = ops.row_sumsq(x, 256)
+    Wp = ops.dec_pack_weights(W, act=bool(act), out_f32=bool(f32))
+    assert Wp is not None and Wp.shape == W.shape
+    # the packed copy is a permutation of the 16-byte chunks of W
+    assert torch.equal(Wp.view(-1, 8).float().sum(1).sort().values.cpu(), W.reshape(-1, 8).float().sum(1).sort().values.cpu())
+    y0, _ = ops.dec_gemm2(x, W, ss_in=ss, norm_w=nw, act=bool(act), out_f32=bool(f32))
+    y1, _ = ops.dec_gemm2(x, Wp, ss_in=ss, norm_w=nw, act=bool(act), out_f32=bool(f32), packed=True)
+    assert rel(y1, y0) < (1e-5 if f32 else 4e-3)
+    if not act and not f32:
+        r = rnd(M, N, dev=backend)
+        yr0, s0 = ops.dec_gemm2(x, W, res=r, want_ss=True)
+        yr1, s1 = ops.dec_gemm2(x, Wp, res=r, want_ss=True, packed=True)
+        assert rel(yr1, yr0) < 4e-3 and rel(s1.sum(1), s0.sum(1)) < 1e-2
+    assert ops.dec_pack_weights(rnd(40, 48, dev=backend)) is None          # not a tile multiple -> caller keeps row-major
+    # norm weight folded into the packed copy, rstd applied to the reduced products: same result up to bf16 rounding placement
+    Wf = ops.dec_pack_weights(W, act=bool(act), out_f32=bool(f32), norm_w=nw)
+    y2, _ = ops.dec_gemm2(x, Wf, ss_in=ss, norm_w=nw, act=bool(act), out_f32=bool(f32), packed=3)
+    xf = x.float()
+    xn = xf * torch.rsqrt((xf * xf).mean(-1, keepdim=True) + 1e-6) * nw.float()
+    yr = xn @ W.float().T
+    if act:
+        Fh = N // 2
+        yr = yr.view(M, Fh // 8, 2, 8)                                      # gate / up rows interleaved in blocks of 8
+        yr = (torch.nn.functional.silu(yr[:, :, 0]) * yr[:, :, 1]).reshape(M, Fh)
+    assert rel(y2, yr) < 1.5e-2 and rel(y2, y0) < 1.5e-2
+
+
 def test_sampler_two_eos_ids_and_forced_token(backend):
     """a row finishes on EITHER listed EOS id (HF accepts a list; Qwen3's generation_config has two); bra_force_token raises
     one logit at the scheduled step only"""
@@ -542,7 +578,7 @@ def test_lmhead_lse_at_full_vocab(hip_device):
     assert rel(logp, ref_lp) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 def test_gemm_tile_variants(backend, variant):
     """every tile variant (128/256-row tiles x register prefetch depth 1/2) against the fp32 statement"""
     from bioreason_amd._lib import get_lib
@@ -563,6 +599,31 @@ def test_gemm_tile_variants(backend, variant):
             logp, lse = ops.lmhead_logprob(h, e, tgt)
             lg = (h.float() @ e.float().T).to(BF).float()
             assert (lse.cpu() - torch.logsumexp(lg, -1).cpu()).abs().max() < 2e-3
+        if variant == 6:
+            # the ring kernel's own corner cases: tiles straddling M and N, a single K-tile (prologue == whole loop), K-tiles
+            # from both operand pairs, every epilogue (bf16 + bias + residual, dlogits)
+            for (M, N, K, K2) in [(600, 300, 320, 64), (257, 260, 64, 0), (256, 512, 128, 128)]:
+                a, b = rnd(M, K, dev=backend), rnd(N, K, dev=backend)
+                a2 = rnd(M, K2, dev=backend) if K2 else None
+                b2 = rnd(N, K2, dev=backend) if K2 else None
+                bias, res = rnd(N, dev=backend), rnd(M, N, dev=backend)
+                ref = a.float() @ b.float().T + (a2.float() @ b2.float().T if K2 else 0)
+                c = ops.gemm_nt(a, b, a2=a2, b2=b2, bias=bias, res=res, alpha=0.5)
+                want = ((0.5 * ref + bias.float()).to(BF).float() + res.float())
+                assert rel(c, want) < 4e-3
+            M, N, K = 300, 520, 128
+            h, e = rnd(M, K, dev=backend, scale=0.3), rnd(N, K, dev=backend, scale=0.3)
+            tgt = (torch.arange(M) * 7 % N).to(torch.int32).to(backend)
+            logp, lse = ops.lmhead_logprob(h, e, tgt)
+            lg = (h.float() @ e.float().T).to(BF).float()
+            assert (lse.cpu() - torch.logsumexp(lg, -1).cpu()).abs().max() < 2e-3
+            assert (logp.cpu() - (lg.gather(1, tgt.long()[:, None]).squeeze(1) - torch.logsumexp(lg, -1)).cpu()).abs().max() < 2e-3
+            coef = torch.randn(M).to(backend)
+            dl = ops.lmhead_dlogits(h, e, tgt, lse, coef)
+            p_ = torch.softmax(lg, -1)
+            onehot = torch.zeros(M, N, device=lg.device)
+            onehot[torch.arange(M), tgt.long().to(lg.device)] = 1
+            assert rel(dl, coef.float().to(lg.device)[:, None] * (onehot - p_)) < 1e-2
     finally:
         get_lib().call("bra_gemm_set_variant", -1)
 

@@ -18,13 +18,20 @@ if os.environ.get("GV_PREFILL") == "1":
               ("lora_A", T, 64, 2048, 0), ("lora_A_gu_bwd", T, 64, 12288, 0)]
 else:
   shapes = [("qkv", T, 4096, 2048, 128), ("o", T, 2048, 2048, 64), ("gate_up", T, 12288, 2048, 64), ("down", T, 2048, 6144, 64),
-          ("enc_qkv", 16384, 3072, 1024, 0), ("enc_ffn_dn", 16384, 1024, 4096, 0), ("lm_head", 2048, 151936, 2048, 0), ("sq8192", 8192, 8192, 8192, 0)]
+          ("d_gate_up", T, 2048, 12288, 128), ("d_down", T, 6144, 2048, 64), ("d_qkv", T, 2048, 4096, 64),
+          ("enc_qkv", 16384, 3072, 1024, 0), ("enc_ffn_dn", 16384, 1024, 4096, 0), ("lm_head", 2048, 151936, 2048, 0), ("sq8192", 8192, 8192, 8192, 0),
+          ("sft_lm_head", 17440, 151936, 2048, 0)]
 for name, M, N, K, K2 in shapes:
     a = torch.randn(M, K, device=dev).to(BF); b = torch.randn(N, K, device=dev).to(BF)
     a2 = torch.randn(M, K2, device=dev).to(BF) if K2 else None; b2 = torch.randn(N, K2, device=dev).to(BF) if K2 else None
     c = torch.empty(M, N, dtype=BF, device=dev)
     res = {}
-    for v in (0, 1, 4, 5):
+    if os.environ.get("GV_CHECK") == "1":            # variant 6 against variant 5 on the same operands (both fp32-accumulated)
+        get_lib().call("bra_gemm_set_variant", 5); c5 = ops.gemm_nt(a, b, a2=a2, b2=b2).float()
+        get_lib().call("bra_gemm_set_variant", 6); c6 = ops.gemm_nt(a, b, a2=a2, b2=b2).float()
+        print(name, "max |v6 - v5| / max|v5| =", float((c6 - c5).abs().max() / c5.abs().max()), "mismatching elements", int((c6 != c5).sum()), flush=True)
+        del c5, c6
+    for v in ((5, 6) if os.environ.get('GV_FAST') == '1' else (0, 4, 5, 6)):
         get_lib().call("bra_gemm_set_variant", v)
         ms = timeit(lambda: ops.gemm_nt(a, b, a2=a2, b2=b2, out=c))
         res[v] = round(2.0 * M * N * (K + K2) / ms / 1e9)
