@@ -577,7 +577,13 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmArgs g) {
 // restage a slot >= 2 phases after its last read):  the halves of K-tile t (indices <= 4t+3) are retired by the wait of
 // phase 4t-1 and first read in phase 4t;  slot (j mod 10) is rewritten by index j+10 at phase j+3, its last reads
 // happened at phase 4t+1 (B halves) / 4t+2 (A halves), i.e. >= 2 phases earlier for every h.
-template <int EPI>
+// PH2 = 1: TWO phases per K-tile instead of four — (B-sub 0, B-sub 1, A-sub 0 | quadrants (0,0) (0,1)) and (A-sub 1 | quadrants
+// (1,1) (1,0)) — i.e. 32-MFMA clusters (512 cycles) against 16 / 8 fragment reads + two half-tile DMA issues: the load half of
+// a phase then fits under the partner wave's MFMA half (with 16-MFMA clusters it took ~1.8x as long and the matrix pipe idled
+// 45 % of the time), and there are half as many barriers.  Stream element j = 4t + h is issued at phase floor((j - 6) / 2):
+// phase 2t issues (t+1, A halves), phase 2t+1 issues (t+2, B halves); the wait of phase g retires everything up to index
+// 2g + 5 (two half-tiles stay in flight); slot reuse distance is >= 2 phases for every half, as in the four-phase form.
+template <int EPI, int PH2 = 0>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256, BK = 64, HALF = 128 * BK * 2, NSLOT = 10;
     BRA_DYN_SMEM(smem);
@@ -687,6 +693,38 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs g) {
 
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
+    if (PH2) {
+        auto wait2 = [&](int gph) {                                       // landed: <= 2 gph + 5; issued: min(2 gph + 7, nstream - 1)
+            const int fly = nstream - 6 - 2 * gph;
+            if (fly >= 2) wait_vmcnt<4>(); else if (fly == 1) wait_vmcnt<2>(); else wait_vmcnt<0>();
+        };
+        issue(0, I0{}, 0); issue(0, I1{}, 1); issue(0, I2{}, 2); issue(0, I3{}, 3);
+        issue(1, I0{}, 4); issue(1, I1{}, 5);
+        wait2(-1);
+        bare_barrier();
+        if (wr == 1) bare_barrier();
+        int rb2 = 0, gp = 0;
+#pragma unroll 1
+        for (int t = 0; t < nt; ++t) {
+            const int sB = wrap(rb2 + (wc >> 1)), sA = wrap(rb2 + 2 + wr);
+            // ---- phase 2t
+            read_b(sB, I0{}); read_b(sB, I1{}); sched_fence(); read_a(sA, 0);
+            issue(t + 1, I2{}, wrap(rb2 + 6)); issue(t + 1, I3{}, wrap(rb2 + 7)); wait2(gp); ++gp;
+            sched_fence(); bare_barrier(); wait_lds(); sched_fence();
+            mma(I0{}, I0{}); mma(I0{}, I1{});
+            sched_fence(); bare_barrier();
+            // ---- phase 2t + 1
+            read_a(sA, 1);
+            issue(t + 2, I0{}, wrap(rb2 + 8)); issue(t + 2, I1{}, wrap(rb2 + 9)); wait2(gp); ++gp;
+            sched_fence(); bare_barrier(); wait_lds(); sched_fence();
+            mma(I1{}, I1{}); mma(I1{}, I0{});
+            sched_fence(); bare_barrier();
+            rb2 = rb2 + 4 >= NSLOT ? rb2 + 4 - NSLOT : rb2 + 4;
+        }
+        if (wr == 0) bare_barrier();
+        gemm_epilogue_w<EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane);
+        return;
+    }
     // prologue: stream indices 0..6 (K-tile 0 whole, K-tile 1 up to its first A half); K-tile 0 landed before phase 0
     issue(0, I0{}, 0); issue(0, I1{}, 1); issue(0, I2{}, 2); issue(0, I3{}, 3);
     issue(1, I0{}, 4); issue(1, I1{}, 5); issue(1, I2{}, 6);
@@ -803,20 +841,22 @@ static int launch_skinny(const GemmArgs& g, int out_f32, bra_stream_t stream) {
 // tile variant: bit 0 = register prefetch depth 2, bit 1 = 256-row tiles (8 waves).  Chosen per call by
 // pick_variant(); bra_gemm_set_variant(v >= 0) pins it (tuning / A-B measurements only).
 static int g_forced_variant = -1;
-static int ring_min_fill_pct = 70;
+static int ring_min_fill_pct = 75;
+static int ring_two_phase = 1;
 
 static int pick_variant(const GemmArgs& g) {
-    if (g_forced_variant >= 0) return g_forced_variant;
+    if (g_forced_variant >= 0) return g_forced_variant >= 6 ? 6 : g_forced_variant;
     // measured on MI355X (profiles/r1_gemm_variants.txt): the LDS-DMA kernel with skewed fragment reads wins on every
     // large-M shape of the path (850-1130 TFLOP/s vs 640-870 for the register-staged 128x128 kernel); it needs
     // K % 64 == 0 and enough 256x128 tiles to fill the chip, otherwise the 128x128 kernel keeps more CUs busy
     const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
     if (g.K % 64 == 0 && g.K2 % 64 == 0 && g.split_k <= 1) {
-        // 256 x 256 ring kernel: the fastest inner loop, but half as many tiles — take it when its last round of tiles
-        // still fills most of the 256 CUs
+        // 256 x 256 ring kernel: the fastest inner loop (measured 1.07-1.15x the 256 x 128 kernel per tile-flop,
+        // profiles/r2_gemm_variants.txt), but half as many tiles — take it when a single partial round still beats two
+        // rounds of the smaller tile (>= 140 tiles), or when its rounds fill most of the 256 CUs
         const long t = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
         const long rounds = (t + 255) / 256;
-        if (t >= 192 && 100 * t >= ring_min_fill_pct * rounds * 256) return 6;
+        if (t >= 140 && (t <= 256 || 100 * t >= ring_min_fill_pct * rounds * 256)) return 6;
     }
     if (g.K % 64 == 0 && g.K2 % 64 == 0 && tiles256 >= 128) return 5;
     return 0;
@@ -853,8 +893,13 @@ template <int EPI>
 static int launch_ring(const GemmArgs& g, bra_stream_t stream) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     const size_t smem = 10 * (size_t)128 * 64 * 2;                  // the whole 160 KiB: ten half-tile slots
-    BRA_ALLOW_SMEM((gemm_ring_kernel<EPI>), smem);
-    BRA_LAUNCH((gemm_ring_kernel<EPI>), dim3(tiles), dim3(512), smem, stream, g);
+    if (ring_two_phase) {
+        BRA_ALLOW_SMEM((gemm_ring_kernel<EPI, 1>), smem);
+        BRA_LAUNCH((gemm_ring_kernel<EPI, 1>), dim3(tiles), dim3(512), smem, stream, g);
+    } else {
+        BRA_ALLOW_SMEM((gemm_ring_kernel<EPI, 0>), smem);
+        BRA_LAUNCH((gemm_ring_kernel<EPI, 0>), dim3(tiles), dim3(512), smem, stream, g);
+    }
     return BRA_LAUNCH_STATUS();
 }
 
@@ -889,7 +934,12 @@ static int check_common(const GemmArgs& g) {
 
 using namespace bra;
 
-extern "C" int bra_gemm_set_variant(int v) { bra::g_forced_variant = v; return 0; }
+extern "C" int bra_gemm_set_variant(int v) {
+    bra::g_forced_variant = v;
+    if (v == 6) bra::ring_two_phase = 0;                 // 6 = four-phase ring, 7 = two-phase ring (A/B measurements)
+    if (v == 7 || v < 0) bra::ring_two_phase = 1;
+    return 0;
+}
 extern "C" int bra_gemm_set_ring_fill(int pct) { bra::ring_min_fill_pct = pct; return 0; }
 
 extern "C" int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2,

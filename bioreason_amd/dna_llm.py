@@ -238,13 +238,16 @@ class DNALLMModel(nn.Module):
             per[b].append(proj[s, : int(lengths[s])])
         return [torch.cat(c, dim=0) if c else torch.zeros((0, self.text_hidden_size), device=proj.device) for c in per]
 
-    def _inputs_embeds(self, input_ids, dna_tokenized, batch_idx_map, dna_alias=None):
+    def _inputs_embeds(self, input_ids, dna_tokenized, batch_idx_map, dna_alias=None, dna_enc=None):
+        """`dna_enc` (optional): the encoder output rows of exactly these sequences, computed earlier in the same training
+        step (`encode_dna`): the encoder is frozen and runs under no_grad (dna_llm.py:121), so the rollout, the reference
+        pass and the policy pass of one GRPO step see the same rows; only the trainable projection is re-applied."""
         eng = self.text_model.ensure_packed()
         B, P = input_ids.shape
         ids32 = input_ids.to(torch.int32).reshape(-1).contiguous()
         dev = ids32.device
         if dna_tokenized is not None and batch_idx_map:
-            enc = self.encode_dna(dna_tokenized, dna_alias)
+            enc = dna_enc if dna_enc is not None else self.encode_dna(dna_tokenized, dna_alias)
             proj = self.dna_projection(enc)                                        # [n*Sd, H_text], differentiable
             n, Sd = dna_tokenized["input_ids"].shape
             order = sorted(range(n), key=lambda i: batch_idx_map[i])               # stable: per-sample concat order
@@ -264,19 +267,20 @@ class DNALLMModel(nn.Module):
     # ---- the reference's two entry points ----------------------------------------------------------------------------
     def forward(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
                 dna_tokenized: Optional[Dict[str, torch.Tensor]] = None, batch_idx_map: Optional[List[int]] = None,
-                labels: Optional[torch.Tensor] = None, dna_alias: Optional[List[int]] = None, **kwargs):
+                labels: Optional[torch.Tensor] = None, dna_alias: Optional[List[int]] = None, dna_enc: Optional[torch.Tensor] = None,
+                **kwargs):
         if input_ids is None or attention_mask is None:
             raise ValueError("Either 'inputs' or 'input_ids'/'attention_mask' must be provided")
-        embeds = self._inputs_embeds(input_ids, dna_tokenized, batch_idx_map, dna_alias)
+        embeds = self._inputs_embeds(input_ids, dna_tokenized, batch_idx_map, dna_alias, dna_enc)
         return self.text_model(inputs_embeds=embeds, attention_mask=attention_mask, labels=labels, **kwargs)
 
     @torch.no_grad()
     def generate(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
                  dna_tokenized: Optional[Dict[str, torch.Tensor]] = None, batch_idx_map: Optional[List[int]] = None,
-                 dna_alias: Optional[List[int]] = None, **generation_kwargs) -> torch.Tensor:
+                 dna_alias: Optional[List[int]] = None, dna_enc: Optional[torch.Tensor] = None, **generation_kwargs) -> torch.Tensor:
         if input_ids is None or attention_mask is None:
             raise ValueError("Either 'inputs' or 'input_ids'/'attention_mask' must be provided")
-        embeds = self._inputs_embeds(input_ids, dna_tokenized, batch_idx_map, dna_alias)
+        embeds = self._inputs_embeds(input_ids, dna_tokenized, batch_idx_map, dna_alias, dna_enc)
         gc = generation_kwargs.pop("generation_config", None)
         kw = {}
         for k in ("max_new_tokens", "do_sample", "temperature", "top_k", "top_p", "eos_token_id", "pad_token_id"):

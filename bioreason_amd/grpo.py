@@ -32,7 +32,7 @@ def per_token_logps(model, prompt_ids: torch.Tensor, prompt_mask: torch.Tensor, 
     ids = torch.cat([prompt_ids, completion_ids.to(prompt_ids.dtype)], dim=1)
     mask = torch.cat([prompt_mask, completion_mask_.to(prompt_mask.dtype)], dim=1)
     embeds = model._inputs_embeds(ids, multimodal.get("dna_tokenized"), multimodal.get("batch_idx_map"),
-                                  multimodal.get("dna_alias"))
+                                  multimodal.get("dna_alias"), multimodal.get("dna_enc"))
     hid = model.text_model.hidden_states(embeds, mask)                     # [B*(P+C), H]
     S = P + C
     dev = ids.device
@@ -103,7 +103,8 @@ def per_token_logps_shared_prefix(model, prompt_ids: torch.Tensor, prompt_mask: 
     sel = torch.tensor(reps, device=dev)
     gmap = torch.tensor([where[a] for a in prompt_alias], device=dev)
     R = len(reps)
-    embeds = model._inputs_embeds(prompt_ids, multimodal.get("dna_tokenized"), multimodal.get("batch_idx_map"), multimodal.get("dna_alias"))
+    embeds = model._inputs_embeds(prompt_ids, multimodal.get("dna_tokenized"), multimodal.get("batch_idx_map"), multimodal.get("dna_alias"),
+                                  multimodal.get("dna_enc"))
     # (1) distinct prompts, K/V captured (positions = arange, as Qwen3Model.forward assigns them, TF:qwen3:391-394)
     cache_r = KVCache(eng, R, S, dev)
     meta = SeqMeta(B=R, S=P, pos=torch.arange(P, dtype=torch.int32, device=dev).repeat(R),

@@ -88,12 +88,18 @@ class GemmProfile:
         self.records = []
 
     def wants(self, M: int, N: int, K: int, K2: int) -> bool:
-        """dominant_only: exactly the launches k_gemm.hip's pick_variant() sends to gemm_glds_kernel<*, 1> (the 256x128
-        LDS-DMA tile kernel, MFMA-bound); otherwise every launch with M >= min_m (that also counts the N = 32 LoRA
-        projections, which are HBM-bound reads of the activations)"""
+        """dominant_only: exactly the launches k_gemm.hip's pick_variant() sends to the LDS-DMA MFMA kernels (gemm_ring_kernel
+        256x256 / gemm_glds_kernel 256x128, MFMA-bound); otherwise every launch with M >= min_m (that also counts the N = 32
+        LoRA projections, which are HBM-bound reads of the activations)"""
         if not self.dominant_only:
             return M >= self.min_m
-        return K % 64 == 0 and K2 % 64 == 0 and ((M + 255) // 256) * ((N + 127) // 128) >= 128
+        if K % 64 or K2 % 64:
+            return False
+        t = ((M + 255) // 256) * ((N + 255) // 256)               # k_gemm.hip pick_variant(): 256 x 256 ring kernel ...
+        rounds = (t + 255) // 256
+        if t >= 140 and (t <= 256 or 100 * t >= 75 * rounds * 256):
+            return True
+        return ((M + 255) // 256) * ((N + 127) // 128) >= 128     # ... else the 256 x 128 LDS-DMA kernel
 
     def summary(self):
         torch.cuda.synchronize()

@@ -60,6 +60,7 @@ class GRPOConfig:
     rollout_graph: Optional[bool] = None
     rollout_shared_prefix: bool = True
     grad_buckets: int = 4
+    share_dna_encoding: bool = True      # frozen-encoder rows computed once per step and shared by its three passes
 
 
 def token_stat_rewards(completion_ids: torch.Tensor, completion_mask: torch.Tensor) -> torch.Tensor:
@@ -190,6 +191,11 @@ class GRPOStepRunner(_DataParallelStep):
         m, c = self.model, self.cfg
         dev = batch["input_ids"].device
         mm = {"dna_tokenized": batch["dna_tokenized"], "batch_idx_map": batch["batch_idx_map"], "dna_alias": batch.get("dna_alias")}
+        if c.share_dna_encoding and batch["dna_tokenized"] is not None and batch["batch_idx_map"]:
+            # the frozen encoder (no_grad, dna_llm.py:121) once per distinct sequence and STEP: its rows feed the rollout, the
+            # reference pass and the policy pass alike (the reference evaluates it three times to the same values); the
+            # trainable projection on top is applied — and differentiated — in every pass
+            mm["dna_enc"] = m.encode_dna(batch["dna_tokenized"], batch.get("dna_alias"))
         prompt_ids, prompt_mask = batch["input_ids"], batch["attention_mask"]
         B = prompt_ids.shape[0]
         sched = batch.get("eos_schedule")

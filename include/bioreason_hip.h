@@ -41,11 +41,12 @@ int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, const voi
                      const void* res, long ldres, int out_f32, int accumulate, void* stream);
 
 /* tuning knob for A/B measurements: pins the tile variant of bra_gemm_* (0-3: register-staged 128/256-row tiles x prefetch
- * depth, 4/5: 256 x 128 LDS-DMA kernel without / with skewed fragment reads, 6: 256 x 256 phased ring kernel); v < 0 restores
+ * depth, 4/5: 256 x 128 LDS-DMA kernel without / with skewed fragment reads, 6 / 7: 256 x 256 ring kernel with four / two phases
+ * per K-tile); v < 0 restores
  * the built-in per-shape choice.  Process-wide: meant for benchmarks and tests, not for concurrent callers. */
 int bra_gemm_set_variant(int v);
 /* minimum fill (percent of 256 CUs busy, averaged over the rounds of 256 x 256 tiles) at which the per-shape choice takes the
- * ring kernel (default 70) */
+ * ring kernel (default 75) */
 int bra_gemm_set_ring_fill(int pct);
 
 /* C[M,N] (f32, pre-zeroed or holding a running gradient) += alpha * A[M,K] B[N,K]^T with the K range cut

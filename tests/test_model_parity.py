@@ -256,6 +256,30 @@ def test_shared_prefix_paths_equal_full_paths(backend):
     assert (full.cpu()[w] - shared.cpu()[w]).abs().max() < 0.05
 
 
+def test_shared_dna_encoding_is_exact(backend):
+    """the frozen encoder's rows computed once (`encode_dna`) and handed to forward / generate / per_token_logps give the
+    same bits as letting each call run the encoder (GRPOStepRunner shares them across the three passes of a step)"""
+    from bioreason_amd import grpo
+    fix = torch.load(os.path.join(GOLD, "tiny_a.pt"), weights_only=False)
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    labels = b.pop("labels")
+    enc = m.encode_dna(b["dna_tokenized"])
+    with torch.no_grad():
+        a0 = m(**b, labels=labels)
+        a1 = m(**b, labels=labels, dna_enc=enc)
+    assert torch.equal(a0.logits, a1.logits) and torch.equal(a0.loss, a1.loss)
+    kw = dict(max_new_tokens=5, do_sample=True, temperature=0.7, top_k=10, top_p=0.9, eos_token_id=None, seed=4)
+    assert torch.equal(m.generate(**b, **kw), m.generate(**b, dna_enc=enc, **kw))
+    comp = fix["fp32_lora"]["completion"].to(backend)
+    cm = torch.ones_like(comp, dtype=torch.int32)
+    mm = {"dna_tokenized": b["dna_tokenized"], "batch_idx_map": b["batch_idx_map"]}
+    with torch.no_grad():
+        l0 = grpo.per_token_logps(m, b["input_ids"], b["attention_mask"], comp, cm, **mm)
+        l1 = grpo.per_token_logps(m, b["input_ids"], b["attention_mask"], comp, cm, dna_enc=enc, **mm)
+    assert torch.equal(l0, l1)
+
+
 def test_shared_prefix_decode_kernel_matches_per_copy_decode(backend):
     """bra_dec_attn_shared (one MFMA pass over the prompt K / V^T for all copies of a prompt) + per-copy completion
     attention against the per-copy fused decode: same choices under teacher forcing (hd = 128, G = 2, 2 copies)."""

@@ -31,7 +31,7 @@ for name, M, N, K, K2 in shapes:
         get_lib().call("bra_gemm_set_variant", 6); c6 = ops.gemm_nt(a, b, a2=a2, b2=b2).float()
         print(name, "max |v6 - v5| / max|v5| =", float((c6 - c5).abs().max() / c5.abs().max()), "mismatching elements", int((c6 != c5).sum()), flush=True)
         del c5, c6
-    for v in ((5, 6) if os.environ.get('GV_FAST') == '1' else (0, 4, 5, 6)):
+    for v in ((5, 6, 7) if os.environ.get('GV_FAST') == '1' else (0, 4, 5, 6, 7)):
         get_lib().call("bra_gemm_set_variant", v)
         ms = timeit(lambda: ops.gemm_nt(a, b, a2=a2, b2=b2, out=c))
         res[v] = round(2.0 * M * N * (K + K2) / ms / 1e9)
