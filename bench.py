@@ -67,7 +67,7 @@ def executed_flops(world_local_prompts: int, P: int, Cn: int, mode: str):
     enc_seq = SD * L_e * (8 * d_e * d_e + 6 * d_e * f_e) + L_e * 4 * SD * SD * d_e
     R = world_local_prompts
     if mode == "sft":
-        B = R
+        B = 8 * R
         fwd = lin(B * P) + attn(P, B) + 2 * d * V * B * P
         bwd = lin(B * P) + 2.5 * attn(P, B) + 2 * 2 * d * V * B * SFT_LABEL_TAIL
         return NDNA * B * enc_seq + fwd + bwd
@@ -398,6 +398,7 @@ def main():
         }
         if args.mode == "grpo":
             line["decode_roofline"] = decode_roofline(model, runner.rollout_profile, Cn, R)
+            line["rollout_phases_ms"] = {k: round(v, 2) for k, v in runner.rollout_profile.items() if isinstance(v, float)}
             line["rollout_issue"] = {"mode": "graph" if getattr(model.text_model.engine, "_rollout_use_graph", False) else "eager",
                                      "probe_host_vs_device_ms_per_token": getattr(model.text_model.engine, "_rollout_probe_ms", None)}
             # the reference's accounting (every row re-runs its full prompt and the encoder): an upper bound on executed work
