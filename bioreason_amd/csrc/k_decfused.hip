@@ -200,6 +200,7 @@ struct DecAttnArgs {
     int chunk_off, nchunk_tot;             // slot of this call's chunks inside the partial buffers (shared-prefix split)
     const int* t_ptr;                      // optional device-side cur_len (graph replay: the launch arguments stay constant)
     unsigned long long* probe;
+    const float* rope_rows;                // optional [B, hd]: cos | sin of each sequence's CURRENT position (bra_rope_rows): no pos -> table hop
 };
 
 // per-head RMSNorm (optional weight) + rotate-half RoPE of the 8-dim slice this lane owns (dims 8*dl .. 8*dl+7);
@@ -220,17 +221,23 @@ __device__ __forceinline__ void norm_rope_slice(float (&x)[8], const bf16_t* nw,
     for (int i = 0; i < 8; ++i) x[i] = round_bf(w[i] * round_bf(x[i] * rstd));
     const int hsl = (dl & (LPK / 2 - 1)) * 8;        // index into the half-dim cos/sin row
     const bool upper = dl >= LPK / 2;
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(cosr + hsl), c1 = *reinterpret_cast<const f32x4*>(cosr + hsl + 4);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sinr + hsl), s1 = *reinterpret_cast<const f32x4*>(sinr + hsl + 4);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float other = wave_shfl_xor(x[i], LPK / 2);
-        const float c = cosr[hsl + i], s = sinr[hsl + i];
+        const float c = i < 4 ? c0[i & 3] : c1[i & 3], s = i < 4 ? s0[i & 3] : s1[i & 3];
         x[i] = round_bf(upper ? x[i] * c + other * s : x[i] * c - other * s);
     }
 }
 
-template <int HD, int G>
-__device__ __forceinline__ void dec_attn_partial_body(const DecAttnArgs& a, const int c, const int hkv, const int b) {
+// GT = q heads per kv head of the model; G = q heads THIS wave processes: GT (hsel = kv head) or 1 (hsel = q head: the VALU
+// dot products of this body are the long pole of the launch, so the both-kernel gives every q head its own wave)
+template <int HD, int GT, int G = GT>
+__device__ __forceinline__ void dec_attn_partial_body(const DecAttnArgs& a, const int c, const int hsel, const int b) {
     constexpr int CK = 64, LPK = HD / 8, KPI = 64 / LPK, NIT = CK / KPI, GRP = NIT / 2;   // 64 positions per wave
+    const int hkv = G == GT ? hsel : hsel / GT;
+    const int hq0 = G == GT ? hkv * GT : hsel;
     const int lane = lane_id();
     unsigned long long* pr = (a.probe && c == 0 && hkv == 0 && b == 0) ? a.probe + 8 : nullptr;
     da_stamp(pr, 0);
@@ -260,15 +267,15 @@ __device__ __forceinline__ void dec_attn_partial_body(const DecAttnArgs& a, cons
         vb[i] = ld16(vb_ + (long)(k1 < s_end ? k1 : s_end - 1) * HD);
     }
     const bf16_t* row = a.qkv + (long)b * a.ldqkv;
-    const int p = a.pos[b];
-    const float* cosr = a.cosT + (long)p * (HD / 2);
-    const float* sinr = a.sinT + (long)p * (HD / 2);
+    const float* cosr; const float* sinr;
+    if (a.rope_rows) { cosr = a.rope_rows + (long)b * HD; sinr = cosr + HD / 2; }
+    else { const int p = a.pos[b]; cosr = a.cosT + (long)p * (HD / 2); sinr = a.sinT + (long)p * (HD / 2); }
     // ---- queries of the G heads of this kv group
     const float sc = a.scale * kLog2eD;
     float qv[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        unpack8(ld16(row + (long)(hkv * G + g) * HD + dl * 8), qv[g]);
+        unpack8(ld16(row + (long)(hq0 + g) * HD + dl * 8), qv[g]);
         norm_rope_slice<HD>(qv[g], a.qw, cosr, sinr, dl, a.eps);
 #pragma unroll
         for (int i = 0; i < 8; ++i) qv[g][i] *= sc;
@@ -279,7 +286,7 @@ __device__ __forceinline__ void dec_attn_partial_body(const DecAttnArgs& a, cons
     norm_rope_slice<HD>(kn, a.kw, cosr, sinr, dl, a.eps);
     unpack8(ld16(row + Nq + Nkv + (long)hkv * HD + dl * 8), vn);
     const bool owns_new = cur_len >= s_begin && cur_len < s_begin + CK;
-    if (owns_new && kg == 0) {
+    if (owns_new && kg == 0 && hq0 == hkv * GT) {
         st16(kb_ + (long)cur_len * HD, pack8(kn));
         st16(vb_ + (long)cur_len * HD, pack8(vn));
     }
@@ -362,7 +369,7 @@ __device__ __forceinline__ void dec_attn_partial_body(const DecAttnArgs& a, cons
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[g][e] += wave_shfl_xor(acc[g][e], mk);
         }
-        const int hq = hkv * G + g;
+        const int hq = hq0 + g;
         const long base = ((long)b * a.Hq + hq) * nchunk_tot + a.chunk_off + c;
         if (kg == 0) {
             f32x4 lo = {acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
@@ -428,7 +435,7 @@ extern "C" int bra_dec_attn_partial(const void* qkv, long ldqkv, const void* qw,
     const int G = Hq / Hkv;
     DecAttnArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, (bf16_t*)kc, (bf16_t*)vc,
                      (const uint8_t*)kmask, part_o, part_ml, B, Hq, Hkv, Smax, cur_len, (cur_len + 1 + 63) / 64, eps, scale, chunk_off,
-                     nchunk_tot > 0 ? nchunk_tot : (cur_len + 1 + 63) / 64, t_dev, nullptr};
+                     nchunk_tot > 0 ? nchunk_tot : (cur_len + 1 + 63) / 64, t_dev, nullptr, nullptr};
     bra_stream_t st = (bra_stream_t)stream;
     dim3 grid((a.nchunk + 3) / 4, Hkv, B);
 #define BRA_DA(HD_, G_)                                                                         \
@@ -464,6 +471,7 @@ struct DecSharedArgs {
     float eps, scale;
     const int* t_ptr;                     // optional device-side completion index t: nchunk_tot = ceil(P/64) + ceil((t+1)/64)
     unsigned long long* probe;            // diagnostics (bra_debug_set_probe): 100 MHz stamps of one prompt-part and one completion-part wave
+    const float* rope_rows;               // optional [B, hd]: cos | sin of each sequence's current position
 };
 
 
@@ -515,9 +523,9 @@ __device__ __forceinline__ void dec_attn_shared_body(const DecSharedArgs& a, con
     ss += wave_shfl_xor(ss, 32);
     const float rstd = rsqrtf(ss / (float)HD + a.eps);
     da_stamp(pr, 2);                                   // q arrived
-    const int p = a.pos[b];
-    const float* cosr = a.cosT + (long)p * (HD / 2);
-    const float* sinr = a.sinT + (long)p * (HD / 2);
+    const float* cosr; const float* sinr;
+    if (a.rope_rows) { cosr = a.rope_rows + (long)b * HD; sinr = cosr + HD / 2; }
+    else { const int p = a.pos[b]; cosr = a.cosT + (long)p * (HD / 2); sinr = a.sinT + (long)p * (HD / 2); }
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
         float w[8];
@@ -532,10 +540,12 @@ __device__ __forceinline__ void dec_attn_shared_body(const DecSharedArgs& a, con
         const bool upper = s >= DS / 2;
         const int sp = s ^ (DS / 2);
         float o[8];
+        const int hbase = (s & (DS / 2 - 1)) * 32 + fq * 8;            // index into the half-dim cos / sin row
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cosr + hbase), c1 = *reinterpret_cast<const f32x4*>(cosr + hbase + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sinr + hbase), s1 = *reinterpret_cast<const f32x4*>(sinr + hbase + 4);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int hidx = (s & (DS / 2 - 1)) * 32 + fq * 8 + i;      // index into the half-dim cos / sin row
-            const float cv = cosr[hidx], sv = sinr[hidx];
+            const float cv = i < 4 ? c0[i & 3] : c1[i & 3], sv = i < 4 ? s0[i & 3] : s1[i & 3];
             const float rot = upper ? qv[s][i] * cv + qv[sp][i] * sv : qv[s][i] * cv - qv[sp][i] * sv;
             o[i] = round_bf(rot) * sc;
         }
@@ -618,8 +628,8 @@ __global__ __launch_bounds__(64) void dec_attn_both_kernel(DecSharedArgs s, DecA
     if (w < nsh) {
         dec_attn_shared_body<HD, G>(s, w % npc, (w / npc) % s.Hkv, w / (npc * s.Hkv));
     } else {
-        const int v = w - nsh;
-        dec_attn_partial_body<HD, G>(a, v % ncc, (v / ncc) % a.Hkv, v / (ncc * a.Hkv));
+        const int v = w - nsh;                 // (sequence, q head, completion chunk): one q head per wave
+        dec_attn_partial_body<HD, G, 1>(a, v % ncc, (v / ncc) % a.Hq, v / (ncc * a.Hq));
     }
 }
 
@@ -637,7 +647,7 @@ extern "C" int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, 
     if (vt_sd < ((P + 63) / 64) * 64 || vt_sd % 4 || kp_ss % 8) return BRA_ERR_ARG;
     DecSharedArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, cosT, sinT, pos, (const bf16_t*)kp, kp_sr, kp_sh, kp_ss,
                        (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask, part_o, part_ml, R, copies, Hq, Hkv, P,
-                       nchunk_tot, eps, scale, t_dev, nullptr};
+                       nchunk_tot, eps, scale, t_dev, nullptr, nullptr};
     bra_stream_t st = (bra_stream_t)stream;
     dim3 grid((P + 63) / 64, Hkv, R);
 #define BRA_DS(HD_, G_)                                                                         \
@@ -657,7 +667,7 @@ extern "C" int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, co
                                  const float* sinT, const int* pos, const void* kp, long kp_sr, long kp_sh, long kp_ss,
                                  const void* vtp, long vt_sr, long vt_sh, long vt_sd, const void* pmask, void* kc, void* vc,
                                  float* part_o, float* part_ml, int R, int copies, int Hq, int Hkv, int hd, int P, int C,
-                                 int t, float eps, float scale, const int* t_dev, void* stream) {
+                                 int t, float eps, float scale, const int* t_dev, const float* rope_rows, void* stream) {
     if (R <= 0 || copies <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || P <= 0 || t < 0 || t >= C) return BRA_ERR_ARG;
     const int G = Hq / Hkv, B = R * copies;
     if (copies * G > 16) return BRA_ERR_UNSUPPORTED;
@@ -666,11 +676,11 @@ extern "C" int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, co
     const int npc = (P + 63) / 64, ncc = (t + 64) / 64, ntot = npc + ncc;
     DecSharedArgs s = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, cosT, sinT, pos, (const bf16_t*)kp, kp_sr, kp_sh, kp_ss,
                        (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask, part_o, part_ml, R, copies, Hq, Hkv, P,
-                       ntot, eps, scale, t_dev, g_debug_probe};
+                       ntot, eps, scale, t_dev, g_debug_probe, rope_rows};
     DecAttnArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, (bf16_t*)kc,
-                     (bf16_t*)vc, nullptr, part_o, part_ml, B, Hq, Hkv, C, t, ncc, eps, scale, npc, ntot, t_dev, g_debug_probe};
+                     (bf16_t*)vc, nullptr, part_o, part_ml, B, Hq, Hkv, C, t, ncc, eps, scale, npc, ntot, t_dev, g_debug_probe, rope_rows};
     bra_stream_t st = (bra_stream_t)stream;
-    const dim3 grid(npc * Hkv * R + ncc * Hkv * B);
+    const dim3 grid(npc * Hkv * R + ncc * Hq * B);
 #define BRA_DB(HD_, G_)                                                                         \
     if (hd == HD_ && G == G_) {                                                                 \
         BRA_LAUNCH((dec_attn_both_kernel<HD_, G_>), grid, dim3(64), 0, st, s, a, npc, ncc);     \

@@ -19,6 +19,7 @@ struct Layer {
                                                                        // into Wqkv / Wgu; bit 2 (record 0): final norm folded into head_packed
     int pad_;
     const void* head_packed;                                           // record 0 only: fragment-packed lm_head matrix, or null
+    const float* rope_rows;                                            // record 0 only: [B, hd] cos | sin rows of the current positions, or null
 };
 
 }  // namespace
@@ -170,7 +171,7 @@ extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R
         CK(sg_qkv(sg, l, x, qkv));
         CK(bra_dec_attn_both(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, l.kp, (long)Hkv * P * hd, (long)P * hd, (long)hd, l.vtp,
                              (long)Hkv * hd * vt_pitch, (long)hd * vt_pitch, vt_pitch, pmask, l.kc, l.vc, part_o, part_ml, R,
-                             copies, Hq, Hkv, hd, P, C, t, eps, scale, t_dev, stream));
+                             copies, Hq, Hkv, hd, P, C, t, eps, scale, t_dev, L > 0 ? ls[0].rope_rows : nullptr, stream));
         CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, ntot, t_dev, npc, stream));
         CK(sg_tail(sg, l, o, x, h, act));
     }

@@ -246,10 +246,29 @@ __global__ __launch_bounds__(64) void force_token_kernel(float* logits, long ldl
 }
 
 // counters of the replayed token loop: pos[0 .. n) += 1 (rotary positions), a[0] += 1, b[0] += 1 (step index, cache length)
-__global__ __launch_bounds__(64) void advance_counters_kernel(int* pos, int n, int* a, int* b) {
+__global__ __launch_bounds__(64) void advance_counters_kernel(int* pos, int n, int* a, int* b, const float* cosT, const float* sinT,
+                                                              int hd, float* rows) {
     const int i = (int)threadIdx.x;
+    if (rows) {                                   // one pass: every lane reads the positions it needs before anyone bumps them
+        const int half = hd / 2;
+        for (int e = i; e < n * hd; e += 64) {
+            const int s = e / hd, d = e % hd;
+            const int p = pos[s] + 1;
+            rows[e] = d < half ? cosT[(long)p * half + d] : sinT[(long)p * half + d - half];
+        }
+        __syncthreads();
+    }
     for (int j = i; j < n; j += 64) pos[j] += 1;
     if (i == 0) { if (a) a[0] += 1; if (b) b[0] += 1; }
+}
+
+__global__ __launch_bounds__(64) void rope_rows_kernel(const float* cosT, const float* sinT, const int* pos, int n, int hd, float* rows) {
+    const int half = hd / 2;
+    for (int e = (int)threadIdx.x; e < n * hd; e += 64) {
+        const int s = e / hd, d = e % hd;
+        const int p = pos[s];
+        rows[e] = d < half ? cosT[(long)p * half + d] : sinT[(long)p * half + d - half];
+    }
 }
 
 // completion_mask[b, c] = c <= first_eos(b) ; also lengths[b] = mask.sum()
@@ -389,9 +408,18 @@ extern "C" int bra_force_token(float* logits, long ldl, int B, int V, int token,
     return BRA_LAUNCH_STATUS();
 }
 
-extern "C" int bra_advance_counters(int* pos, int n, int* a, int* b, void* stream) {
+extern "C" int bra_advance_counters(int* pos, int n, int* a, int* b, const float* cosT, const float* sinT, int hd, float* rope_rows,
+                                    void* stream) {
     if (n < 0 || (n > 0 && !pos)) return BRA_ERR_ARG;
-    BRA_LAUNCH(advance_counters_kernel, dim3(1), dim3(64), 0, stream, pos, n, a, b);
+    if (rope_rows && (!cosT || !sinT || hd <= 0 || hd % 2)) return BRA_ERR_ARG;
+    BRA_LAUNCH(advance_counters_kernel, dim3(1), dim3(64), 0, stream, pos, n, a, b, cosT, sinT, hd, rope_rows);
+    return BRA_LAUNCH_STATUS();
+}
+
+extern "C" int bra_rope_rows(const float* cosT, const float* sinT, const int* pos, int n, int hd, float* rope_rows, void* stream) {
+    if (n <= 0) return 0;
+    if (!cosT || !sinT || !pos || !rope_rows || hd <= 0 || hd % 2) return BRA_ERR_ARG;
+    BRA_LAUNCH(rope_rows_kernel, dim3(1), dim3(64), 0, stream, cosT, sinT, pos, n, hd, rope_rows);
     return BRA_LAUNCH_STATUS();
 }
 

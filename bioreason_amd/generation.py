@@ -54,7 +54,7 @@ class _LayerDesc(ctypes.Structure):
                 + [(n, ctypes.c_int) for n in ("r_qkv", "r_o", "r_gu", "r_d")]
                 + [(n, ctypes.c_float) for n in ("s_qkv", "s_o", "s_gu", "s_d")]
                 + [("kc", ctypes.c_void_p), ("vc", ctypes.c_void_p), ("kp", ctypes.c_void_p), ("vtp", ctypes.c_void_p)]
-                + [("flags", ctypes.c_int), ("pad_", ctypes.c_int), ("head_packed", ctypes.c_void_p)])
+                + [("flags", ctypes.c_int), ("pad_", ctypes.c_int), ("head_packed", ctypes.c_void_p), ("rope_rows", ctypes.c_void_p)])
 
 
 class DecodeState:
@@ -221,6 +221,10 @@ class SharedDecodeState:
             if self.head_p is not None:
                 arr[0].head_packed = self.head_p.data_ptr()
                 arr[0].flags |= 4 if head_folded else 0
+        # (cos | sin) rows of every sequence's current position, refreshed once per token by bra_advance_counters
+        self.rope_rows = torch.zeros((B, eng.hd), dtype=torch.float32, device=dev) if os.environ.get("BRA_DEC_ROPE_ROWS", "1") == "1" else None
+        if self.rope_rows is not None:
+            arr[0].rope_rows = self.rope_rows.data_ptr()
         self.arr = arr
 
         def buf(n):
@@ -415,8 +419,12 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             shared.step(cur, next_pos, pmask, t_grid, logits, t_dev=step_t, embed_done=fuse_embed)
         else:
             state.step(cur, next_pos, kmask, P + t_grid, logits, len_dev=len_t, embed_done=fuse_embed)
-        ops.advance_counters(next_pos, step_t, len_t)
+        ops.advance_counters(next_pos, step_t, len_t, rope=rope_args)
 
+    rope_args = None
+    if shared is not None and getattr(shared, "rope_rows", None) is not None:
+        rope_args = (shared.cosT, shared.sinT, eng.hd, shared.rope_rows)
+        ops.rope_rows(shared.cosT, shared.sinT, next_pos, eng.hd, shared.rope_rows)
     _tick("decode_setup")
     last = max_new_tokens - 1                 # index of the final draw (no decode step follows it)
     t = 0

@@ -403,8 +403,14 @@ def force_token(logits: torch.Tensor, token: int, step_t: torch.Tensor, at: torc
     get_lib().call("bra_force_token", logits, _ld(logits), B, V, int(token), step_t, at, current_stream(logits))
 
 
-def advance_counters(pos: torch.Tensor, a: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None):
-    get_lib().call("bra_advance_counters", pos, pos.numel(), a, b, current_stream(pos))
+def advance_counters(pos: torch.Tensor, a: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None, rope=None):
+    """rope = (cosT, sinT, hd, rows [n, hd] fp32): also refresh the (cos | sin) rows of the advanced positions"""
+    cosT, sinT, hd, rows = rope if rope is not None else (None, None, 0, None)
+    get_lib().call("bra_advance_counters", pos, pos.numel(), a, b, cosT, sinT, hd, rows, current_stream(pos))
+
+
+def rope_rows(cosT: torch.Tensor, sinT: torch.Tensor, pos: torch.Tensor, hd: int, rows: torch.Tensor):
+    get_lib().call("bra_rope_rows", cosT, sinT, pos, pos.numel(), hd, rows, current_stream(pos))
 
 
 def row_sumsq(x: torch.Tensor, nss: int = 32) -> torch.Tensor:

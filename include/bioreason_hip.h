@@ -209,7 +209,7 @@ int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, const void* k
                       const int* pos, const void* kp, long kp_sr, long kp_sh, long kp_ss, const void* vtp, long vt_sr,
                       long vt_sh, long vt_sd, const void* pmask, void* kc, void* vc, float* part_o, float* part_ml, int R,
                       int copies, int Hq, int Hkv, int hd, int P, int C, int t, float eps, float scale, const int* t_dev,
-                      void* stream);
+                      const float* rope_rows, void* stream);
 int bra_attn_decode_merge(const float* part_o, const float* part_ml, void* o, int B, int Hq, int hd, int nchunk,
                           const int* t_dev, int npc, void* stream);
 int bra_qwen_decode_step_fused(const void* layers_host, int L, int B, int H, int Hq, int Hkv, int hd, int F, int Smax,
@@ -286,8 +286,14 @@ int bra_sample_embed(const float* logits, long ldl, int B, int V, float temperat
 /* synthetic EOS schedule for benchmarks / tests with random-init weights (SURVEY 8d "straggler run"): logits[b, token]
  * is raised above every other entry when *step_ptr == at[b], so row b draws `token` at that step.  B <= 64. */
 int bra_force_token(float* logits, long ldl, int B, int V, int token, const int* step_ptr, const int* at, void* stream);
-/* counters of the replayed token loop: pos[0..n) += 1, a[0] += 1, b[0] += 1 (a, b optional) */
-int bra_advance_counters(int* pos, int n, int* a, int* b, void* stream);
+/* counters of the replayed token loop: pos[0..n) += 1, a[0] += 1, b[0] += 1 (a, b optional); when `rope_rows` is given, also
+ * rope_rows[i][0..hd/2) = cosT[pos[i]], [hd/2..hd) = sinT[pos[i]] for the NEW positions (see bra_rope_rows) */
+int bra_advance_counters(int* pos, int n, int* a, int* b, const float* cosT, const float* sinT, int hd, float* rope_rows,
+                         void* stream);
+/* rope_rows [n, hd] fp32 = (cos | sin) table rows of the positions pos[0..n): the decode attention kernels read the row of
+ * their sequence directly instead of hopping pos -> table (one dependent memory round trip per layer less); optional last
+ * pointer argument of bra_dec_attn_both */
+int bra_rope_rows(const float* cosT, const float* sinT, const int* pos, int n, int hd, float* rope_rows, void* stream);
 /* completion mask up to and including the first EOS (grpo_trainer.py:605-609) */
 int bra_eos_mask(const int* ids, int B, int C, int eos_id, int* mask, int* lengths, void* stream);
 /* rewards [N,F] -> sum over F -> (r - mean_group) / (std_group + 1e-4), groups of G (grpo_trainer.py:682-691) */
