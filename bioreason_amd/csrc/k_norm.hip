@@ -280,6 +280,127 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(RopeBwdArgs a) {
     dst[d + half] = f2bf(g2);
 }
 
+// ---- vectorised forms (hd = 64 or 128, every stride a multiple of 8 elements): HD / 8 lanes per head, 16 bytes per lane.
+// Lane j of a head owns dims 8j .. 8j+7; its rotation partner (dims +- hd/2) is lane j ^ (LPH / 2).  Same arithmetic and
+// rounding points as the scalar kernels above (only the order of the sum-of-squares butterfly differs).
+template <int HD>
+__global__ __launch_bounds__(256) void qk_norm_rope_fwd_vec_kernel(RopeArgs a) {
+    constexpr int LPH = HD / 8, HALF = HD / 2;
+    const int H = a.Hq + 2 * a.Hkv;
+    const long nhead = (long)a.T * H;
+    const long gl = (long)blockIdx.x * 256 + threadIdx.x;
+    const long hidx = gl / LPH;
+    const int j = (int)(gl % LPH);
+    const bool live = hidx < nhead;
+    const long hc = live ? hidx : nhead - 1;
+    const int h = (int)(hc % H);
+    const int t = (int)(hc / H);
+    const bool is_q = h < a.Hq, is_k = !is_q && h < a.Hq + a.Hkv;
+    const bool upper = j >= LPH / 2;
+    const int dh = (j & (LPH / 2 - 1)) * 8;                     // index into the half-dim cos / sin row
+    float x[8];
+    unpack8(ld16(a.qkv + (long)t * a.ldqkv + (long)h * HD + j * 8), x);
+    const bf16_t* nw = is_q ? a.qw : (is_k ? a.kw : nullptr);
+    u32x4 nwv = {0u, 0u, 0u, 0u};
+    if (nw) nwv = ld16(nw + j * 8);
+    f32x4 c0 = {1.f, 1.f, 1.f, 1.f}, c1 = c0, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (is_q || is_k) {
+        const int p = a.pos[t];
+        const float* cp = a.cosT + (long)p * HALF + dh;
+        const float* sp = a.sinT + (long)p * HALF + dh;
+        c0 = *reinterpret_cast<const f32x4*>(cp); c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+        s0 = *reinterpret_cast<const f32x4*>(sp); s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+#pragma unroll
+    for (int m = LPH >> 1; m >= 1; m >>= 1) ss += wave_shfl_xor(ss, m);
+    if (nw) {
+        const float rstd = rsqrtf(ss / (float)HD + a.eps);
+        float w[8];
+        unpack8(nwv, w);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = round_bf(w[i] * round_bf(x[i] * rstd));
+    }
+    if (is_q && a.qscale != 1.f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = round_bf(x[i] * a.qscale);
+    }
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float other = wave_shfl_xor(x[i], LPH / 2);
+        const float c = i < 4 ? c0[i & 3] : c1[i & 3], sn = i < 4 ? s0[i & 3] : s1[i & 3];
+        o[i] = (is_q || is_k) ? (upper ? x[i] * c + other * sn : x[i] * c - other * sn) : x[i];
+    }
+    if (!live) return;
+    const int b = t / a.S, sidx = t % a.S;
+    bf16_t* dst;
+    if (is_q) dst = a.q + b * a.q_sb + sidx * a.q_ss + (long)h * a.q_sh;
+    else if (is_k) dst = a.k + b * a.k_sb + (sidx + a.s_off) * a.k_ss + (long)(h - a.Hq) * a.k_sh;
+    else dst = a.v + b * a.v_sb + (sidx + a.s_off) * a.v_ss + (long)(h - a.Hq - a.Hkv) * a.v_sh;
+    st16(dst + j * 8, pack8(o));
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void qk_norm_rope_bwd_vec_kernel(RopeBwdArgs a) {
+    constexpr int LPH = HD / 8, HALF = HD / 2;
+    const int H = a.Hq + 2 * a.Hkv;
+    const long nhead = (long)a.T * H;
+    const long gl = (long)blockIdx.x * 256 + threadIdx.x;
+    const long hidx = gl / LPH;
+    const int j = (int)(gl % LPH);
+    const bool live = hidx < nhead;
+    const long hc = live ? hidx : nhead - 1;
+    const int h = (int)(hc % H);
+    const int t = (int)(hc / H);
+    const bool is_q = h < a.Hq, is_k = !is_q && h < a.Hq + a.Hkv;
+    const bool upper = j >= LPH / 2;
+    const int dh = (j & (LPH / 2 - 1)) * 8;
+    const int b = t / a.S, sidx = t % a.S;
+    const bf16_t* gsrc;
+    if (is_q) gsrc = a.dq + b * a.q_sb + sidx * a.q_ss + (long)h * a.q_sh;
+    else if (is_k) gsrc = a.dk + b * a.k_sb + sidx * a.k_ss + (long)(h - a.Hq) * a.k_sh;
+    else gsrc = a.dv + b * a.v_sb + sidx * a.v_ss + (long)(h - a.Hq - a.Hkv) * a.v_sh;
+    float g[8], x[8];
+    unpack8(ld16(gsrc + j * 8), g);
+    unpack8(ld16(a.qkv + (long)t * a.ldqkv + (long)h * HD + j * 8), x);
+    const bf16_t* nw = is_q ? a.qw : (is_k ? a.kw : nullptr);
+    float w[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (nw) unpack8(ld16(nw + j * 8), w);
+    if (is_q || is_k) {   // transpose of the rotation: first half r1 = g1 c + g2 s, second half r2 = g2 c - g1 s
+        const int p = a.pos[t];
+        const float* cp = a.cosT + (long)p * HALF + dh;
+        const float* sp = a.sinT + (long)p * HALF + dh;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float other = wave_shfl_xor(g[i], LPH / 2);
+            const float c = i < 4 ? c0[i & 3] : c1[i & 3], sn = i < 4 ? s0[i & 3] : s1[i & 3];
+            g[i] = upper ? g[i] * c - other * sn : g[i] * c + other * sn;
+        }
+    }
+    if (is_q && a.qscale != 1.f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] *= a.qscale;
+    }
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ss += x[i] * x[i]; if (nw) dot += w[i] * g[i] * x[i]; }
+#pragma unroll
+    for (int m = LPH >> 1; m >= 1; m >>= 1) { ss += wave_shfl_xor(ss, m); dot += wave_shfl_xor(dot, m); }
+    if (nw) {
+        const float rstd = rsqrtf(ss / (float)HD + a.eps);
+        const float cm = dot * rstd / (float)HD;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = rstd * (w[i] * g[i] - x[i] * rstd * cm);
+    }
+    if (!live) return;
+    st16(a.dqkv + (long)t * a.lddqkv + (long)h * HD + j * 8, pack8(g));
+}
+
 }  // namespace bra
 
 using namespace bra;
@@ -351,6 +472,14 @@ extern "C" int bra_qk_norm_rope_fwd(const void* qkv, long ldqkv, const void* qw,
                   hd, eps, qscale, (bf16_t*)q, q_sb, q_ss, q_sh, (bf16_t*)k, k_sb, k_ss, k_sh, (bf16_t*)v, v_sb,
                   v_ss, v_sh, s_off};
     const long total = (long)T * (Hq + 2 * Hkv) * (hd / 2);
+    const bool vec = (hd == 128 || hd == 64) && ldqkv % 8 == 0 && !((q_sb | q_ss | q_sh | k_sb | k_ss | k_sh | v_sb | v_ss | v_sh) & 7);
+    if (vec) {
+        const long lanes = (long)T * (Hq + 2 * Hkv) * (hd / 8);
+        const dim3 grid((unsigned)((lanes + 255) / 256));
+        if (hd == 128) BRA_LAUNCH((qk_norm_rope_fwd_vec_kernel<128>), grid, dim3(256), 0, stream, a);
+        else BRA_LAUNCH((qk_norm_rope_fwd_vec_kernel<64>), grid, dim3(256), 0, stream, a);
+        return BRA_LAUNCH_STATUS();
+    }
     BRA_LAUNCH(qk_norm_rope_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
     return BRA_LAUNCH_STATUS();
 }
@@ -367,6 +496,15 @@ extern "C" int bra_qk_norm_rope_bwd(const void* qkv, long ldqkv, const void* qw,
                      Hkv, hd, eps, qscale, (const bf16_t*)dq, q_sb, q_ss, q_sh, (const bf16_t*)dk, k_sb, k_ss, k_sh,
                      (const bf16_t*)dv, v_sb, v_ss, v_sh, (bf16_t*)dqkv, lddqkv};
     const long total = (long)T * (Hq + 2 * Hkv) * (hd / 2);
+    const bool vec = (hd == 128 || hd == 64) && ldqkv % 8 == 0 && lddqkv % 8 == 0 &&
+                     !((q_sb | q_ss | q_sh | k_sb | k_ss | k_sh | v_sb | v_ss | v_sh) & 7);
+    if (vec) {
+        const long lanes = (long)T * (Hq + 2 * Hkv) * (hd / 8);
+        const dim3 grid((unsigned)((lanes + 255) / 256));
+        if (hd == 128) BRA_LAUNCH((qk_norm_rope_bwd_vec_kernel<128>), grid, dim3(256), 0, stream, a);
+        else BRA_LAUNCH((qk_norm_rope_bwd_vec_kernel<64>), grid, dim3(256), 0, stream, a);
+        return BRA_LAUNCH_STATUS();
+    }
     BRA_LAUNCH(qk_norm_rope_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
     return BRA_LAUNCH_STATUS();
 }
