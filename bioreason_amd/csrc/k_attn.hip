@@ -179,6 +179,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
     }
     __syncthreads();
 
+    // key-validity word of the NEXT tile is requested one iteration ahead (its mask load is a dependent L2 round trip)
+    uint64_t valid_next = ntile > 0 ? key_valid_word(a, b, 0, lane) : 0ull;
     for (int t = 0; t < ntile; ++t) {
         const int kv0 = t * 64;
         const int tl = opaque_i(tid), ll = opaque_i(lane);      // per-iteration copies: keeps address math out of registers across the loop
@@ -189,7 +191,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
             load_rows<HD, NT>(rk, kb_, a.k_ss, kv0 + 64, a.Sk, tl);
             load_trans<HD, NT>(rv, vtb, a.vt_sd, kv0 + 64, tl);
         }
-        const uint64_t valid = key_valid_word(a, b, kv0, lane);
+        const uint64_t valid = valid_next;
+        valid_next = key_valid_word(a, b, kv0 + 64, ll);
         // wave-uniform skip: every key of this tile is after every query of this wave
         const bool skip = a.causal && (kv0 > qw0 + 31 + a.q_off);
         if (!skip) {
