@@ -709,3 +709,94 @@ def test_lora_dropout_kernels(backend, M, K, R):
     # p = 0 reproduces the plain kernels
     t0 = ops.lora_down_drop(x, A, 0.5, 0.0, seeds)
     assert rel(t0, (0.5 * x.float() @ A.float().T).to(BF)) < 4e-3
+
+
+# ----------------------------------------------------------------------------- one-launch shared-prefix decode attention
+def _rope_ref(x, cos, sin):
+    """rotate-half RoPE (TF:qwen3:109-133) of x [..., hd] with cos / sin [..., hd/2] rows"""
+    h = x.shape[-1] // 2
+    x1, x2 = x[..., :h], x[..., h:]
+    return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], -1)
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,R,copies,P,C,t,use_rows", [
+    (128, 4, 2, 1, 8, 200, 256, 0, True),        # first decode step: no completion keys yet
+    (128, 4, 2, 1, 8, 200, 256, 1, True),
+    (128, 4, 2, 2, 3, 150, 192, 64, False),      # two prompts, completion exactly one full chunk
+    (128, 2, 2, 1, 5, 70, 192, 130, True),       # G = 1, three completion chunks (the last ragged)
+    (64, 8, 2, 2, 4, 129, 128, 77, False),       # hd 64, G = 4
+])
+@pytest.mark.parametrize("flags", [0, 32, 64])
+def test_dec_attn_one_launch(backend, monkeypatch, hd, Hq, Hkv, R, copies, P, C, t, use_rows, flags):
+    """(flags: 0 = items kernel + tails kernel, 32 = K / V^T through LDS-DMA, 64 = one launch with waiting tails)
+    bra_dec_attn_one: q/k RMSNorm + RoPE, cache append, attention over the shared prompt K / V^T + each sequence's own
+    completion keys + the new key, merged in the same launch — against plain fp32 torch (TF:qwen3:231-284 on one token)."""
+    from bioreason_amd._lib import get_lib, current_stream
+    monkeypatch.setenv("BRA_DEC_ONE_FLAGS", str(flags))
+    dev = backend
+    B, G = R * copies, Hq // Hkv
+    Nq, Nkv = Hq * hd, Hkv * hd
+    eps, scale = 1e-6, hd ** -0.5
+    qkv = rnd(B, Nq + 2 * Nkv, dev=dev, seed=1)
+    qw, kw = (1.0 + 0.1 * rnd(hd, dev=dev, seed=2).float()).to(BF), (1.0 + 0.1 * rnd(hd, dev=dev, seed=3).float()).to(BF)
+    kp = rnd(R, Hkv, P, hd, dev=dev, seed=4)
+    vp = rnd(R, Hkv, P, hd, dev=dev, seed=5)
+    pitch = (P + 63) // 64 * 64
+    vtp = torch.zeros(R, Hkv, hd, pitch, dtype=BF, device=dev)
+    vtp[..., :P] = vp.transpose(2, 3)
+    pmask = torch.ones(R, P, dtype=torch.uint8, device=dev)
+    pmask[0, :13] = 0                                            # left padding of prompt 0
+    kc = torch.zeros(B, Hkv, C, hd, dtype=BF, device=dev)
+    cp = (C + 63) // 64 * 64
+    vct = torch.zeros(B, Hkv, hd, cp, dtype=BF, device=dev)
+    kc_old, vc_old = rnd(B, Hkv, max(t, 1), hd, dev=dev, seed=6), rnd(B, Hkv, max(t, 1), hd, dev=dev, seed=7)
+    if t > 0:
+        kc[:, :, :t] = kc_old[:, :, :t]
+        vct[:, :, :, :t] = vc_old[:, :, :t].transpose(2, 3)
+    npos = P + C + 1
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = torch.arange(npos).float()[:, None] * inv[None]
+    cosT, sinT = ang.cos().to(BF).float().to(dev).contiguous(), ang.sin().to(BF).float().to(dev).contiguous()
+    pos = (torch.arange(B, dtype=torch.int32) % 5 + P - 13 + t).to(dev)
+    rope_rows = torch.cat([cosT[pos.long()], sinT[pos.long()]], -1).contiguous() if use_rows else None
+    nslot = (P + 63) // 64 + (C + 63) // 64
+    part_o = torch.full((B * Hq, nslot, hd), float("nan"), dtype=torch.float32, device=dev)
+    part_ml = torch.full((B * Hq, nslot, 2), float("nan"), dtype=torch.float32, device=dev)
+    counters = torch.zeros(R * Hkv, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    o = torch.zeros(B, Nq, dtype=BF, device=dev)
+    get_lib().call("bra_dec_attn_one", qkv, Nq + 2 * Nkv, qw, kw, cosT, sinT, pos, rope_rows, kp, Hkv * P * hd, P * hd, hd, vtp,
+                   Hkv * hd * pitch, hd * pitch, pitch, pmask, kc, vct, cp, part_o, part_ml, nslot, counters, err, o, Nq, R, copies,
+                   Hq, Hkv, hd, P, C, t, eps, scale, None, current_stream(qkv))
+    assert int(err.item()) == 0
+    want_arrivals = (P + 63) // 64 + copies * ((t + 63) // 64)
+    assert (counters.cpu() == (want_arrivals if flags & 64 else 0)).all()
+    # ---- reference
+    f = qkv.float().cpu()
+    q = f[:, :Nq].view(B, Hq, hd)
+    k = f[:, Nq:Nq + Nkv].view(B, Hkv, hd)
+    v = f[:, Nq + Nkv:].view(B, Hkv, hd)
+
+    def nrm(x, w):
+        y = (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)).to(BF).float()
+        return (w.float().cpu() * y).to(BF).float()
+    c_, s_ = cosT.cpu()[pos.long().cpu()][:, None], sinT.cpu()[pos.long().cpu()][:, None]
+    qn = _rope_ref(nrm(q, qw), c_, s_).to(BF).float()
+    kn = _rope_ref(nrm(k, kw), c_, s_).to(BF).float()
+    # caches after the append
+    assert torch.equal(kc[:, :, t].float().cpu(), kn)
+    assert torch.equal(vct[:, :, :, t].float().cpu(), v)
+    if t > 0:
+        assert torch.equal(kc[:, :, :t].cpu(), kc_old[:, :, :t].cpu())
+    ref = torch.zeros(B, Hq, hd)
+    for b in range(B):
+        r = b // copies
+        for hq in range(Hq):
+            h = hq // G
+            keys = torch.cat([kp[r, h].float().cpu(), kc_old[b, h, :t].float().cpu() if t > 0 else torch.zeros(0, hd), kn[b, h][None]], 0)
+            vals = torch.cat([vp[r, h].float().cpu(), vc_old[b, h, :t].float().cpu() if t > 0 else torch.zeros(0, hd), v[b, h][None]], 0)
+            valid = torch.cat([pmask[r].bool().cpu(), torch.ones(t + 1, dtype=torch.bool)])
+            sc = (keys @ qn[b, hq]) * scale
+            sc[~valid] = float("-inf")
+            ref[b, hq] = torch.softmax(sc, 0) @ vals
+    assert rel(o.view(B, Hq, hd), ref) < 6e-3

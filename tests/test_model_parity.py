@@ -280,9 +280,12 @@ def test_shared_dna_encoding_is_exact(backend):
     assert torch.equal(l0, l1)
 
 
-def test_shared_prefix_decode_kernel_matches_per_copy_decode(backend):
-    """bra_dec_attn_shared (one MFMA pass over the prompt K / V^T for all copies of a prompt) + per-copy completion
+@pytest.mark.parametrize("attn_impl", ["both", "one"])
+def test_shared_prefix_decode_kernel_matches_per_copy_decode(backend, monkeypatch, attn_impl):
+    """(attn_impl: the two-launch attention of the step, or the opt-in bra_dec_attn_one path with its transposed V cache)
+    bra_dec_attn_shared (one MFMA pass over the prompt K / V^T for all copies of a prompt) + per-copy completion
     attention against the per-copy fused decode: same choices under teacher forcing (hd = 128, G = 2, 2 copies)."""
+    monkeypatch.setenv("BRA_DEC_ATTN", attn_impl)
     fix = torch.load(os.path.join(GOLD, "tiny_b.pt"), weights_only=False)
     cfg = fix["config"]
     m = build(fix, backend, True)
