@@ -85,6 +85,14 @@ __device__ __forceinline__ uint32_t wave_shfl_u32(uint32_t v, int src) { return 
 __device__ __forceinline__ uint32_t wave_shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
 __device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p); }
 #endif
+// exchange with lane ^ 1 (DPP quad permute: a VALU move, no LDS crossbar round trip)
+#ifdef BRA_EMU
+__device__ __forceinline__ uint32_t lane_swap1(uint32_t v) { return wave_shfl_xor_u32(v, 1); }
+#else
+__device__ __forceinline__ uint32_t lane_swap1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+}
+#endif
 __device__ __forceinline__ float wave_shfl_xor(float v, int m) {
     return __builtin_bit_cast(float, wave_shfl_xor_u32(__builtin_bit_cast(uint32_t, v), m));
 }

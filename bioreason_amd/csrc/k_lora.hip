@@ -20,45 +20,53 @@ struct LoraDownArgs {
     int M, K, R;
     float alpha;
     DropCfg d;
+    int nb_live;                    // rank blocks that belong to a target module; the padding blocks behind them produce zeros
 };
 
-// workgroup = 32 rows of x against all R = 32 RB adapter rows; K in steps of 64 through LDS, the two waves take one half
-// of every step each (M / 32 workgroups of two waves keep every CU busy; the halves meet in LDS at the end)
-template <int RB>
-__global__ __launch_bounds__(128) void lora_down_drop_kernel(LoraDownArgs g) {
-    constexpr int XP = 64 + 8;
-    __shared__ bf16_t xs[2][32 * XP];
-    __shared__ bf16_t as[2][32 * RB * XP];
-    __shared__ float red[RB][64][16];
+// workgroup = 32 rows of x against all R = 32 RB adapter rows; K in steps of 128 through LDS, the four waves take two of the
+// eight 16-wide slices of every step each (M / 32 workgroups; the four partial tiles meet in LDS at the end).  The kernel is
+// bound by the latency of its one-step-ahead prefetch, not by bytes or VALU work (tools/lora_bench.py): a step therefore
+// carries 8 KB of x + 8 NL KB of A per workgroup, twice what the two-wave form had in flight.
+// RB = rank blocks of the (padded) output, NL <= RB of them live: both compile-time, so that no branch sits between the
+// accumulators and their MFMAs (a run-time block count moved them between AGPRs and VGPRs around every K step)
+template <int RB, int NL>
+__global__ __launch_bounds__(256) void lora_down_drop_kernel(LoraDownArgs g) {
+    constexpr int KS = 128, XP = KS + 8;
+    constexpr int XS_ELEMS = 2 * 32 * XP, AS_ELEMS = 2 * 32 * NL * XP;
+    constexpr int RED_BYTES = 3 * NL * 64 * 16 * 4, STAGE_BYTES = (XS_ELEMS + AS_ELEMS) * 2;
+    __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES];
+    bf16_t* xs = reinterpret_cast<bf16_t*>(lds);                       // [2][32 * XP]
+    bf16_t* as = xs + XS_ELEMS;                                        // [2][32 * NL * XP]
+    float* red = reinterpret_cast<float*>(lds);                        // [3][NL][64][16], after the K loop
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int m0 = (int)blockIdx.x * 32;
-    const int nstep = (g.K + 63) / 64;
+    const int nstep = (g.K + KS - 1) / KS;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    u32x4 rx[2], ra[2 * RB];
+    u32x4 rx[2], ra[2 * NL];
     auto issue = [&](int s) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int c = tid + 128 * i, row = c >> 3, k = 64 * s + 8 * (c & 7);
+            const int c = tid + 256 * i, row = c >> 4, k = KS * s + 8 * (c & 15);
             int m = m0 + row; m = m < g.M ? m : g.M - 1;
             const u32x4 v = ld16(g.x + (long)m * g.ldx + (k < g.K ? k : 0));
             rx[i] = k < g.K ? v : zero4;
         }
 #pragma unroll
-        for (int i = 0; i < 2 * RB; ++i) {
-            const int c = tid + 128 * i, row = c >> 3, k = 64 * s + 8 * (c & 7);
+        for (int i = 0; i < 2 * NL; ++i) {                       // rows of the live blocks only
+            const int c = tid + 256 * i, row = c >> 4, k = KS * s + 8 * (c & 15);
             const u32x4 v = ld16(g.A + (long)(row < g.R ? row : g.R - 1) * g.lda + (k < g.K ? k : 0));
             ra[i] = (k < g.K && row < g.R) ? v : zero4;
         }
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { const int c = tid + 128 * i; st16(&xs[buf][(c >> 3) * XP + 8 * (c & 7)], rx[i]); }
+        for (int i = 0; i < 2; ++i) { const int c = tid + 256 * i; st16(&xs[buf * 32 * XP + (c >> 4) * XP + 8 * (c & 15)], rx[i]); }
 #pragma unroll
-        for (int i = 0; i < 2 * RB; ++i) { const int c = tid + 128 * i; st16(&as[buf][(c >> 3) * XP + 8 * (c & 7)], ra[i]); }
+        for (int i = 0; i < 2 * NL; ++i) { const int c = tid + 256 * i; st16(&as[buf * 32 * NL * XP + (c >> 4) * XP + 8 * (c & 15)], ra[i]); }
     };
-    f32x16 acc[RB];
+    f32x16 acc[NL];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+    for (int rb = 0; rb < NL; ++rb)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[rb][q] = 0.f;
     issue(0); commit(0);
@@ -70,23 +78,23 @@ __global__ __launch_bounds__(128) void lora_down_drop_kernel(LoraDownArgs g) {
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             const int kk = 2 * wave + k2;
-            const u32x4 xf = ld16(&xs[buf][(lane & 31) * XP + 16 * kk + 8 * h]);
-            const uint32_t e0 = (uint32_t)mrow * (uint32_t)g.K + (uint32_t)(64 * s + 16 * kk + 8 * h);
+            const u32x4 xf = ld16(&xs[buf * 32 * XP + (lane & 31) * XP + 16 * kk + 8 * h]);
+            const uint32_t e0 = (uint32_t)mrow * (uint32_t)g.K + (uint32_t)(KS * s + 16 * kk + 8 * h);
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
+            for (int rb = 0; rb < NL; ++rb) {
                 const u32x4 af = drop_apply8(xf, g.d.seed[rb], e0, g.d.thr16, g.d.inv_keep);
-                const u32x4 bf = ld16(&as[buf][(32 * rb + (lane & 31)) * XP + 16 * kk + 8 * h]);
+                const u32x4 bf = ld16(&as[buf * 32 * NL * XP + (32 * rb + (lane & 31)) * XP + 16 * kk + 8 * h]);
                 acc[rb] = mfma_32x32x16(af, bf, acc[rb]);
             }
         }
         if (s + 1 < nstep) commit(buf ^ 1);
         __syncthreads();
     }
-    if (wave == 1) {
+    if (wave != 0) {
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < NL; ++rb)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) red[rb][lane][q] = acc[rb][q];
+            for (int q = 0; q < 16; ++q) red[(((wave - 1) * NL + rb) * 64 + lane) * 16 + q] = acc[rb][q];
     }
     __syncthreads();
     if (wave != 0) return;
@@ -96,7 +104,13 @@ __global__ __launch_bounds__(128) void lora_down_drop_kernel(LoraDownArgs g) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int m = m0 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (m < g.M && r < g.R) g.t[(long)m * g.ldt + r] = f2bf(g.alpha * (acc[rb][q] + red[rb][lane][q]));
+            float v = 0.f;
+            if (rb < NL) {
+                v = acc[rb < NL ? rb : 0][q];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += red[((w * NL + (rb < NL ? rb : 0)) * 64 + lane) * 16 + q];
+            }
+            if (m < g.M && r < g.R) g.t[(long)m * g.ldt + r] = f2bf(g.alpha * v);
         }
     }
 }
@@ -108,54 +122,63 @@ struct LoraUpArgs {
     int M, K, R;
     int k_chunk;                    // columns per workgroup (multiple of 32)
     DropCfg d;
+    int nb_live;                    // rank blocks that belong to a target module (padding blocks contribute nothing)
 };
 
 // wave = 32 rows of dts, walks 32-column tiles of the output; rank-32 product per target, masked, summed over targets
-template <int RB>
+template <int RB, int NL>
 __global__ __launch_bounds__(256) void lora_up_drop_kernel(LoraUpArgs g) {
     const int lane = lane_id(), wave = (int)threadIdx.x >> 6, h = lane >> 5;
     const int m_base = ((int)blockIdx.x * 4 + wave) * 32;
     if (m_base >= g.M) return;
     int mr = m_base + (lane & 31); mr = mr < g.M ? mr : g.M - 1;
-    u32x4 df[RB][2];
+    u32x4 df[NL][2];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+    for (int rb = 0; rb < NL; ++rb)
 #pragma unroll
         for (int c = 0; c < 2; ++c) df[rb][c] = ld16(g.dts + (long)mr * g.ldd + 32 * rb + 16 * c + 8 * h);
+    uint32_t rowbase[8];                                       // m * K of the 8 rows this lane hashes (see below)
+    {
+        const uint32_t odd0 = (uint32_t)lane & 1u;             // column parity = lane parity (k0 is a multiple of 32)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = (int)(8 * odd0) + i;
+            rowbase[i] = (uint32_t)(m_base + (q & 3) + 8 * (q >> 2) + 4 * h) * (uint32_t)g.K;
+        }
+    }
     const int k_lo = (int)blockIdx.y * g.k_chunk;
     int k_hi = k_lo + g.k_chunk; k_hi = k_hi < g.K ? k_hi : g.K;
     for (int k0 = k_lo; k0 < k_hi; k0 += 32) {
         const int kc = k0 + (lane & 31);
         const int kr = kc < g.K ? kc : g.K - 1;
-        u32x4 af[RB][2];
+        u32x4 af[NL][2];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < NL; ++rb)
 #pragma unroll
             for (int c = 0; c < 2; ++c) af[rb][c] = ld16(g.AT + (long)kr * g.ldat + 32 * rb + 16 * c + 8 * h);
         float o[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) o[q] = 0.f;
+        // a hash covers the column pair (k even, k odd) = this lane and lane ^ 1: each computes 8 of the 16 rows and they swap
+        const uint32_t odd = (uint32_t)kr & 1u;
+        const uint32_t fsh = odd ? 17u : 1u;                   // this column's 15-bit field inside a pair hash
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
+        for (int rb = 0; rb < NL; ++rb) {
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
             acc = mfma_32x32x16(df[rb][0], af[rb][0], acc);
             acc = mfma_32x32x16(df[rb][1], af[rb][1], acc);
-            // a hash covers the column pair (k even, k odd) = this lane and lane ^ 1: each computes 8 of the 16 rows
-            const uint32_t odd = (uint32_t)kr & 1u;
             uint32_t hh[16];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int q = (int)(8 * odd) + i;              // even lane: register rows 0..7, odd lane: 8..15
-                const int m = m_base + (q & 3) + 8 * (q >> 2) + 4 * h;
-                const uint32_t mine = drop_hash(g.d.seed[rb], ((uint32_t)m * (uint32_t)g.K + (uint32_t)kr) >> 1);
-                const uint32_t other = wave_shfl_xor_u32(mine, 1);
+                const uint32_t mine = drop_hash(g.d.seed[rb], (rowbase[i] + (uint32_t)kr) >> 1);     // even lane: register rows 0..7, odd: 8..15
+                const uint32_t other = lane_swap1(mine);
                 hh[i] = odd ? other : mine;
                 hh[8 + i] = odd ? mine : other;
             }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) o[q] += drop_field(hh[q], (uint32_t)kr, g.d.thr16) ? acc[q] : 0.f;
+            for (int q = 0; q < 16; ++q) o[q] += ((hh[q] >> fsh) & 0x7fffu) >= g.d.thr16 ? acc[q] : 0.f;
         }
         if (kc < g.K) {
 #pragma unroll
@@ -186,21 +209,24 @@ static DropCfg make_cfg(float p, unsigned s0, unsigned s1, unsigned s2, unsigned
 }
 
 extern "C" int bra_lora_down_drop(const void* x, long ldx, const void* A, long lda, void* t, long ldt, int M, int K, int R,
-                                  float alpha, float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, void* stream) {
+                                  float alpha, float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, int nb_live, void* stream) {
     if (M == 0) return 0;
     if (!x || !A || !t || M < 0 || K <= 0 || K % 8 || ldx % 8 || lda % 8 || (R != 32 && R != 64 && R != 128)) return BRA_ERR_ARG;
     if (!(p >= 0.f && p < 1.f) || (long)M * K >= (1l << 32)) return BRA_ERR_ARG;
-    LoraDownArgs g = {(const bf16_t*)x, ldx, (const bf16_t*)A, lda, (bf16_t*)t, ldt, M, K, R, alpha, make_cfg(p, s0, s1, s2, s3)};
+    if (nb_live <= 0 || nb_live > R / 32) nb_live = R / 32;
+    LoraDownArgs g = {(const bf16_t*)x, ldx, (const bf16_t*)A, lda, (bf16_t*)t, ldt, M, K, R, alpha, make_cfg(p, s0, s1, s2, s3), nb_live};
     const dim3 grid((M + 31) / 32);
     bra_stream_t st = (bra_stream_t)stream;
-    if (R == 32) BRA_LAUNCH((lora_down_drop_kernel<1>), grid, dim3(128), 0, st, g);
-    else if (R == 64) BRA_LAUNCH((lora_down_drop_kernel<2>), grid, dim3(128), 0, st, g);
-    else BRA_LAUNCH((lora_down_drop_kernel<4>), grid, dim3(128), 0, st, g);
+#define BRA_LD(RB_, NL_) BRA_LAUNCH((lora_down_drop_kernel<RB_, NL_>), grid, dim3(256), 0, st, g)
+    if (R == 32) BRA_LD(1, 1);
+    else if (R == 64) { if (nb_live == 1) BRA_LD(2, 1); else BRA_LD(2, 2); }
+    else { if (nb_live == 3) BRA_LD(4, 3); else if (nb_live == 4) BRA_LD(4, 4); else { g.nb_live = 4; BRA_LD(4, 4); } }
+#undef BRA_LD
     return BRA_LAUNCH_STATUS();
 }
 
 extern "C" int bra_lora_up_drop(const void* dts, long ldd, const void* AT, long ldat, void* out, long ldo, int M, int K, int R,
-                                float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, void* stream) {
+                                float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, int nb_live, void* stream) {
     if (M == 0) return 0;
     if (!dts || !AT || !out || M < 0 || K <= 0 || ldd % 8 || ldat % 8 || (R != 32 && R != 64 && R != 128)) return BRA_ERR_ARG;
     if (!(p >= 0.f && p < 1.f) || (long)M * K >= (1l << 32)) return BRA_ERR_ARG;
@@ -208,12 +234,15 @@ extern "C" int bra_lora_up_drop(const void* dts, long ldd, const void* AT, long 
     int splits = (1024 + mblk - 1) / mblk;                       // enough workgroups to fill the chip
     int k_chunk = ((K + splits - 1) / splits + 31) / 32 * 32;
     k_chunk = k_chunk < 128 ? 128 : k_chunk;
-    LoraUpArgs g = {(const bf16_t*)dts, ldd, (const bf16_t*)AT, ldat, (bf16_t*)out, ldo, M, K, R, k_chunk, make_cfg(p, s0, s1, s2, s3)};
+    if (nb_live <= 0 || nb_live > R / 32) nb_live = R / 32;
+    LoraUpArgs g = {(const bf16_t*)dts, ldd, (const bf16_t*)AT, ldat, (bf16_t*)out, ldo, M, K, R, k_chunk, make_cfg(p, s0, s1, s2, s3), nb_live};
     const dim3 grid(mblk, (K + k_chunk - 1) / k_chunk);
     bra_stream_t st = (bra_stream_t)stream;
-    if (R == 32) BRA_LAUNCH((lora_up_drop_kernel<1>), grid, dim3(256), 0, st, g);
-    else if (R == 64) BRA_LAUNCH((lora_up_drop_kernel<2>), grid, dim3(256), 0, st, g);
-    else BRA_LAUNCH((lora_up_drop_kernel<4>), grid, dim3(256), 0, st, g);
+#define BRA_LU(RB_, NL_) BRA_LAUNCH((lora_up_drop_kernel<RB_, NL_>), grid, dim3(256), 0, st, g)
+    if (R == 32) BRA_LU(1, 1);
+    else if (R == 64) { if (nb_live == 1) BRA_LU(2, 1); else BRA_LU(2, 2); }
+    else { if (nb_live == 3) BRA_LU(4, 3); else BRA_LU(4, 4); }        // (padding blocks hold zeros: treating them as live is exact, only slower)
+#undef BRA_LU
     return BRA_LAUNCH_STATUS();
 }
 

@@ -21,14 +21,21 @@ struct WgradArgs {
     int m_chunk;                    // rows of m per workgroup (multiple of 32)
     float alpha;
     DropCfg d;                      // DROP: Y is used as keep_rb(m, n) / (1 - p) * Y[m, n], one mask stream per rank block
+    int nb_live;                    // DROP: rank blocks that belong to a target module (the rest is padding: skipped)
 };
 
 constexpr int WG_YP = 128 + 8;      // LDS row pitch of the Y tile (elements): 272 bytes, odd multiple of 16
 
 // one workgroup: 128 columns of Y x all R, over m in [blockIdx.y * m_chunk, + m_chunk); 4 waves x 32 columns
-template <int RB, int DROP>
+// NL = live rank blocks (<= RB; the padding blocks of a fused projection hold zeros in T): compile-time, so that no branch
+// sits between the accumulators and their MFMAs
+template <int RB, int DROP, int NL = RB>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
-    __shared__ bf16_t ys[2][32 * WG_YP];
+    // plain: the Y tile double-buffered.  DROP: one MASKED copy of the tile per live rank block (the mask is applied where a
+    // thread holds 8 consecutive elements of a row — one hash per element pair, no exchange between lanes — and the fragment
+    // reads below then differ per rank block only by their base address), single-buffered with two barriers per step
+    constexpr int NYS = DROP ? NL : 2;
+    __shared__ bf16_t ys[NYS][32 * WG_YP];
     constexpr int WG_TP = 32 * RB + 8, TPT = RB >= 2 ? RB / 2 : 1;      // T tile pitch; 16-byte chunks per thread
     __shared__ bf16_t ts[2][32 * WG_TP];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -61,9 +68,19 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
             rt[i] = (m < m_hi && tr < 32) ? v : zero4;
         }
     };
-    auto commit = [&](int buf) {
-        st16(&ys[buf][yr * WG_YP + yc], ry[0]);
-        st16(&ys[buf][(yr + 16) * WG_YP + yc], ry[1]);
+    auto commit = [&](int buf, int s) {
+        if (DROP) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t e0 = (uint32_t)(m_lo + 32 * s + yr + 16 * i) * (uint32_t)g.N + (uint32_t)(n0 + yc);
+#pragma unroll
+                for (int rb = 0; rb < NL; ++rb)
+                    st16(&ys[rb][(yr + 16 * i) * WG_YP + yc], drop_apply8(ry[i], g.d.seed[rb], e0, g.d.thr16, g.d.inv_keep));
+            }
+        } else {
+            st16(&ys[buf][yr * WG_YP + yc], ry[0]);
+            st16(&ys[buf][(yr + 16) * WG_YP + yc], ry[1]);
+        }
 #pragma unroll
         for (int i = 0; i < TPT; ++i) {
             const int c = tid + 256 * i, tr = c / (4 * RB), tc = (c % (4 * RB)) * 8;
@@ -77,44 +94,29 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
 
-    if (nstep > 0) { issue(0); commit(0); }
+    if (nstep > 0) { issue(0); commit(0, 0); }
     __syncthreads();
     const int ncol = wave * 32 + (lane & 31);       // this lane's Y column inside the tile (A row)
+    const bool r_major = g.c_sn == 1;               // C is [R, N] (dA): n is its contiguous index -> lanes along n in the epilogue
     for (int s = 0; s < nstep; ++s) {
         const int buf = s & 1;
         if (s + 1 < nstep) issue(s + 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int mb = 16 * kk + 8 * h;          // this lane's 8 consecutive m of the k = 16 step
-            uint32_t a[4];
+            u32x4 af0;
+            if (!DROP) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                a[j] = (uint32_t)ys[buf][(mb + 2 * j) * WG_YP + ncol] | ((uint32_t)ys[buf][(mb + 2 * j + 1) * WG_YP + ncol] << 16);
-            const u32x4 af0 = {a[0], a[1], a[2], a[3]};
+                for (int j = 0; j < 4; ++j)
+                    af0[j] = (uint32_t)ys[buf][(mb + 2 * j) * WG_YP + ncol] | ((uint32_t)ys[buf][(mb + 2 * j + 1) * WG_YP + ncol] << 16);
+            }
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
+            for (int rb = 0; rb < NL; ++rb) {                    // (a padding block's T columns are zero: nothing to add)
                 u32x4 af = af0;
                 if (DROP) {
-                    // the lane's 8 elements run down a column of Y: indices (m_g + i) * N + n_g.  A hash covers the pair
-                    // (n even, n odd) = this lane and lane ^ 1, so each of the two computes half of the 8 and they swap
-                    const uint32_t n_g = (uint32_t)(n0 + ncol);
-                    const uint32_t m_g = (uint32_t)(m_lo + 32 * s + mb);
-                    const uint32_t odd = n_g & 1u;
-                    uint32_t hh[8];                              // hashes of rows 0..7 (compile-time indices only)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t row = m_g + 4 * odd + (uint32_t)i;      // even lane: rows 0..3, odd lane: rows 4..7
-                        const uint32_t mine = drop_hash(g.d.seed[rb], (row * (uint32_t)g.N + n_g) >> 1);
-                        const uint32_t other = wave_shfl_xor_u32(mine, 1);
-                        hh[i] = odd ? other : mine;
-                        hh[4 + i] = odd ? mine : other;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float lo = drop_field(hh[2 * j], n_g, g.d.thr16) ? bf_lo(a[j]) * g.d.inv_keep : 0.f;
-                        const float hi = drop_field(hh[2 * j + 1], n_g, g.d.thr16) ? bf_hi(a[j]) * g.d.inv_keep : 0.f;
-                        af[j] = pack_bf2(lo, hi);
-                    }
+                    for (int j = 0; j < 4; ++j)
+                        af[j] = (uint32_t)ys[rb][(mb + 2 * j) * WG_YP + ncol] | ((uint32_t)ys[rb][(mb + 2 * j + 1) * WG_YP + ncol] << 16);
                 }
                 const int rc = rb * 32 + (lane & 31);
                 uint32_t b[4];
@@ -122,13 +124,27 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
                 for (int j = 0; j < 4; ++j)
                     b[j] = (uint32_t)ts[buf][(mb + 2 * j) * WG_TP + rc] | ((uint32_t)ts[buf][(mb + 2 * j + 1) * WG_TP + rc] << 16);
                 const u32x4 bf = {b[0], b[1], b[2], b[3]};
-                acc[rb] = mfma_32x32x16(af, bf, acc[rb]);
+                // lanes of the accumulator run along the operand given SECOND: the contiguous index of C goes there
+                acc[rb] = r_major ? mfma_32x32x16(bf, af, acc[rb]) : mfma_32x32x16(af, bf, acc[rb]);
             }
         }
-        if (s + 1 < nstep) commit(buf ^ 1);
+        if (DROP) __syncthreads();                   // every wave is done with the masked copies of step s
+        if (s + 1 < nstep) commit(buf ^ 1, s + 1);
         __syncthreads();
     }
     if (nstep == 0) return;
+    if (r_major) {
+        // D[i][j]: i = r (register index), j = column n of Y (lane & 31): 32 consecutive floats of a row of C per atomic instruction
+        const int n = n0 + wave * 32 + (lane & 31);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int r = rb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (n < g.N && r < g.R) atomicAdd(g.C + (long)n * g.c_sn + (long)r * g.c_sr, g.alpha * acc[rb][q]);
+            }
+        return;
+    }
     // D[i][j]: i = A row = column n of Y (register index), j = B row = r (lane & 31)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -157,12 +173,14 @@ static int wgrad_launch(WgradArgs& g, int m_chunk, bool drop, void* stream) {
     g.m_chunk = (m_chunk + 31) / 32 * 32;
     const dim3 grid((g.N + 127) / 128, (g.M + g.m_chunk - 1) / g.m_chunk);
     bra_stream_t st = (bra_stream_t)stream;
-#define BRA_WG(RB_)                                                                          \
-    do {                                                                                     \
-        if (drop) BRA_LAUNCH((wgrad_tn_kernel<RB_, 1>), grid, dim3(256), 0, st, g);          \
-        else BRA_LAUNCH((wgrad_tn_kernel<RB_, 0>), grid, dim3(256), 0, st, g);               \
+#define BRA_WG(RB_, NL_)                                                                          \
+    do {                                                                                          \
+        if (drop) BRA_LAUNCH((wgrad_tn_kernel<RB_, 1, NL_>), grid, dim3(256), 0, st, g);          \
+        else BRA_LAUNCH((wgrad_tn_kernel<RB_, 0, RB_>), grid, dim3(256), 0, st, g);               \
     } while (0)
-    if (g.R == 32) BRA_WG(1); else if (g.R == 64) BRA_WG(2); else BRA_WG(4);
+    if (g.R == 32) BRA_WG(1, 1);
+    else if (g.R == 64) { if (drop && g.nb_live == 1) BRA_WG(2, 1); else BRA_WG(2, 2); }
+    else { if (drop && g.nb_live == 3) BRA_WG(4, 3); else BRA_WG(4, 4); }
 #undef BRA_WG
     return BRA_LAUNCH_STATUS();
 }
@@ -171,18 +189,19 @@ extern "C" int bra_wgrad_tn(const void* Y, long ldy, const void* T, long ldt, fl
                             int R, float alpha, int m_chunk, void* stream) {
     if (M == 0 || N == 0) return 0;
     if (!Y || !T || !C || M < 0 || N < 0 || N % 8 || ldy % 8 || ldt % 8 || (R != 32 && R != 64 && R != 128)) return BRA_ERR_ARG;
-    WgradArgs g = {(const bf16_t*)Y, ldy, (const bf16_t*)T, ldt, C, c_sn, c_sr, M, N, R, 0, alpha, {}};
+    WgradArgs g = {(const bf16_t*)Y, ldy, (const bf16_t*)T, ldt, C, c_sn, c_sr, M, N, R, 0, alpha, {}, R / 32};
     return wgrad_launch(g, m_chunk, false, stream);
 }
 
 // the same with Y masked per rank block: dA of a LoRA branch whose input went through dropout (k_lora.hip)
 extern "C" int bra_wgrad_tn_drop(const void* Y, long ldy, const void* T, long ldt, float* C, long c_sn, long c_sr, int M,
                                  int N, int R, float alpha, int m_chunk, float p, unsigned s0, unsigned s1, unsigned s2,
-                                 unsigned s3, void* stream) {
+                                 unsigned s3, int nb_live, void* stream) {
     if (M == 0 || N == 0) return 0;
     if (!Y || !T || !C || M < 0 || N < 0 || N % 8 || ldy % 8 || ldt % 8 || (R != 32 && R != 64 && R != 128)) return BRA_ERR_ARG;
     if (!(p >= 0.f && p < 1.f) || (long)M * N >= (1l << 32)) return BRA_ERR_ARG;
-    WgradArgs g = {(const bf16_t*)Y, ldy, (const bf16_t*)T, ldt, C, c_sn, c_sr, M, N, R, 0, alpha, {}};
+    if (nb_live <= 0 || nb_live > R / 32) nb_live = R / 32;
+    WgradArgs g = {(const bf16_t*)Y, ldy, (const bf16_t*)T, ldt, C, c_sn, c_sr, M, N, R, 0, alpha, {}, nb_live};
     g.d.thr16 = drop_threshold(p);
     g.d.inv_keep = 1.f / (1.f - p);
     g.d.seed[0] = s0; g.d.seed[1] = s1; g.d.seed[2] = s2; g.d.seed[3] = s3;

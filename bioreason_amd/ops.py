@@ -136,7 +136,7 @@ def wgrad_tn(y: torch.Tensor, t: torch.Tensor, out: torch.Tensor, transposed_out
     c_sn, c_sr = (1, _ld(out)) if transposed_out else (_ld(out), 1)
     if drop is not None:
         get_lib().call("bra_wgrad_tn_drop", y, _ld(y), t, _ld(t), out, c_sn, c_sr, M, N, R, alpha, m_chunk, drop[0],
-                       *_seeds4(drop[1]), current_stream(y))
+                       *_seeds4(drop[1]), min(len(drop[1]), 4), current_stream(y))
         return out
     get_lib().call("bra_wgrad_tn", y, _ld(y), t, _ld(t), out, c_sn, c_sr, M, N, R, alpha, m_chunk, current_stream(y))
     return out
@@ -159,7 +159,8 @@ def lora_down_drop(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, see
     M, K = x.shape
     R = A.shape[0]
     t = torch.empty((M, R), dtype=BF16, device=x.device)
-    get_lib().call("bra_lora_down_drop", x, _ld(x), A, _ld(A), t, _ld(t), M, K, R, alpha, p, *_seeds4(seeds), current_stream(x))
+    get_lib().call("bra_lora_down_drop", x, _ld(x), A, _ld(A), t, _ld(t), M, K, R, alpha, p, *_seeds4(seeds), min(len(seeds), 4),
+                   current_stream(x))
     return t
 
 
@@ -168,7 +169,8 @@ def lora_up_drop(dts: torch.Tensor, AT: torch.Tensor, p: float, seeds) -> torch.
     M, R = dts.shape
     K = AT.shape[0]
     out = torch.empty((M, K), dtype=BF16, device=dts.device)
-    get_lib().call("bra_lora_up_drop", dts, _ld(dts), AT, _ld(AT), out, _ld(out), M, K, R, p, *_seeds4(seeds), current_stream(dts))
+    get_lib().call("bra_lora_up_drop", dts, _ld(dts), AT, _ld(AT), out, _ld(out), M, K, R, p, *_seeds4(seeds), min(len(seeds), 4),
+                   current_stream(dts))
     return out
 
 

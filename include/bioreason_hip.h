@@ -69,13 +69,16 @@ int bra_wgrad_tn(const void* Y, long ldy, const void* T, long ldt, float* C, lon
  *   bra_lora_down_drop: t[M,R] = alpha * (drop_j(x) A^T)              x [M,K], A [R,K]
  *   bra_lora_up_drop:   out[M,K] = sum_j drop_j'( dts[:, j] A[j, :] )  dts [M,R], AT [K,R]   (input gradient of the branch)
  *   bra_wgrad_tn_drop:  bra_wgrad_tn with Y = drop_rb(Y)               (dA of the branch)
- *   bra_dropout_mask:   out[M,K] bytes = keep(seed, m, k)              (tests: inject the same masks into the oracle) */
+ *   bra_dropout_mask:   out[M,K] bytes = keep(seed, m, k)              (tests: inject the same masks into the oracle)
+ * nb_live = rank blocks that belong to a target module (<= R / 32; 0 = all): a fused projection pads its rank to 64 / 128
+ * columns, and the padding blocks (zero rows of A, zero columns of dts) are skipped instead of masked. */
 int bra_lora_down_drop(const void* x, long ldx, const void* A, long lda, void* t, long ldt, int M, int K, int R, float alpha,
-                       float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, void* stream);
+                       float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, int nb_live, void* stream);
 int bra_lora_up_drop(const void* dts, long ldd, const void* AT, long ldat, void* out, long ldo, int M, int K, int R, float p,
-                     unsigned s0, unsigned s1, unsigned s2, unsigned s3, void* stream);
+                     unsigned s0, unsigned s1, unsigned s2, unsigned s3, int nb_live, void* stream);
 int bra_wgrad_tn_drop(const void* Y, long ldy, const void* T, long ldt, float* C, long c_sn, long c_sr, int M, int N, int R,
-                      float alpha, int m_chunk, float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, void* stream);
+                      float alpha, int m_chunk, float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, int nb_live,
+                      void* stream);
 int bra_dropout_mask(void* out, int M, int K, float p, unsigned seed, void* stream);
 
 /* Fused lm_head + log-softmax statistics WITHOUT materialising logits

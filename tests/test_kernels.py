@@ -712,7 +712,7 @@ def test_lora_dropout_kernels(backend, M, K, R):
 
 
 # ----------------------------------------------------------------------------- one-launch shared-prefix decode attention
-def _rope_ref(x, cos, sin):
+def _rope_rows_ref(x, cos, sin):
     """rotate-half RoPE (TF:qwen3:109-133) of x [..., hd] with cos / sin [..., hd/2] rows"""
     h = x.shape[-1] // 2
     x1, x2 = x[..., :h], x[..., h:]
@@ -781,8 +781,8 @@ def test_dec_attn_one_launch(backend, monkeypatch, hd, Hq, Hkv, R, copies, P, C,
         y = (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)).to(BF).float()
         return (w.float().cpu() * y).to(BF).float()
     c_, s_ = cosT.cpu()[pos.long().cpu()][:, None], sinT.cpu()[pos.long().cpu()][:, None]
-    qn = _rope_ref(nrm(q, qw), c_, s_).to(BF).float()
-    kn = _rope_ref(nrm(k, kw), c_, s_).to(BF).float()
+    qn = _rope_rows_ref(nrm(q, qw), c_, s_).to(BF).float()
+    kn = _rope_rows_ref(nrm(k, kw), c_, s_).to(BF).float()
     # caches after the append
     assert torch.equal(kc[:, :, t].float().cpu(), kn)
     assert torch.equal(vct[:, :, :, t].float().cpu(), v)
@@ -800,3 +800,30 @@ def test_dec_attn_one_launch(backend, monkeypatch, hd, Hq, Hkv, R, copies, P, C,
             sc[~valid] = float("-inf")
             ref[b, hq] = torch.softmax(sc, 0) @ vals
     assert rel(o.view(B, Hq, hd), ref) < 6e-3
+
+
+@pytest.mark.parametrize("R,nlive", [(64, 1), (128, 3)])
+def test_lora_dropout_padded_rank_blocks(backend, R, nlive):
+    """a fused projection pads its rank to 64 / 128 columns (o, down: 1 target in 64; q/k/v: 3 in 128): the kernels are told
+    how many rank blocks are live (= number of seeds) and must treat the padding exactly as the zero rows / columns it is"""
+    M, K, p = 97, 136, 0.25
+    seeds = [5, 6, 7, 8][:nlive]
+    x, A, dts = rnd(M, K, dev=backend), rnd(R, K, dev=backend, scale=K ** -0.5), rnd(M, R, dev=backend)
+    A[32 * nlive:] = 0
+    dts[:, 32 * nlive:] = 0
+    masks = [ops.dropout_mask(M, K, p, seeds[j], backend).float().cpu() for j in range(nlive)]
+    xd = [(x.float().cpu() * mk / (1 - p)).to(BF).float() for mk in masks]
+    t = ops.lora_down_drop(x, A, 0.5, p, seeds)
+    want_t = torch.zeros(M, R)
+    for j in range(nlive):
+        want_t[:, 32 * j:32 * j + 32] = 0.5 * xd[j] @ A.float().cpu()[32 * j:32 * j + 32].T
+    assert rel(t, want_t.to(BF)) < 4e-3 and (t[:, 32 * nlive:] == 0).all()
+    up = ops.lora_up_drop(dts, A.T.contiguous(), p, seeds)
+    want_up = sum((dts.float().cpu()[:, 32 * j:32 * j + 32] @ A.float().cpu()[32 * j:32 * j + 32]) * masks[j] / (1 - p) for j in range(nlive))
+    assert rel(up, want_up.to(BF)) < 4e-3
+    dA = torch.zeros(R, K, device=backend)
+    ops.wgrad_tn(x, dts, dA, transposed_out=True, drop=(p, seeds))
+    want_dA = torch.zeros(R, K)
+    for j in range(nlive):
+        want_dA[32 * j:32 * j + 32] = dts.float().cpu()[:, 32 * j:32 * j + 32].T @ xd[j]
+    assert rel(dA, want_dA) < 1e-5 and (dA[32 * nlive:] == 0).all()
