@@ -10,7 +10,9 @@ GRPO "step" (default, cfg-3 of SURVEY §8d) = one full GRPO step on one batch of
 NT-500M encoder + Qwen3-1.7B, 1 unique prompt x G=8 rollouts per GPU, prompt P = 2180 (2 DNA sequences x 1024 NT
 tokens + 128 text tokens), 256 sampled tokens per rollout (EOS suppressed so every rollout has the full length),
 reference log-probs (adapters off), policy forward/backward in train mode (LoRA r=32, lora_dropout 0.05 on all 7
-projections + dna_projection), reward all-gather + group advantages, gradient all-reduce, AdamW with grad clip 1.0.
+projections + dna_projection), the reward hop of grpo_trainer.py:642-676 (completion ids -> host -> decode -> the five python
+reward functions reason.py enables by default -> device; a synthetic id -> text table stands in for the tokenizer files),
+reward all-gather + group advantages, gradient all-reduce, AdamW with grad clip 1.0.
 SFT "step" (cfg-2) = forward (full-row lm_head logits + shifted CE on the last 64 positions) / backward / all-reduce /
 AdamW over B=8 distinct samples of the same shape.
 Inputs are resident in HBM before the timed region.  value = samples per second over all ranks.
@@ -320,7 +322,13 @@ def main():
         eos_id = 151645 if args.eos_uniform else None
         cfg = GRPOConfig(num_generations=G, max_completion_length=Cn, eos_token_id=eos_id, pad_token_id=151643 if eos_id else None,
                          seed=42, rollout_graph=False if args.no_graph else None, rollout_shared_prefix=not args.no_shared_decode)
-        runner = GRPOStepRunner(model, cfg)
+        # the reference's reward hop runs inside the timed step: ids -> host -> decode -> the five python reward functions
+        # reason.py:291-296 enables by default -> device (a synthetic id -> text table stands in for the tokenizer files)
+        from bioreason_amd.rewards import text_reward_fn
+        from bioreason_amd.synth import SyntheticTokenizer
+        reward_names = ["xmlcount", "soft_format", "strict_format", "less_than_4", "correctness"]
+        runner = GRPOStepRunner(model, cfg, reward_fn=text_reward_fn(SyntheticTokenizer(model.text_model.engine.V), reward_names,
+                                                                     prompts=[None] * B, answer=["adenocarcinoma"] * B))
         batch = synth_prompt_batch(B=B, n_unique=R, Sd=SD, text_len=TEXT_LEN, n_dna=NDNA, dna_token_id=model.dna_token_id,
                                    device=dev, seed=42 + rank)
         if args.eos_uniform:

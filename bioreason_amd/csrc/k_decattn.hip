@@ -1,23 +1,22 @@
-// k_decattn.hip — decode attention of the shared-prefix rollout in ONE launch (no separate merge kernel).
+// k_decattn.hip — decode attention of the shared-prefix rollout: an items kernel and a merge kernel.
 // The step of HF's `_sample` loop (TF:generation/utils.py:2876-2925) runs Qwen3Attention.forward (TF:qwen3:231-284) on
 // ONE new token per sequence: q/k RMSNorm + RoPE (TF:qwen3:252-256), KV-cache append, softmax(q K^T) V over the prompt
 // and the completion so far.  GRPO decodes `copies` rollouts of each prompt together (grpo_trainer.py:107-116): they share
-// ONE copy of the prompt K / V^T.  At 8 sequences this op moves ~10-17 MB and is bound by latency, not bandwidth, so the
-// launch is organised around the dependent chain:
-//   * one-wave workgroups ("items"), all independent:
-//       prompt item  (prompt r, kv-head, 64-key chunk): S^T = K Q^T and O^T = V^T P on MFMA for the <= 16 query rows
-//                    (copies x q-heads of the group) that share those keys;
-//       completion item (sequence, kv-head, 64-key chunk of the keys cached so far): the same MFMA body on the sequence's own
-//                    K rows and V^T rows (the completion V cache is kept TRANSPOSED, [B, Hkv, hd, Cp], for this);
-//     each item stores (max, sum, O) partials write-through and adds 1 to the arrival counter of its (prompt, kv-head);
-//   * one "tail" wave per (sequence, q-head): normalises + rotates q and the NEW k, appends k / v to the caches, scores
-//     the new key itself (its partial never leaves registers), waits for the arrivals of its kv-head, merges the
-//     partials and writes the attention output row.  Tails have the highest workgroup ids: when one is resident every
-//     item has been dispatched, and items never wait, so the wait always ends (it is bounded anyway: `err`).
-// Inter-workgroup visibility follows the agent-scope rules of bra_device.h (sc1 payload, drained, counted; sc1 reads).
+// ONE copy of the prompt K / V^T.  At 8 sequences this op moves ~10-17 MB and is bound by latency and by the ~16 B/clk a CU
+// can fill, not by HBM bandwidth, so the work is cut into many independent one-wave workgroups ("items"):
+//   prompt item      (prompt r, kv-head, 64-key chunk): S^T = K Q^T and O^T = V^T P on MFMA for the <= 16 query rows
+//                    (copies x q-heads of the group) that share those keys; q is requested first so that its norm / rotate
+//                    chain runs under the K / V^T flight;
+//   completion item  (sequence, kv-head, 64-key chunk of the keys cached so far): the same MFMA body on the sequence's own
+//                    K rows and V^T rows (the completion V cache is kept TRANSPOSED, [B, Hkv, hd, cp], for this);
+//   new-key item     (sequence, q-head): normalises + rotates q and the NEW k, appends k / v to the caches and emits the new
+//                    key's own partial (max = its score, sum = 1, O = v) — no item ever reads the row being appended;
+// each writes (max, sum, O) partials; dec_attn_merge_kernel (one wave per (sequence, q-head), every load issued before the
+// first is used, two partial rows per 16-byte-per-lane instruction) combines them after the kernel boundary.
+// A single-launch form (tail waves waiting on arrival counters, partials published write-through) was built and measured:
+// 20-29 us per layer against 13.5-15.8 for two launches — waves that poll starve the items' memory traffic (NOTES.md).
 #include "bra_device.h"
 #include "bra_api_internal.h"
-#include <stdlib.h>
 
 namespace bra {
 
@@ -35,26 +34,12 @@ struct DecOneArgs {
     const uint8_t* pmask;                   // [R, P] validity of prompt positions (left padding) or null
     bf16_t* kc;                             // completion K cache   [B, Hkv, C, hd]
     bf16_t* vct; long cp;                   // completion V^T cache [B, Hkv, hd, cp]
-    float* part_o; float* part_ml;          // [B * Hq, nslot, hd], [B * Hq, nslot, 2]
-    int* counters;                          // [R * Hkv] arrivals (zeroed by the caller before the launch)
-    int* err;                               // += 1 when a bounded wait ran out (never expected)
+    float* part_o; float* part_ml;          // [B * Hq, nslot, hd], [B * Hq, nslot, 2]: slots = prompt chunks, completion chunks, new key
     bf16_t* o; long ldo;                    // attention output [B, Hq * hd]
     int R, copies, Hq, Hkv, P, C, t, nslot, npc, ncc_grid;
     float eps, scale;
     const int* t_ptr;                       // optional device-side t (graph replay: constant launch arguments)
-    unsigned long long* probe;              // diagnostics (bra_debug_set_probe): 100 MHz stamps, 8 per stamped wave
-    int flags;                              // experiment switches (BRA_DEC_ONE_FLAGS), 0 in production
-    int phase;                              // 0: items + tails in one launch (tails wait on the counters); 1: items only; 2: tails only
-                                            // (launched after the items kernel: no wait, no counters)
 };
-
-#ifdef BRA_EMU
-__device__ __forceinline__ void oa_stamp(unsigned long long*, int) {}
-#else
-__device__ __forceinline__ void oa_stamp(unsigned long long* p, int slot) {
-    if (p && lane_id() == 0) p[slot] = __builtin_amdgcn_s_memrealtime();
-}
-#endif
 
 // per-head RMSNorm (weight nw) + rotate-half RoPE of the 8-dim slice this lane owns (dims 8 dl .. 8 dl + 7); the HD / 8 lanes
 // of a row are consecutive, the rotation partner (dims +- HD / 2) is lane ^ (HD / 16)
@@ -87,11 +72,10 @@ __device__ __forceinline__ void nr_slice(float (&x)[8], const bf16_t* nw, const 
 //   rel(kb, i) = 32 (kb / 2) + 8 (i / 4) + 4 (kb % 2) + (i % 4)
 // so that the eight contraction slots a lane feeds into the PV product (its four scores of block 2 kk, then of block 2 kk + 1)
 // are eight CONSECUTIVE keys: the V^T fragment of a lane is one 16-byte load.
-template <int HD, int G, int DMA>
+template <int HD, int G>
 __device__ __forceinline__ void one_item(const DecOneArgs& a, const bf16_t* kbase, long kss, const bf16_t* vbase, long vsd,
                                          const int key0, const int nkeys, const uint8_t* mask, const int r, const int hkv,
-                                         const int row_lo, const int row_hi, const int slot, unsigned long long* pr) {
-    oa_stamp(pr, 0);
+                                         const int row_lo, const int row_hi, const int slot) {
     constexpr int DS = HD / 32;           // 32-deep contraction steps over the head dim
     constexpr int DB = HD / 16;           // 16-wide output blocks over the head dim
     const int lane = lane_id();
@@ -117,43 +101,33 @@ __device__ __forceinline__ void one_item(const DecOneArgs& a, const bf16_t* kbas
         cs[s][0] = *reinterpret_cast<const f32x4*>(cosr + hb); cs[s][1] = *reinterpret_cast<const f32x4*>(cosr + hb + 4);
         cs[s][2] = *reinterpret_cast<const f32x4*>(sinr + hb); cs[s][3] = *reinterpret_cast<const f32x4*>(sinr + hb + 4);
     }
-    // ---- validity of the 64 positions of this chunk (bit = offset inside the chunk)
     uint8_t mb;
     {
         const int key = key0 + lane;
         mb = mask ? mask[key < nkeys ? key : nkeys - 1] : (uint8_t)1;
     }
     // ---- K rows straight into MFMA A fragments: lane (fr, fq) holds K[key rel(kb, fr)][32 s + 8 fq .. +8]
-    // ---- V^T fragments: lane (fr = d within block, fq) holds keys key0 + 32 kk + 8 fq .. +8 of row d
-    // DMA: the same per-lane 16-byte pieces travel global -> LDS (slot = instruction, lane-major) without passing through
-    // the register file, and are read back by the lane that requested them just before their MFMA
     u32x4 kf[4][DS];
-    u32x4 vf[DB][2];
-    BRA_DYN_SMEM(smem);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         int key = key0 + 32 * (kb >> 1) + 8 * (fr >> 2) + 4 * (kb & 1) + (fr & 3);
         key = key < nkeys ? key : nkeys - 1;
 #pragma unroll
-        for (int s = 0; s < DS; ++s) {
-            if (DMA) glds16(kbase + (long)key * kss + s * 32 + fq * 8, smem + (kb * DS + s) * 1024);
-            else kf[kb][s] = ld16(kbase + (long)key * kss + s * 32 + fq * 8);
-        }
+        for (int s = 0; s < DS; ++s) kf[kb][s] = ld16(kbase + (long)key * kss + s * 32 + fq * 8);
     }
+    // ---- V^T fragments: lane (fr = d within block, fq) holds keys key0 + 32 kk + 8 fq .. +8 of row d
+    u32x4 vf[DB][2];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (DMA) glds16(vbase + (long)(db * 16 + fr) * vsd + key0 + kk * 32 + fq * 8, smem + (4 * DS + db * 2 + kk) * 1024);
-            else vf[db][kk] = ld16(vbase + (long)(db * 16 + fr) * vsd + key0 + kk * 32 + fq * 8);
-        }
+        for (int kk = 0; kk < 2; ++kk) vf[db][kk] = ld16(vbase + (long)(db * 16 + fr) * vsd + key0 + kk * 32 + fq * 8);
+    // ---- validity of the 64 positions of this chunk (bit = offset inside the chunk)
     uint64_t vbits;
     {
         const int key = key0 + lane;
         vbits = wave_ballot(key < nkeys && mb != 0);
     }
     sched_fence();
-    oa_stamp(pr, 1);                       // every request issued
     // ---- q: RMSNorm, RoPE, scale
     float qv[DS][8];
     float ss = 0.f;
@@ -188,14 +162,6 @@ __device__ __forceinline__ void one_item(const DecOneArgs& a, const bf16_t* kbas
         }
         qf[s] = pack8(o);
     }
-    oa_stamp(pr, 2);                       // q ready
-    if (DMA) {
-        wait_vmcnt<2 * DB>();              // everything but the V^T pieces has landed
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int s = 0; s < DS; ++s) kf[kb][s] = *reinterpret_cast<const u32x4*>(smem + (kb * DS + s) * 1024 + lane * 16);
-    }
     // ---- scores: D[MFMA row 4 fq + j][query row fr] per 16-key block
     f32x4 sreg[4];
     float m = kNegA;
@@ -226,18 +192,9 @@ __device__ __forceinline__ void one_item(const DecOneArgs& a, const bf16_t* kbas
         }
     l += wave_shfl_xor(l, 16);
     l += wave_shfl_xor(l, 32);
-    oa_stamp(pr, 3);                       // scores + softmax (K arrived)
-    if (DMA) {
-        wait_vmcnt<0>();
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) vf[db][kk] = *reinterpret_cast<const u32x4*>(smem + (4 * DS + db * 2 + kk) * 1024 + lane * 16);
-    }
-    // ---- O^T[d][row] = V^T . P, partials written through to memory
+    // ---- O^T[d][row] = V^T . P
     const long base = ((long)b * a.Hq + hq) * a.nslot + slot;
     const bool live = fr < rows && fr >= row_lo && fr < row_hi;
-    const wt_buf po = wt_make(a.part_o, (unsigned)((long)a.R * a.copies * a.Hq * a.nslot * HD * 4));
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -250,38 +207,19 @@ __device__ __forceinline__ void one_item(const DecOneArgs& a, const bf16_t* kbas
             pf.w = pack_bf2(sreg[2 * kk + 1][2], sreg[2 * kk + 1][3]);
             acc = mfma_16x16x32(vf[db][kk], pf, acc);
         }
-        if (live) {                                                                                         // d = 16 db + 4 fq + j
-            if ((a.flags & 1) || a.phase == 1) *reinterpret_cast<f32x4*>(a.part_o + base * HD + db * 16 + 4 * fq) = acc;
-            else wt_st16(po, (unsigned)((base * HD + db * 16 + 4 * fq) * 4), __builtin_bit_cast(u32x4, acc));
-        }
+        if (live) *reinterpret_cast<f32x4*>(a.part_o + base * HD + db * 16 + 4 * fq) = acc;       // d = 16 db + 4 fq + j
     }
-    if (live && fq == 0) {
-        const uint64_t mlw = (uint64_t)__builtin_bit_cast(uint32_t, m) | ((uint64_t)__builtin_bit_cast(uint32_t, l) << 32);
-        agent_st8(a.part_ml + base * 2, mlw);
-    }
-    oa_stamp(pr, 4);                       // partial stores issued (V^T arrived)
-#ifndef BRA_EMU
-    if ((a.flags & 3) == 1) { drain_stores(); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
-#endif
-    if (a.phase == 1) return;              // the kernel boundary publishes
-    drain_stores();
-    oa_stamp(pr, 5);                       // stores drained
-    wave_converge();
-    if (lane == 0) agent_add(a.counters + r * a.Hkv + hkv, 1);
-    oa_stamp(pr, 6);
+    if (live && fq == 0) { a.part_ml[base * 2] = m; a.part_ml[base * 2 + 1] = l; }
 }
 
-// The tail of (sequence b, q-head hq): new-token q / k / v, cache append, the new key's own score, then the merge.
+// The new token of (sequence b, q-head hq): q / k / v of the new position, cache append (one q-head per kv group does it), and
+// the new key's partial in the slot behind the completion chunks: max = its score, sum = 1, O = v.
 template <int HD, int G>
-__device__ __forceinline__ void one_tail(const DecOneArgs& a, const int b, const int hq, const int t, unsigned long long* pr) {
-    oa_stamp(pr, 0);
+__device__ __forceinline__ void one_newkey(const DecOneArgs& a, const int b, const int hq, const int t) {
     constexpr int LPK = HD / 8;           // lanes of one 8-dims-per-lane row
-    constexpr int LR = HD / 4;            // lanes of one partial row in the merge (4 floats = 16 bytes each)
-    constexpr int PR = 64 / LR;           // partial rows per wave-instruction
-    constexpr int PRE = 24;               // merge instructions whose loads are all issued before the first is consumed
     const int lane = lane_id();
     const int grp = lane / LPK, dl = lane % LPK;
-    const int hkv = hq / G, r = b / a.copies;
+    const int hkv = hq / G;
     const int Nq = a.Hq * HD, Nkv = a.Hkv * HD;
     const bf16_t* row = a.qkv + (long)b * a.ldqkv;
     // lane groups of LPK lanes: group 1 = the k row, group 2 = the v row, every other group = the q row
@@ -295,14 +233,13 @@ __device__ __forceinline__ void one_tail(const DecOneArgs& a, const int b, const
 #pragma unroll
     for (int i = 0; i < 8; ++i) y[i] = x[i];
     nr_slice<HD>(y, which == 1 ? a.kw : a.qw, cosr, sinr, dl, a.eps);
-    // ---- score of the new key (always attendable): q . k_new, both rounded to bf16 as the cached rows are
+    // score of the new key (always attendable): q . k_new, both rounded to bf16 as the cached rows are
     float d = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) d += y[i] * wave_shfl_xor(y[i], LPK);          // group 0 <-> group 1
 #pragma unroll
     for (int mk = LPK >> 1; mk >= 1; mk >>= 1) d += wave_shfl_xor(d, mk);
     const float s_new = wave_shfl(d, 0) * a.scale * kLog2eA;
-    // ---- append k_new (row layout) and v_new (transposed layout); one tail per kv-head group does it
     if (hq % G == 0) {
         if (grp == 1) st16(a.kc + (((long)b * a.Hkv + hkv) * a.C + t) * HD + dl * 8, pack8(y));
         if (grp == 2) {
@@ -311,59 +248,66 @@ __device__ __forceinline__ void one_tail(const DecOneArgs& a, const int b, const
             for (int i = 0; i < 8; ++i) vp[(long)i * a.cp] = f2bf(x[i]);
         }
     }
-    // ---- v_new in the merge layout: lane (p = lane / LR, d4 = lane % LR) owns dims 4 d4 .. 4 d4 + 3
+    const long base = ((long)b * a.Hq + hq) * a.nslot + a.npc + (t + 63) / 64;
+    if (grp == 2) {
+        float* op = a.part_o + base * HD + dl * 8;
+        *reinterpret_cast<f32x4*>(op) = f32x4{x[0], x[1], x[2], x[3]};
+        *reinterpret_cast<f32x4*>(op + 4) = f32x4{x[4], x[5], x[6], x[7]};
+    }
+    if (lane == 0) { a.part_ml[base * 2] = s_new; a.part_ml[base * 2 + 1] = 1.f; }
+}
+
+template <int HD, int G>
+__global__ __launch_bounds__(64) void dec_attn_items_kernel(DecOneArgs a) {
+    const int w = (int)blockIdx.x;
+    const int t = a.t_ptr ? a.t_ptr[0] : a.t;
+    const int nP = a.npc * a.Hkv * a.R;
+    const int nC = a.ncc_grid * a.copies * a.Hkv * a.R;
+    if (w < nP) {
+        const int c = w % a.npc, hkv = (w / a.npc) % a.Hkv, r = w / (a.npc * a.Hkv);
+        one_item<HD, G>(a, a.kp + r * a.kp_sr + hkv * a.kp_sh, a.kp_ss, a.vtp + r * a.vt_sr + hkv * a.vt_sh, a.vt_sd, c * 64, a.P,
+                        a.pmask ? a.pmask + (long)r * a.P : nullptr, r, hkv, 0, 16, c);
+    } else if (w < nP + nC) {
+        const int v = w - nP;
+        const int c = v % a.ncc_grid, copy = (v / a.ncc_grid) % a.copies, hkv = (v / (a.ncc_grid * a.copies)) % a.Hkv;
+        const int r = v / (a.ncc_grid * a.copies * a.Hkv);
+        if (c * 64 >= t) return;                                 // (graph replay sizes the grid for the longest completion)
+        const int b = r * a.copies + copy;
+        one_item<HD, G>(a, a.kc + ((long)b * a.Hkv + hkv) * a.C * HD, HD, a.vct + ((long)b * a.Hkv + hkv) * HD * a.cp, a.cp, c * 64, t,
+                        nullptr, r, hkv, copy * G, copy * G + G, a.npc + c);
+    } else {
+        const int v = w - nP - nC;
+        one_newkey<HD, G>(a, v / a.Hq, v % a.Hq, t);
+    }
+}
+
+// one wave per (sequence, q-head): slots [0, npc + ceil(t / 64)] -> o.  Lane (p = lane / LR, d4 = lane % LR) owns dims
+// 4 d4 .. 4 d4 + 3 of partial rows p, p + PR, ...: PR rows per 16-byte-per-lane instruction, all requested up front.
+template <int HD>
+__global__ __launch_bounds__(64) void dec_attn_merge_kernel(DecOneArgs a) {
+    constexpr int LR = HD / 4, PR = 64 / LR, PRE = 24;
+    const int lane = lane_id();
+    const int hq = (int)blockIdx.x, b = (int)blockIdx.y;
+    const int t = a.t_ptr ? a.t_ptr[0] : a.t;
+    const int nsl = a.npc + (t + 63) / 64 + 1;
     const int p = lane / LR, d4 = lane % LR;
-    const int vsrc = 2 * LPK + d4 / 2;
-    float vn[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float lo = wave_shfl(x[j], vsrc), hi = wave_shfl(x[4 + j], vsrc);
-        vn[j] = (d4 & 1) ? hi : lo;
-    }
-    oa_stamp(pr, 1);                       // prologue done
-    if (a.flags & 4) return;
-    // ---- wait for every item of this (prompt, kv-head)
-    const int ncc = (t + 63) / 64;
-    const int nsl = a.npc + ncc;
-    const int target = a.npc + a.copies * ncc;
-    if (lane == 0 && a.phase == 0) {
-        int* cnt = a.counters + r * a.Hkv + hkv;
-        int spins = 0;
-        while (agent_ld4(cnt) < target) {
-            short_sleep();
-#ifndef BRA_EMU
-            if (a.flags & 8) __builtin_amdgcn_s_sleep(20);
-#endif
-            if (++spins > (1 << 18)) { agent_add(a.err, 1); break; }
-        }
-    }
-    wave_converge();
-    mem_fence_compiler();
-#ifndef BRA_EMU
-    if (a.flags & 16) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-    oa_stamp(pr, 2);                       // arrivals complete
-    // ---- merge: every load of the (max, sum) pairs and of the first PRE * PR partial rows is issued before anything is used
     const long base = ((long)b * a.Hq + hq) * a.nslot;
     float mc[4], lc[4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
         const int c = lane + 64 * q4;
-        const float* mlp = a.part_ml + (base + (c < nsl ? c : nsl - 1)) * 2;
-        const uint64_t w = a.phase == 2 ? *reinterpret_cast<const uint64_t*>(mlp) : agent_ld8(mlp);
-        mc[q4] = __builtin_bit_cast(float, (uint32_t)w);
-        lc[q4] = __builtin_bit_cast(float, (uint32_t)(w >> 32));
+        const u32x2 w = ld8(a.part_ml + (base + (c < nsl ? c : nsl - 1)) * 2);
+        const uint32_t wm = w.x, wl = w.y;       // (a bit_cast applied to `w.y` directly reads element 0 with this clang)
+        mc[q4] = __builtin_bit_cast(float, wm);
+        lc[q4] = __builtin_bit_cast(float, wl);
     }
-    const wt_buf po = wt_make(a.part_o, (unsigned)((long)a.R * a.copies * a.Hq * a.nslot * HD * 4));
     u32x4 v0[PRE];
 #pragma unroll
     for (int u = 0; u < PRE; ++u) {
         const int c = u * PR + p;
-        const long eo = (base + (c < nsl ? c : nsl - 1)) * HD + d4 * 4;
-        v0[u] = a.phase == 2 ? ld16(a.part_o + eo) : wt_ld16(po, (unsigned)(eo * 4));
+        v0[u] = ld16(a.part_o + (base + (c < nsl ? c : nsl - 1)) * HD + d4 * 4);
     }
-    oa_stamp(pr, 3);                       // merge loads issued
-    float m = s_new;
+    float m = kNegA;
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
         if (lane + 64 * q4 >= nsl) { mc[q4] = kNegA; lc[q4] = 0.f; }
@@ -374,14 +318,10 @@ __device__ __forceinline__ void one_tail(const DecOneArgs& a, const int b, const
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) { mc[q4] = fast_exp2(mc[q4] - m); l += lc[q4] * mc[q4]; }      // mc now holds the slot weight
     l = wave_sum<64>(l);
-    const float wn = fast_exp2(s_new - m);
-    l += wn;
-    float acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = p == 0 ? wn * vn[j] : 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < PRE; ++u) {
-        const int c = u * PR + p;                    // < 64 * ... : PRE * PR <= 96 slots, weight registers 0 and 1
+        const int c = u * PR + p;                    // PRE * PR <= 96 slots: weight registers 0 and 1
         const float wsel = (c >> 6) == 0 ? mc[0] : mc[1];
         float w = wave_shfl(wsel, c & 63);
         w = c < nsl ? w : 0.f;
@@ -396,7 +336,7 @@ __device__ __forceinline__ void one_tail(const DecOneArgs& a, const int b, const
         for (int u = 0; u < 8; ++u) {
             const int c = c0 + u * PR + p;
             const int cc = c < nsl ? c : nsl - 1;
-            v[u] = a.phase == 2 ? ld16(a.part_o + (base + cc) * HD + d4 * 4) : wt_ld16(po, (unsigned)(((base + cc) * HD + d4 * 4) * 4));
+            v[u] = ld16(a.part_o + (base + cc) * HD + d4 * 4);
             const float wsel = (cc >> 6) == 0 ? mc[0] : ((cc >> 6) == 1 ? mc[1] : ((cc >> 6) == 2 ? mc[2] : mc[3]));
             w[u] = wave_shfl(wsel, cc & 63);
             w[u] = c < nsl ? w[u] : 0.f;
@@ -412,7 +352,6 @@ __device__ __forceinline__ void one_tail(const DecOneArgs& a, const int b, const
     for (int mk = LR; mk < 64; mk <<= 1)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] += wave_shfl_xor(acc[j], mk);
-    oa_stamp(pr, 4);                       // merged (loads arrived)
     const float inv = l > 0.f ? 1.f / l : 0.f;
     if (p == 0) {
         u32x2 ov;
@@ -420,84 +359,38 @@ __device__ __forceinline__ void one_tail(const DecOneArgs& a, const int b, const
         ov.y = pack_bf2(acc[2] * inv, acc[3] * inv);
         st8(a.o + (long)b * a.ldo + (long)hq * HD + d4 * 4, ov);
     }
-    oa_stamp(pr, 5);
-}
-
-template <int HD, int G, int DMA>
-__global__ __launch_bounds__(64) void dec_attn_one_kernel(DecOneArgs a) {
-    int w = (int)blockIdx.x;
-    const int t = a.t_ptr ? a.t_ptr[0] : a.t;
-    const int nP = a.npc * a.Hkv * a.R;
-    const int nC = a.ncc_grid * a.copies * a.Hkv * a.R;
-    if (a.phase == 2) w += nP + nC;
-    if (w < nP) {
-        const int c = w % a.npc, hkv = (w / a.npc) % a.Hkv, r = w / (a.npc * a.Hkv);
-        one_item<HD, G, DMA>(a, a.kp + r * a.kp_sr + hkv * a.kp_sh, a.kp_ss, a.vtp + r * a.vt_sr + hkv * a.vt_sh, a.vt_sd, c * 64, a.P,
-                        a.pmask ? a.pmask + (long)r * a.P : nullptr, r, hkv, 0, 16, c, (a.probe && w == 0) ? a.probe : nullptr);
-    } else if (w < nP + nC) {
-        const int v = w - nP;
-        const int c = v % a.ncc_grid, copy = (v / a.ncc_grid) % a.copies, hkv = (v / (a.ncc_grid * a.copies)) % a.Hkv;
-        const int r = v / (a.ncc_grid * a.copies * a.Hkv);
-        if (c * 64 >= t) return;                                 // (graph replay sizes the grid for the longest completion)
-        const int b = r * a.copies + copy;
-        one_item<HD, G, DMA>(a, a.kc + ((long)b * a.Hkv + hkv) * a.C * HD, HD, a.vct + ((long)b * a.Hkv + hkv) * HD * a.cp, a.cp, c * 64, t,
-                        nullptr, r, hkv, copy * G, copy * G + G, a.npc + c, (a.probe && w == nP + nC - 1) ? a.probe + 8 : nullptr);
-    } else {
-        const int v = w - nP - nC;
-        one_tail<HD, G>(a, v / a.Hq, v % a.Hq, t, !a.probe ? nullptr : (v == 0 ? a.probe + 16 : (v == a.R * a.copies * a.Hq - 1 ? a.probe + 24 : nullptr)));
-    }
 }
 
 }  // namespace bra
 
 using namespace bra;
 
-extern "C" void* bra_debug_get_probe(void);
-static int one_flags() {
-    const char* e = getenv("BRA_DEC_ONE_FLAGS");
-    return e ? atoi(e) : 0;
-}
-
-// counters [R * Hkv] must be zero at launch (one memset per token step covers every layer, see bra_qwen_decode_step_one);
-// err is a sticky diagnostic word.  nslot >= ceil(P / 64) + ceil(C / 64) partial slots per (sequence, q-head), <= 256.
+// nslot = partial slots per (sequence, q-head) >= ceil(P / 64) + ceil(C / 64) + 1, <= 256.
 extern "C" int bra_dec_attn_one(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT, const float* sinT,
                                 const int* pos, const float* rope_rows, const void* kp, long kp_sr, long kp_sh, long kp_ss,
                                 const void* vtp, long vt_sr, long vt_sh, long vt_sd, const void* pmask, void* kc, void* vct, long cp,
-                                float* part_o, float* part_ml, int nslot, int* counters, int* err, void* o, long ldo, int R, int copies,
+                                float* part_o, float* part_ml, int nslot, void* o, long ldo, int R, int copies,
                                 int Hq, int Hkv, int hd, int P, int C, int t, float eps, float scale, const int* t_dev, void* stream) {
     if (R <= 0 || copies <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || P <= 0 || t < 0 || t >= C) return BRA_ERR_ARG;
     const int G = Hq / Hkv;
     if (copies * G > 16) return BRA_ERR_UNSUPPORTED;
-    if (!qkv || !qw || !kw || !cosT || !sinT || !pos || !kp || !vtp || !kc || !vct || !part_o || !part_ml || !counters || !err || !o)
-        return BRA_ERR_ARG;
+    if (!qkv || !qw || !kw || !cosT || !sinT || !pos || !kp || !vtp || !kc || !vct || !part_o || !part_ml || !o) return BRA_ERR_ARG;
     const int npc = (P + 63) / 64, ncc = (t + 63) / 64;
     if (vt_sd < (long)npc * 64 || vt_sd % 8 || kp_ss % 8 || cp < ((C + 63) / 64) * 64 || cp % 8 || ldqkv % 8 || ldo % 4) return BRA_ERR_ARG;
-    if (nslot < npc + (C + 63) / 64 || nslot > 256) return BRA_ERR_ARG;
-    if ((long)R * copies * Hq * nslot * hd * 4 >= (1l << 31)) return BRA_ERR_UNSUPPORTED;
+    if (nslot < npc + (C + 63) / 64 + 1 || nslot > 256) return BRA_ERR_ARG;
     DecOneArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, rope_rows,
                     (const bf16_t*)kp, kp_sr, kp_sh, kp_ss, (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask,
-                    (bf16_t*)kc, (bf16_t*)vct, cp, part_o, part_ml, counters, err, (bf16_t*)o, ldo,
-                    R, copies, Hq, Hkv, P, C, t, nslot, npc, ncc, eps, scale, t_dev, (unsigned long long*)bra_debug_get_probe(), one_flags(), 0};
+                    (bf16_t*)kc, (bf16_t*)vct, cp, part_o, part_ml, (bf16_t*)o, ldo,
+                    R, copies, Hq, Hkv, P, C, t, nslot, npc, ncc, eps, scale, t_dev};
     bra_stream_t st = (bra_stream_t)stream;
-    const int nitems = npc * Hkv * R + ncc * copies * Hkv * R, ntails = R * copies * Hq;
-    const int split = !(a.flags & 64);      // default: items kernel, then tails kernel (spinning tails starve the items' memory traffic)
-    const int dma = (a.flags & 32) ? 1 : 0;
-    const size_t smem = dma ? (size_t)(4 * (hd / 32) + 2 * (hd / 16)) * 1024 : 0;
-#define BRA_DO(HD_, G_, DMA_)                                                                                   \
-    if (hd == HD_ && G == G_ && dma == DMA_) {                                                                  \
-        if (split) {                                                                                            \
-            a.phase = 1;                                                                                        \
-            BRA_LAUNCH((dec_attn_one_kernel<HD_, G_, DMA_>), dim3(nitems), dim3(64), smem, st, a);              \
-            a.phase = 2;                                                                                        \
-            BRA_LAUNCH((dec_attn_one_kernel<HD_, G_, DMA_>), dim3(ntails), dim3(64), smem, st, a);              \
-        } else {                                                                                                \
-            a.phase = 0;                                                                                        \
-            BRA_LAUNCH((dec_attn_one_kernel<HD_, G_, DMA_>), dim3(nitems + ntails), dim3(64), smem, st, a);     \
-        }                                                                                                       \
-        return BRA_LAUNCH_STATUS();                                                                             \
+    const int nitems = npc * Hkv * R + ncc * copies * Hkv * R + R * copies * Hq;
+#define BRA_DO(HD_, G_)                                                                                   \
+    if (hd == HD_ && G == G_) {                                                                           \
+        BRA_LAUNCH((dec_attn_items_kernel<HD_, G_>), dim3(nitems), dim3(64), 0, st, a);                   \
+        BRA_LAUNCH((dec_attn_merge_kernel<HD_>), dim3(Hq, R * copies), dim3(64), 0, st, a);               \
+        return BRA_LAUNCH_STATUS();                                                                       \
     }
-    BRA_DO(128, 1, 0) BRA_DO(128, 2, 0) BRA_DO(128, 4, 0) BRA_DO(64, 1, 0) BRA_DO(64, 2, 0) BRA_DO(64, 4, 0)
-    BRA_DO(128, 1, 1) BRA_DO(128, 2, 1) BRA_DO(128, 4, 1) BRA_DO(64, 1, 1) BRA_DO(64, 2, 1) BRA_DO(64, 4, 1)
+    BRA_DO(128, 1) BRA_DO(128, 2) BRA_DO(128, 4) BRA_DO(64, 1) BRA_DO(64, 2) BRA_DO(64, 4)
 #undef BRA_DO
     return BRA_ERR_UNSUPPORTED;
 }

@@ -180,27 +180,19 @@ extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R
     return 0;
 }
 
-// Shared-prefix variant with the ONE-launch decode attention (k_decattn.hip): 5 launches per layer (qkv, attention incl.
-// merge, o, gate/up + SwiGLU, down).  The layer records' `vc` fields hold the TRANSPOSED completion V caches
-// [B, Hkv, hd, cp]; `counters` int [L, R * Hkv] are the arrival counters of the attention launches, zeroed here once per
-// token step; `err` is the sticky diagnostic word of bra_dec_attn_one.
+// Shared-prefix variant on k_decattn.hip (bra_dec_attn_one: items kernel + merge kernel): 6 launches per layer.  The layer
+// records' `vc` fields hold the TRANSPOSED completion V caches [B, Hkv, hd, cp].
 extern "C" int bra_qwen_decode_step_one(const void* layers_host, int L, int R, int copies, int H, int Hq, int Hkv, int hd,
                                         int F, int P, long vt_pitch, int C, long cp, int V, float eps, float scale, const void* E,
                                         const void* norm_w, const float* cosT, const float* sinT, const int* tok,
                                         const int* pos, const void* pmask, int t, const int* t_dev, int embed_done, void* x, void* qkv, void* o,
                                         void* h, void* act, float* ss_ws, int nss, float* part_o, float* part_ml, int nslot,
-                                        int* counters, int* err, float* logits, void* stream) {
+                                        float* logits, void* stream) {
     const Layer* ls = (const Layer*)layers_host;
     const int B = R * copies;
     const int Nq = Hq * hd, Nkv = Hkv * hd, Nqkv = Nq + 2 * Nkv;
     int rc;
 #define CK(call) do { rc = (call); if (rc) return rc; } while (0)
-    if (!counters || !err) return BRA_ERR_ARG;
-#ifdef BRA_EMU
-    memset(counters, 0, sizeof(int) * (size_t)L * R * Hkv);
-#else
-    if (hipMemsetAsync(counters, 0, sizeof(int) * (size_t)L * R * Hkv, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
-#endif
     const StepGemms sg = step_gemms(ss_ws, nss, B, H, Nq, Nqkv, F, V, eps, stream);
     if (!(embed_done && sg.v2)) {          // else bra_sample_embed already left x = E[tok] and its RMSNorm statistics
         CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));
@@ -211,8 +203,7 @@ extern "C" int bra_qwen_decode_step_one(const void* layers_host, int L, int R, i
         CK(sg_qkv(sg, l, x, qkv));
         CK(bra_dec_attn_one(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, L > 0 ? ls[0].rope_rows : nullptr, l.kp, (long)Hkv * P * hd,
                             (long)P * hd, (long)hd, l.vtp, (long)Hkv * hd * vt_pitch, (long)hd * vt_pitch, vt_pitch, pmask, l.kc, l.vc, cp,
-                            part_o, part_ml, nslot, counters + (long)li * R * Hkv, err, o, Nq, R, copies, Hq, Hkv, hd, P, C, t, eps,
-                            scale, t_dev, stream));
+                            part_o, part_ml, nslot, o, Nq, R, copies, Hq, Hkv, hd, P, C, t, eps, scale, t_dev, stream));
         CK(sg_tail(sg, l, o, x, h, act));
     }
     if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits));

@@ -205,20 +205,16 @@ class SharedDecodeState:
         self.rw = rollout_weights(model)
         self.kp, self.vtp = cache_r.k, vtp                       # [R,Hkv,P,hd], [R,Hkv,hd,pitch]
         self.kc = [torch.zeros((B, eng.Hkv, C, eng.hd), dtype=BF16, device=dev) for _ in range(eng.L)]
-        # attention of the step: "both" = bra_dec_attn_both + bra_attn_decode_merge (row-layout V cache);  "one" =
-        # bra_dec_attn_one (k_decattn.hip: MFMA for the completion keys too, transposed completion V cache [B, Hkv, hd, cp], the
-        # merge done by tail waves).  Measured on MI355X at cfg-3 (tools/dec_attn_one_probe.py, NOTES.md round 2): "one" is
-        # 15.1-17.2 us per layer as items kernel + tails kernel and 20-29 us as a single launch with waiting tails, against
-        # 13.5-15.8 us for "both" + merge — the hand-off of 2.5 MB of partials costs more inside a launch than across one.
-        self.attn_impl = os.environ.get("BRA_DEC_ATTN", "both")
-        nslot = (P + 63) // 64 + (C + 63) // 64
+        # attention of the step: "one" = bra_dec_attn_one (k_decattn.hip: MFMA for the completion keys too, transposed completion
+        # V cache [B, Hkv, hd, cp], the new key as its own partial);  "both" = bra_dec_attn_both + bra_attn_decode_merge
+        # (first generation: row-layout V cache, completion keys on the VALU)
+        self.attn_impl = os.environ.get("BRA_DEC_ATTN", "one")
+        nslot = (P + 63) // 64 + (C + 63) // 64 + 1
         if self.attn_impl == "one" and nslot > 256:
             self.attn_impl = "both"
         if self.attn_impl == "one":
             self.cp = (C + 63) // 64 * 64
             self.vc = [torch.zeros((B, eng.Hkv, eng.hd, self.cp), dtype=BF16, device=dev) for _ in range(eng.L)]
-            self.counters = torch.zeros((eng.L, R * eng.Hkv), dtype=torch.int32, device=dev)
-            self.err = torch.zeros((1,), dtype=torch.int32, device=dev)
         else:
             self.vc = [torch.zeros((B, eng.Hkv, C, eng.hd), dtype=BF16, device=dev) for _ in range(eng.L)]
         self.vt_pitch = vtp[0].shape[-1]
@@ -246,15 +242,10 @@ class SharedDecodeState:
             return torch.empty((B, n), dtype=BF16, device=dev)
 
         self.x, self.h, self.qkv, self.o, self.act = buf(eng.H), buf(eng.H), buf(eng.Nq + 2 * eng.Nkv), buf(eng.Nq), buf(eng.F)
-        nch = (P + 63) // 64 + (C + 63) // 64
+        nch = (P + 63) // 64 + (C + 63) // 64 + 1
         self.part_o = torch.empty((B, eng.Hq, nch, eng.hd), dtype=torch.float32, device=dev)
         self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
         self.cosT, self.sinT = eng.rope(P + C + 1)
-
-    def check(self):
-        """raises if a wait inside bra_dec_attn_one ever ran out (one host sync; called once at the end of a rollout)"""
-        if self.attn_impl == "one" and int(self.err.item()) != 0:
-            raise RuntimeError("bra_dec_attn_one: an arrival wait ran out of its bound; the rollout is not valid")
 
     def step(self, tok, pos, pmask, t: int, logits: torch.Tensor, t_dev=None, embed_done: bool = False):
         e = self.eng
@@ -262,8 +253,7 @@ class SharedDecodeState:
             get_lib().call("bra_qwen_decode_step_one", ctypes.addressof(self.arr), e.L, self.R, self.copies, e.H, e.Hq, e.Hkv,
                            e.hd, e.F, self.P, self.vt_pitch, self.C, self.cp, e.V, e.eps, e.scale, e.E, e.norm_w, self.cosT,
                            self.sinT, tok, pos, pmask, t, t_dev, int(embed_done), self.x, self.qkv, self.o, self.h, self.act,
-                           self.ss_ws, self.nss, self.part_o, self.part_ml, self.part_o.shape[2], self.counters, self.err,
-                           logits, current_stream(self.x))
+                           self.ss_ws, self.nss, self.part_o, self.part_ml, self.part_o.shape[2], logits, current_stream(self.x))
             return
         get_lib().call("bra_qwen_decode_step_shared", ctypes.addressof(self.arr), e.L, self.R, self.copies, e.H, e.Hq, e.Hkv,
                        e.hd, e.F, self.P, self.vt_pitch, self.C, e.V, e.eps, e.scale, e.E, e.norm_w, self.cosT, self.sinT, tok,
@@ -535,8 +525,6 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         graph.reset()            # release the executable graph here, not whenever the cyclic GC finds the closures
         del graph
         _tick("graph_reset")
-    if shared is not None:
-        shared.check()
     out = tokens[:, :n_done]
     if eos >= 0 and not return_full_length and force_tokens is None:
         # HF stops right after the step in which the last row finished: trim the all-pad tail we may have produced

@@ -36,3 +36,25 @@ def synth_prompt_batch(B: int, n_unique: int, Sd: int = 1024, text_len: int = 12
     return {"input_ids": ids.to(device), "attention_mask": torch.ones_like(ids).to(device),
             "dna_tokenized": {"input_ids": dna.to(device), "attention_mask": torch.ones_like(dna).to(device)},
             "batch_idx_map": bmap, "dna_alias": alias, "prompt_alias": [(b // rep) * rep for b in range(B)]}
+
+
+class SyntheticTokenizer:
+    """Stand-in for the Qwen3 tokenizer in benchmarks (no tokenizer files exist offline): a fixed id -> text-piece table,
+    so that the reward hop of the reference — completion ids to the host, `batch_decode(..., skip_special_tokens=True)`,
+    python / regex reward functions over the decoded text, rewards back to the device (grpo_trainer.py:642-676) — runs
+    for real inside the timed step.  Pieces are drawn from the strings the reward regexes look for (reason.py:193-245)
+    and ordinary words, so every reward function does work on every completion."""
+    PIECES = ["<think>", "</think>", "<answer>", "</answer>", "\n", " ", "the", " gene", " variant", " pathway", " therefore",
+              " 1", " 2", " 3", " disease", " protein", ".", ",", " is", " of", " in", " A", " C", " G", " T", " KEGG"]
+
+    def __init__(self, vocab_size: int = 151936, pad_token_id: int = 151643, eos_token_id: int = 151645):
+        self.vocab_size, self.pad_token_id, self.eos_token_id = vocab_size, pad_token_id, eos_token_id
+        self.special = {pad_token_id, eos_token_id}
+        n = len(self.PIECES)
+        self._table = [self.PIECES[(i * 2654435761) % n] for i in range(vocab_size)]
+
+    def batch_decode(self, ids, skip_special_tokens: bool = True):
+        if isinstance(ids, torch.Tensor):
+            ids = ids.tolist()
+        tab, sp = self._table, self.special
+        return ["".join(tab[i] for i in row if not (skip_special_tokens and i in sp)) for row in ids]

@@ -230,27 +230,25 @@ int bra_qwen_decode_step_shared(const void* layers_host, int L, int R, int copie
                                 const void* pmask, int t, const int* t_dev, int embed_done, void* x, void* qkv, void* o, void* h,
                                 void* act, float* ss_ws, int nss, float* part_o, float* part_ml, float* logits, void* stream);
 
-/* bra_dec_attn_both + bra_attn_decode_merge in ONE launch (k_decattn.hip; same operator: Qwen3Attention.forward
- * TF:qwen3:231-284 on one new token per sequence with a KV cache, TF:generation/utils.py:2876-2925).  One-wave items score
- * 64-key chunks of the shared prompt K / V^T and of each sequence's completion cache on MFMA and publish (max, sum, O)
- * partials write-through; one tail wave per (sequence, q-head) appends the new k / v, waits on the arrival counter of its
- * (prompt, kv-head) and merges.  The completion V cache is kept TRANSPOSED: vct [B, Hkv, hd, cp] (cp >= ceil64(C), zeroed
- * by the caller at allocation); kc [B, Hkv, C, hd]; t = completion tokens already cached.  counters int [R * Hkv] must be
- * zero at launch; err int [1] is incremented if a bounded wait runs out (never expected).  o bf16 [B, Hq * hd].
- * nslot = partial slots per (sequence, q-head) >= ceil(P/64) + ceil(C/64), <= 256. */
+/* Shared-prefix decode attention, second generation (k_decattn.hip; same operator as bra_dec_attn_both + bra_attn_decode_merge:
+ * Qwen3Attention.forward TF:qwen3:231-284 on one new token per sequence with a KV cache, TF:generation/utils.py:2876-2925).
+ * Items kernel: one-wave items score 64-key chunks of the shared prompt K / V^T and of each sequence's completion cache on
+ * MFMA (the completion V cache is kept TRANSPOSED: vct [B, Hkv, hd, cp], cp >= ceil64(C), zeroed by the caller at allocation;
+ * kc [B, Hkv, C, hd]; t = completion tokens already cached), one more item per (sequence, q-head) appends the new k / v and
+ * emits the new key's own partial; merge kernel: one wave per (sequence, q-head).  o bf16 [B, Hq * hd].
+ * nslot = partial slots per (sequence, q-head) >= ceil(P/64) + ceil(C/64) + 1, <= 256. */
 int bra_dec_attn_one(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT, const float* sinT,
                      const int* pos, const float* rope_rows, const void* kp, long kp_sr, long kp_sh, long kp_ss,
                      const void* vtp, long vt_sr, long vt_sh, long vt_sd, const void* pmask, void* kc, void* vct, long cp,
-                     float* part_o, float* part_ml, int nslot, int* counters, int* err, void* o, long ldo, int R, int copies,
+                     float* part_o, float* part_ml, int nslot, void* o, long ldo, int R, int copies,
                      int Hq, int Hkv, int hd, int P, int C, int t, float eps, float scale, const int* t_dev, void* stream);
-/* bra_qwen_decode_step_shared on bra_dec_attn_one: 5 launches per layer.  The layer records' vc fields hold the transposed
- * completion V caches; counters int [L, R * Hkv] are zeroed by this call (one memset per token step). */
+/* bra_qwen_decode_step_shared on bra_dec_attn_one.  The layer records' vc fields hold the transposed completion V caches. */
 int bra_qwen_decode_step_one(const void* layers_host, int L, int R, int copies, int H, int Hq, int Hkv, int hd, int F,
                              int P, long vt_pitch, int C, long cp, int V, float eps, float scale, const void* E,
                              const void* norm_w, const float* cosT, const float* sinT, const int* tok, const int* pos,
                              const void* pmask, int t, const int* t_dev, int embed_done, void* x, void* qkv, void* o, void* h,
-                             void* act, float* ss_ws, int nss, float* part_o, float* part_ml, int nslot, int* counters,
-                             int* err, float* logits, void* stream);
+                             void* act, float* ss_ws, int nss, float* part_o, float* part_ml, int nslot, float* logits,
+                             void* stream);
 
 /* ---- data movement around the kernels (k_misc.hip) ---------------------------- */
 int bra_head_transpose(const void* x, long sb, long ss, long sh, void* xt, long t_sb, long t_sh, long pitch, int B,

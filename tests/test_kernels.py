@@ -726,13 +726,10 @@ def _rope_rows_ref(x, cos, sin):
     (128, 2, 2, 1, 5, 70, 192, 130, True),       # G = 1, three completion chunks (the last ragged)
     (64, 8, 2, 2, 4, 129, 128, 77, False),       # hd 64, G = 4
 ])
-@pytest.mark.parametrize("flags", [0, 32, 64])
-def test_dec_attn_one_launch(backend, monkeypatch, hd, Hq, Hkv, R, copies, P, C, t, use_rows, flags):
-    """(flags: 0 = items kernel + tails kernel, 32 = K / V^T through LDS-DMA, 64 = one launch with waiting tails)
-    bra_dec_attn_one: q/k RMSNorm + RoPE, cache append, attention over the shared prompt K / V^T + each sequence's own
+def test_dec_attn_one_launch(backend, hd, Hq, Hkv, R, copies, P, C, t, use_rows):
+    """bra_dec_attn_one (items kernel + merge kernel): q/k RMSNorm + RoPE, cache append, attention over the shared prompt K / V^T + each sequence's own
     completion keys + the new key, merged in the same launch — against plain fp32 torch (TF:qwen3:231-284 on one token)."""
     from bioreason_amd._lib import get_lib, current_stream
-    monkeypatch.setenv("BRA_DEC_ONE_FLAGS", str(flags))
     dev = backend
     B, G = R * copies, Hq // Hkv
     Nq, Nkv = Hq * hd, Hkv * hd
@@ -759,18 +756,13 @@ def test_dec_attn_one_launch(backend, monkeypatch, hd, Hq, Hkv, R, copies, P, C,
     cosT, sinT = ang.cos().to(BF).float().to(dev).contiguous(), ang.sin().to(BF).float().to(dev).contiguous()
     pos = (torch.arange(B, dtype=torch.int32) % 5 + P - 13 + t).to(dev)
     rope_rows = torch.cat([cosT[pos.long()], sinT[pos.long()]], -1).contiguous() if use_rows else None
-    nslot = (P + 63) // 64 + (C + 63) // 64
+    nslot = (P + 63) // 64 + (C + 63) // 64 + 1
     part_o = torch.full((B * Hq, nslot, hd), float("nan"), dtype=torch.float32, device=dev)
     part_ml = torch.full((B * Hq, nslot, 2), float("nan"), dtype=torch.float32, device=dev)
-    counters = torch.zeros(R * Hkv, dtype=torch.int32, device=dev)
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
     o = torch.zeros(B, Nq, dtype=BF, device=dev)
     get_lib().call("bra_dec_attn_one", qkv, Nq + 2 * Nkv, qw, kw, cosT, sinT, pos, rope_rows, kp, Hkv * P * hd, P * hd, hd, vtp,
-                   Hkv * hd * pitch, hd * pitch, pitch, pmask, kc, vct, cp, part_o, part_ml, nslot, counters, err, o, Nq, R, copies,
+                   Hkv * hd * pitch, hd * pitch, pitch, pmask, kc, vct, cp, part_o, part_ml, nslot, o, Nq, R, copies,
                    Hq, Hkv, hd, P, C, t, eps, scale, None, current_stream(qkv))
-    assert int(err.item()) == 0
-    want_arrivals = (P + 63) // 64 + copies * ((t + 63) // 64)
-    assert (counters.cpu() == (want_arrivals if flags & 64 else 0)).all()
     # ---- reference
     f = qkv.float().cpu()
     q = f[:, :Nq].view(B, Hq, hd)

@@ -1,6 +1,6 @@
 """decode attention alone at the cfg-3 shape (1 prompt x 8 rollouts, P = 2180, Hq/Hkv = 16/8, hd 128), 28 layers' worth of
-distinct caches per pass: us per layer of  both + merge  (two launches)  vs  one  (single launch), and the in-kernel stamps
-of the one-launch kernel.  PROBE_T = completion tokens already cached."""
+distinct caches per pass: us per layer of the first generation (bra_dec_attn_both + bra_attn_decode_merge) vs k_decattn.hip
+(bra_dec_attn_one: items kernel + merge kernel).  PROBE_T = completion tokens already cached."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bioreason_amd._lib import get_lib, current_stream
@@ -26,11 +26,9 @@ ang = torch.arange(npos).float()[:, None] * inv[None]
 cosT, sinT = ang.cos().to(dev).contiguous(), ang.sin().to(dev).contiguous()
 pos = torch.full((B,), P + t, dtype=torch.int32, device=dev)
 rope_rows = torch.cat([cosT[pos.long()], sinT[pos.long()]], -1).contiguous()
-nslot = (P + 63) // 64 + (C + 63) // 64
+nslot = (P + 63) // 64 + (C + 63) // 64 + 1
 part_o = torch.zeros(B * Hq, nslot, hd, dtype=torch.float32, device=dev)
 part_ml = torch.zeros(B * Hq, nslot, 2, dtype=torch.float32, device=dev)
-counters = torch.zeros(L, R * Hkv, dtype=torch.int32, device=dev)
-err = torch.zeros(1, dtype=torch.int32, device=dev)
 o = torch.zeros(B, Nq, dtype=BF, device=dev)
 lib = get_lib()
 st = current_stream(qkv)
@@ -46,10 +44,9 @@ def run_both():
 
 
 def run_one():
-    counters.zero_()
     for li in range(L):
         lib.call("bra_dec_attn_one", qkv, Nq + 2 * Nkv, qw, kw, cosT, sinT, pos, rope_rows, kp[li], Hkv * P * hd, P * hd, hd, vtp[li],
-                 Hkv * hd * pitch, hd * pitch, pitch, None, kc[li], vct[li], cp, part_o, part_ml, nslot, counters[li], err, o, Nq, R, copies,
+                 Hkv * hd * pitch, hd * pitch, pitch, None, kc[li], vct[li], cp, part_o, part_ml, nslot, o, Nq, R, copies,
                  Hq, Hkv, hd, P, C, t, eps, scale, None, st)
 
 
@@ -65,19 +62,7 @@ def timeit(fn, reps=20):
     return s.elapsed_time(e) / reps / L * 1e3
 
 
-print("flags", os.environ.get("BRA_DEC_ONE_FLAGS", "0"))
 run_both(); o_both = o.clone()
 run_one(); torch.cuda.synchronize()
-print("max |one - both| = %.4f  (|both| max %.3f)  err=%d" % ((o.float() - o_both.float()).abs().max().item(), o_both.float().abs().max().item(), int(err.item())))
-print("t=%d  both+merge %.2f us/layer   one %.2f us/layer" % (t, timeit(run_both), timeit(run_one)), flush=True)
-probe = torch.zeros(64, dtype=torch.int64, device=dev)
-lib.call("bra_debug_set_probe", probe)
-run_one(); torch.cuda.synchronize()
-lib.call("bra_debug_set_probe", None)
-p = probe.cpu().tolist()
-t0 = p[0]
-names = ["first prompt item", "last completion item", "first tail", "last tail"]
-for i, nm in enumerate(names):
-    w = p[8 * i:8 * i + 8]
-    print(nm + ": " + "  ".join("%.2f" % (0.01 * (x - t0)) if x else "-" for x in w))
-print("item stamps: entry, requests issued, q ready, scores, partial stores issued, drained, counted | tail stamps: entry, prologue, arrivals complete, merge loads issued, merged, end   (us after the first item's entry)")
+print("max |one - both| = %.4f  (|both| max %.3f)" % ((o.float() - o_both.float()).abs().max().item(), o_both.float().abs().max().item()))
+print("t=%d  both+merge %.2f us/layer   items+merge (k_decattn) %.2f us/layer" % (t, timeit(run_both), timeit(run_one)), flush=True)
