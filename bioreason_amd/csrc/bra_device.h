@@ -93,6 +93,37 @@ __device__ __forceinline__ uint32_t lane_swap1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
 }
 #endif
+// rotate within each row of 16 lanes (DPP row_ror: a VALU move); four of them (8, 4, 2, 1) all-reduce an idempotent operator
+// over a row without touching the LDS crossbar
+#ifdef BRA_EMU
+template <int N> __device__ __forceinline__ uint32_t row_ror_u32(uint32_t v) {
+    const uint32_t* b = bra_emu::wave_exchange(&v, 1);
+    const int l = bra_emu::lane_id();
+    return b[((l & ~15) | ((l + N) & 15)) * 16];
+}
+#else
+template <int N> __device__ __forceinline__ uint32_t row_ror_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xF, 0xF, false);
+}
+#endif
+// maximum of a 64-bit key over the 16 lanes of each row / over the wave (every lane receives it)
+__device__ __forceinline__ uint64_t row_max_u64(uint64_t k) {
+#define BRA_ROR_STEP(N)                                                                                        \
+    { const uint64_t o = ((uint64_t)row_ror_u32<N>((uint32_t)(k >> 32)) << 32) | row_ror_u32<N>((uint32_t)k);  \
+      k = o > k ? o : k; }
+    BRA_ROR_STEP(8) BRA_ROR_STEP(4) BRA_ROR_STEP(2) BRA_ROR_STEP(1)
+#undef BRA_ROR_STEP
+    return k;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k) {
+    k = row_max_u64(k);
+#pragma unroll
+    for (int m = 16; m <= 32; m <<= 1) {
+        const uint64_t o = ((uint64_t)wave_shfl_xor_u32((uint32_t)(k >> 32), m) << 32) | wave_shfl_xor_u32((uint32_t)k, m);
+        k = o > k ? o : k;
+    }
+    return k;
+}
 __device__ __forceinline__ float wave_shfl_xor(float v, int m) {
     return __builtin_bit_cast(float, wave_shfl_xor_u32(__builtin_bit_cast(uint32_t, v), m));
 }

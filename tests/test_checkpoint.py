@@ -18,11 +18,10 @@ from test_oracle import rebuild                            # noqa: E402
 
 
 @pytest.fixture
-def emu(emu_lib_path):
-    from bioreason_amd import _lib
-    _lib.use_library_for_tests(emu_lib_path)
-    yield torch.device("cpu")
-    _lib.reset_library()
+def emu(backend):
+    """every test runs twice: on the kernel-source emulator (CPU suite) and on the HIP library (`-m gpu`) — the loaders
+    write into packed device buffers, so the device path is the one that has to round-trip"""
+    return backend
 
 
 def _fix(name="tiny_a"):
