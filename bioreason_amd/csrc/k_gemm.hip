@@ -843,6 +843,7 @@ static int launch_skinny(const GemmArgs& g, int out_f32, bra_stream_t stream) {
 static int g_forced_variant = -1;
 static int ring_min_fill_pct = 75;
 static int ring_two_phase = 1;
+static int ring_row_split = 1;
 
 static int pick_variant(const GemmArgs& g) {
     if (g_forced_variant >= 0) return g_forced_variant >= 6 ? 6 : g_forced_variant;
@@ -915,8 +916,44 @@ static int launch_gemm(const GemmArgs& g, bra_stream_t stream) {
     }
 }
 
+// Tile-count quantisation of the 256 x 256 ring kernel: t tiles on 256 CUs take ceil(t / 256) rounds, and the N = 2048
+// projections of the path (o, down and three of the four input-gradient GEMMs: 54 % of the step's GEMM FLOPs) have
+// t = 77 x 8 = 616 = 2.41 rounds — the third round runs 104 tiles on 104 CUs.  When the last round is less than half full the
+// rows are split: the ring kernel takes the tile-rows that fill whole rounds, the remaining rows go to the 256 x 128 LDS-DMA
+// kernel, whose half-size tiles cover them in about 0.55 of a round (616 tiles: 2.55 rounds instead of 3).
+// Returns the rows of the ring part, or 0 (no split).  Rows are independent in every epilogue this is applied to.
+static int ring_split_rows(const GemmArgs& g) {
+    if (g_forced_variant >= 0 || !ring_row_split || g.K % 64 || g.K2 % 64 || g.split_k > 1) return 0;
+    if (pick_variant(g) != 6) return 0;
+    const long tm = (g.M + 255) / 256, tn = (g.N + 255) / 256, t = tm * tn;
+    const long R = t / 256, rem = t - R * 256;
+    if (R < 1 || rem == 0 || 2 * rem >= 256) return 0;
+    const long rm = (R * 256) / tn;                                  // tile-rows that fit into R whole rounds
+    if (rm <= 0 || rm >= tm) return 0;
+    const long rows2 = g.M - rm * 256;
+    const long halves = ((rows2 + 255) / 256) * ((g.N + 127) / 128);
+    if (halves < 128) return 0;                                      // the 256 x 128 kernel wants its share of the chip
+    const double cost_split = (double)R + 0.55 * (double)((halves + 255) / 256);
+    return cost_split < (double)(R + 1) - 0.15 ? (int)(rm * 256) : 0;
+}
+
 template <int EPI>
 static int dispatch_bk(const GemmArgs& g, bra_stream_t stream) {
+    if (EPI == EPI_BF16 || EPI == EPI_F32) {
+        const int m1 = ring_split_rows(g);
+        if (m1 > 0) {
+            GemmArgs g1 = g, g2 = g;
+            g1.M = m1;
+            g2.M = g.M - m1;
+            g2.A = g.A + (long)m1 * g.lda;
+            if (g.A2) g2.A2 = g.A2 + (long)m1 * g.lda2;
+            g2.C = EPI == EPI_F32 ? (void*)((float*)g.C + (long)m1 * g.ldc) : (void*)((bf16_t*)g.C + (long)m1 * g.ldc);
+            if (g.res) g2.res = g.res + (long)m1 * g.ldres;
+            const int e = launch_ring<EPI>(g1, stream);
+            if (e) return e;
+            return launch_glds<EPI>(g2, stream);
+        }
+    }
     if (g.K % 64 == 0 && g.K2 % 64 == 0) return launch_gemm<64, EPI>(g, stream);
     return launch_gemm<32, EPI>(g, stream);
 }
@@ -941,6 +978,7 @@ extern "C" int bra_gemm_set_variant(int v) {
     return 0;
 }
 extern "C" int bra_gemm_set_ring_fill(int pct) { bra::ring_min_fill_pct = pct; return 0; }
+extern "C" int bra_gemm_set_row_split(int on) { bra::ring_row_split = on; return 0; }
 
 extern "C" int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2,
                                 const void* B2, long ldb2, int K2, void* C, long ldc, int M, int N, int K,

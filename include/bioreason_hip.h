@@ -48,6 +48,9 @@ int bra_gemm_set_variant(int v);
 /* minimum fill (percent of 256 CUs busy, averaged over the rounds of 256 x 256 tiles) at which the per-shape choice takes the
  * ring kernel (default 75) */
 int bra_gemm_set_ring_fill(int pct);
+/* row split of the per-shape choice (default on): when the last round of 256 x 256 tiles would be less than half full, the
+ * tile-rows that fill whole rounds go to the ring kernel and the remaining rows to the 256 x 128 kernel (two launches) */
+int bra_gemm_set_row_split(int on);
 
 /* C[M,N] (f32, pre-zeroed or holding a running gradient) += alpha * A[M,K] B[N,K]^T with the K range cut
  * into `split_k` slices and combined by atomics: weight gradients of LoRA A/B and dna_projection, where

@@ -819,3 +819,25 @@ def test_lora_dropout_padded_rank_blocks(backend, R, nlive):
     for j in range(nlive):
         want_dA[32 * j:32 * j + 32] = dts.float().cpu()[:, 32 * j:32 * j + 32].T @ xd[j]
     assert rel(dA, want_dA) < 1e-5 and (dA[32 * nlive:] == 0).all()
+
+
+@pytest.mark.gpu
+def test_gemm_ring_row_split_is_exact(hip_device):
+    """k_gemm.hip ring_split_rows: at N = 2048 the 19488-row projections are 616 ring tiles = 2.41 rounds, so the rows are split
+    between the ring kernel (whole rounds) and the 256 x 128 kernel (the rest).  Same K order per output element in both
+    kernels: the result must be bit-identical to the unsplit launch, residual included."""
+    from bioreason_amd._lib import get_lib
+    M, N, K, K2 = 8 * 2436, 2048, 2048, 64
+    a, b = rnd(M, K, dev=hip_device, seed=1), rnd(N, K, dev=hip_device, seed=2)
+    a2, b2 = rnd(M, K2, dev=hip_device, seed=3), rnd(N, K2, dev=hip_device, seed=4)
+    res = rnd(M, N, dev=hip_device, seed=5)
+    try:
+        get_lib().call("bra_gemm_set_row_split", 0)
+        c0 = ops.gemm_nt(a, b, a2=a2, b2=b2, res=res)
+        get_lib().call("bra_gemm_set_row_split", 1)
+        c1 = ops.gemm_nt(a, b, a2=a2, b2=b2, res=res)
+    finally:
+        get_lib().call("bra_gemm_set_row_split", 1)
+    assert torch.equal(c0, c1)
+    ref = (a[-300:].float() @ b.float().T + a2[-300:].float() @ b2.float().T + res[-300:].float())
+    assert rel(c1[-300:], ref) < 4e-3
