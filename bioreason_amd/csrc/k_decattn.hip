@@ -259,15 +259,22 @@ __device__ __forceinline__ void one_newkey(const DecOneArgs& a, const int b, con
 
 template <int HD, int G>
 __global__ __launch_bounds__(64) void dec_attn_items_kernel(DecOneArgs a) {
-    const int w = (int)blockIdx.x;
+    // dispatch order = workgroup id: the new-key items go first (their q / k / v -> norm -> rotate -> dot chain is the longest
+    // dependent chain of the launch), then the prompt chunks, then the completion chunks
+    int w = (int)blockIdx.x;
     const int t = a.t_ptr ? a.t_ptr[0] : a.t;
+    const int nK = a.R * a.copies * a.Hq;
     const int nP = a.npc * a.Hkv * a.R;
-    const int nC = a.ncc_grid * a.copies * a.Hkv * a.R;
+    if (w < nK) {
+        one_newkey<HD, G>(a, w / a.Hq, w % a.Hq, t);
+        return;
+    }
+    w -= nK;
     if (w < nP) {
         const int c = w % a.npc, hkv = (w / a.npc) % a.Hkv, r = w / (a.npc * a.Hkv);
         one_item<HD, G>(a, a.kp + r * a.kp_sr + hkv * a.kp_sh, a.kp_ss, a.vtp + r * a.vt_sr + hkv * a.vt_sh, a.vt_sd, c * 64, a.P,
                         a.pmask ? a.pmask + (long)r * a.P : nullptr, r, hkv, 0, 16, c);
-    } else if (w < nP + nC) {
+    } else {
         const int v = w - nP;
         const int c = v % a.ncc_grid, copy = (v / a.ncc_grid) % a.copies, hkv = (v / (a.ncc_grid * a.copies)) % a.Hkv;
         const int r = v / (a.ncc_grid * a.copies * a.Hkv);
@@ -275,9 +282,6 @@ __global__ __launch_bounds__(64) void dec_attn_items_kernel(DecOneArgs a) {
         const int b = r * a.copies + copy;
         one_item<HD, G>(a, a.kc + ((long)b * a.Hkv + hkv) * a.C * HD, HD, a.vct + ((long)b * a.Hkv + hkv) * HD * a.cp, a.cp, c * 64, t,
                         nullptr, r, hkv, copy * G, copy * G + G, a.npc + c);
-    } else {
-        const int v = w - nP - nC;
-        one_newkey<HD, G>(a, v / a.Hq, v % a.Hq, t);
     }
 }
 
