@@ -10,6 +10,7 @@
 #include "bra_emu.h"
 #else
 #include <hip/hip_runtime.h>
+#include <atomic>
 #endif
 
 namespace bra {
@@ -374,14 +375,21 @@ typedef hipStream_t bra_stream_t;
 #define BRA_LAUNCH(kern, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kern, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
 #define BRA_LAUNCH_STATUS() ((int)hipGetLastError())
-// dynamic LDS above 64 KiB must be opted into once per kernel (gfx950 has 160 KiB per CU)
+// dynamic LDS above 64 KiB must be opted into once per kernel AND device (gfx950 has 160 KiB per CU): the attribute lives in
+// the device's copy of the code object, so a process that drives several GPUs sets it on each; the flags are atomics because
+// torch may call the library from more than one thread (autograd worker, RCCL watchdog)
 #define BRA_ALLOW_SMEM(kern, bytes)                                                                       \
     do {                                                                                                  \
-        static bool done_ = false;                                                                        \
-        if (!done_ && (bytes) > 65536) {                                                                  \
-            (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                      (int)(bytes));                                                      \
-            done_ = true;                                                                                 \
+        static std::atomic<unsigned> done_{0u};                     /* bit d = set on device d (d < 32) */   \
+        if ((bytes) > 65536) {                                                                            \
+            int dev_ = 0;                                                                                 \
+            (void)hipGetDevice(&dev_);                                                                    \
+            const unsigned bit_ = 1u << (dev_ & 31);                                                      \
+            if (!(done_.load(std::memory_order_relaxed) & bit_)) {                                        \
+                (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)(bytes));                                                  \
+                done_.fetch_or(bit_, std::memory_order_relaxed);                                          \
+            }                                                                                             \
         }                                                                                                 \
     } while (0)
 #endif

@@ -40,7 +40,6 @@ for name, K, N, R, nt in (("qkv", 2048, 4096, 128, 3), ("o", 2048, 2048, 64, 1),
     r["wgrad_dA_drop"] = timeit(lambda: ops.wgrad_tn(x, dts, dA, transposed_out=True, drop=(0.05, seeds)))
     r["wgrad_dA_nodrop"] = timeit(lambda: ops.wgrad_tn(x, dts, dA, transposed_out=True))
     r["wgrad_dB"] = timeit(lambda: ops.wgrad_tn(dy, t, dB))
-    for mc in (320, 160):
-        r[f"dA_drop_mc{mc}"] = timeit(lambda: ops.wgrad_tn(x, dts, dA, transposed_out=True, drop=(0.05, seeds), m_chunk=mc))
-    r["dB_mc320"] = timeit(lambda: ops.wgrad_tn(dy, t, dB, m_chunk=320))
-    print(f"{name:8s} K={K} N={N} R={R}: " + "  ".join(f"{k} {v:.0f}us ({(mb_dy if 'dB' in k else mb_x) / v:.2f} TB/s)" for k, v in r.items()), flush=True)
+    BT = rn(R, N)
+    r["dts_gemm(dy*B)"] = timeit(lambda: ops.gemm_nt(dy, BT, alpha=2.0))
+    print(f"{name:8s} K={K} N={N} R={R}: " + "  ".join(f"{k} {v:.0f}us ({(mb_dy if ('dB' in k or 'dts' in k) else mb_x) / v:.2f} TB/s)" for k, v in r.items()), flush=True)
