@@ -328,7 +328,10 @@ def main():
         from bioreason_amd.synth import SyntheticTokenizer
         reward_names = ["xmlcount", "soft_format", "strict_format", "less_than_4", "correctness"]
         runner = GRPOStepRunner(model, cfg, reward_fn=text_reward_fn(SyntheticTokenizer(model.text_model.engine.V), reward_names,
-                                                                     prompts=[None] * B, answer=["adenocarcinoma"] * B))
+                                                                     prompts=[None] * B,
+                                                                     # (the reference zips the rewards with the CHARACTERS of answer[0],
+                                                                     # reason.py:193-199: the string must have >= B of them)
+                                                                     answer=[("adenocarcinoma " * ((B + 14) // 15 + 1))[:max(B, 15)]] * B))
         batch = synth_prompt_batch(B=B, n_unique=R, Sd=SD, text_len=TEXT_LEN, n_dna=NDNA, dna_token_id=model.dna_token_id,
                                    device=dev, seed=42 + rank)
         if args.eos_uniform:

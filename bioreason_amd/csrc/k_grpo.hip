@@ -40,6 +40,9 @@ __device__ __forceinline__ float unord_f32(uint32_t o) {
 }
 __device__ __forceinline__ uint64_t cand_key(float v, int idx) { return ((uint64_t)ord_f32(v) << 32) | (uint32_t)(0x7fffffff - idx); }
 
+// EPT = candidates per thread: a slice holds at most 256 * EPT elements (10 covers Qwen3's 151 936-entry vocabulary; every
+// round of the extraction rescans a winner lane's EPT registers, so the count is kept as small as the vocabulary allows)
+template <int EPT>
 __global__ __launch_bounds__(256) void topk_slices_kernel(const float* logits, long ldl, int V, int k, float* cand_v,
                                                           int* cand_i) {
     __shared__ uint64_t lists[16][64];            // [lane-row of the workgroup][rank]
@@ -47,7 +50,6 @@ __global__ __launch_bounds__(256) void topk_slices_kernel(const float* logits, l
     const int per = (V + kSlices - 1) / kSlices;
     const int lo = sl * per, hi = (lo + per) < V ? (lo + per) : V;
     const float* lr = logits + (long)row * ldl;
-    constexpr int EPT = 16;                       // slice <= 4096 elements
     uint64_t key[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -388,7 +390,8 @@ extern "C" int bra_sample_embed(const float* logits, long ldl, int B, int V, flo
     const int k = do_sample ? (top_k > 0 ? (top_k < 64 ? top_k : 64) : 64) : 1;
     float* cv = (float*)ws;
     int* ci = (int*)ws + (long)B * kSlices * k;
-    BRA_LAUNCH(topk_slices_kernel, dim3(kSlices, B), dim3(256), 0, stream, logits, ldl, V, k, cv, ci);
+    if ((V + kSlices - 1) / kSlices <= 2560) BRA_LAUNCH(topk_slices_kernel<10>, dim3(kSlices, B), dim3(256), 0, stream, logits, ldl, V, k, cv, ci);
+    else BRA_LAUNCH(topk_slices_kernel<16>, dim3(kSlices, B), dim3(256), 0, stream, logits, ldl, V, k, cv, ci);
     int r = BRA_LAUNCH_STATUS();
     if (r) return r;
     BRA_LAUNCH(sample_merge_kernel, dim3(B), dim3(64), (size_t)kSlices * k * 8, stream, (const float*)cv, (const int*)ci, k,

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 out=$R/gpurun_out/evidence_$tag; mkdir -p $out
 cd $R
 timeout 200 python bench.py --mode sft --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/${tag}_bench_sft.json
-timeout 200 python bench.py --eos-uniform 64 256 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/${tag}_bench_strag.json
+timeout 200 python bench.py --eos-uniform 64 256 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $out/${tag}_bench_strag.json
 timeout 250 python bench.py --prompts-per-gpu 2 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/${tag}_bench_ppg2.json
 for f in sft strag ppg2; do python - <<PY
 import json
