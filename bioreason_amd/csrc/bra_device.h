@@ -310,48 +310,6 @@ __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cas
 __device__ __forceinline__ u32x2 ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
 __device__ __forceinline__ void st8(void* p, const u32x2& v) { *reinterpret_cast<u32x2*>(p) = v; }
 
-// ---- hand-off between workgroups INSIDE one launch (per-XCD L2s are not coherent with each other, a CU's L1 is never
-// refreshed by other CUs' stores): the producer stores its payload WRITE-THROUGH (sc1), drains its stores, then ONE lane
-// adds to an agent-scope arrival counter; the consumer polls the counter relaxed and reads the payload with sc1 loads
-// (L1 bypassed, line fetched from the memory side).  wt_* = 16-byte sc1 accesses through a buffer descriptor built from
-// wave-uniform values; agent_* = 4 / 8-byte relaxed agent-scope accesses.
-#ifdef BRA_EMU
-struct wt_buf { char* p; };
-__device__ __forceinline__ wt_buf wt_make(const void* p, unsigned) { return wt_buf{(char*)p}; }
-__device__ __forceinline__ void wt_st16(const wt_buf& b, unsigned off, const u32x4& v) { memcpy(b.p + off, &v, 16); }
-__device__ __forceinline__ u32x4 wt_ld16(const wt_buf& b, unsigned off) { u32x4 v; memcpy(&v, b.p + off, 16); return v; }
-__device__ __forceinline__ void agent_st8(void* p, uint64_t v) { __atomic_store_n((uint64_t*)p, v, __ATOMIC_RELAXED); }
-__device__ __forceinline__ uint64_t agent_ld8(const void* p) { return __atomic_load_n((const uint64_t*)p, __ATOMIC_RELAXED); }
-__device__ __forceinline__ int agent_ld4(const int* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
-__device__ __forceinline__ void agent_add(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
-__device__ __forceinline__ void drain_stores() {}
-__device__ __forceinline__ void short_sleep() { bra_emu::host_pause(); }           // the producers run on other host threads
-__device__ __forceinline__ void wave_converge() { bra_emu::wave_sync(); }   // lanes are fibers here: line them up like a lock-step wave
-__device__ __forceinline__ void mem_fence_compiler() {}
-#else
-typedef __amdgpu_buffer_rsrc_t wt_buf;
-__device__ __forceinline__ wt_buf wt_make(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ void wt_st16(const wt_buf& b, unsigned off, const u32x4& v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, b, off, 0, 16);                 // aux 16 = sc1
-}
-__device__ __forceinline__ u32x4 wt_ld16(const wt_buf& b, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(b, off, 0, 16); }
-__device__ __forceinline__ void agent_st8(void* p, uint64_t v) {
-    __hip_atomic_store((unsigned long long*)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint64_t agent_ld8(const void* p) {
-    return __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int agent_ld4(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void agent_add(int* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// inline asm: the compiler drops a builtin wait whenever its own scoreboard believes nothing is outstanding
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void short_sleep() { __builtin_amdgcn_s_sleep(1); }
-__device__ __forceinline__ void wave_converge() {}
-__device__ __forceinline__ void mem_fence_compiler() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#endif
-
 // XCD-aware bijective remap of a linear workgroup id (8 XCDs; block b runs on
 // XCD b % 8): consecutive remapped ids share an XCD and therefore an L2.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {

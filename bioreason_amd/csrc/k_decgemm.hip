@@ -1,5 +1,5 @@
 // k_decgemm.hip — weight-streaming projections of the single-token decode step, second generation.
-// Arithmetic: y[M<=8, N] = rmsnorm(x; w, eps) W^T (+ res) | SwiGLU | fp32 logits — Qwen3DecoderLayer.forward with a
+// Arithmetic: y[M<=16, N] = rmsnorm(x; w, eps) W^T (+ res) | SwiGLU | fp32 logits — Qwen3DecoderLayer.forward with a
 // KV cache (TF:qwen3:294-323), Qwen3RMSNorm (TF:qwen3:59-64), Qwen3MLP (TF:qwen3:81-83), tied lm_head (TF:qwen3:495).
 //
 // At M = 8 rows a projection is pure HBM streaming of its weight matrix (8.4 - 50 MB per launch), and a launch lasts
@@ -20,12 +20,12 @@ namespace bra {
 
 struct DecGemm2Args {
     const bf16_t* x; long ldx;          // [M, K]
-    const float* ss_in; int nss_in;     // NORM: partial sums of squares of the rows of x, [8][nss_in]
+    const float* ss_in; int nss_in;     // NORM: partial sums of squares of the rows of x, [8][nss_in] ([16][nss_in] for M > 8)
     const bf16_t* nw; float eps;        // NORM: RMSNorm weight [K]
     const bf16_t* W; long ldw;          // [N, K]
     const bf16_t* res; long ldres;      // [M, N] or null
     void* out; long ldo;                // bf16 [M, N] | bf16 [M, N/2] (ACT) | f32 [M, N]
-    float* ss_out; int nss_out;         // partial sums of squares of the bf16 outputs, [8][nss_out], column = workgroup
+    float* ss_out; int nss_out;         // partial sums of squares of the bf16 outputs, [8 | 16][nss_out], column = workgroup
     int M, N, K;
     int packed;                         // W is in fragment order (bra_dec_pack_weights): [tile][k-step][lane][8]
     unsigned long long* probe;          // optional timing probe (tools/dec_overhead_probe.py): 8 stamps per probed workgroup
@@ -100,7 +100,7 @@ __device__ __forceinline__ void dg2_epilogue(const DecGemm2Args& g, float (&v)[4
         if (!live) ss = 0.f;
         ss += wave_shfl_xor(ss, 16);
         ss += wave_shfl_xor(ss, 32);
-        if (fq == 0 && fr < 8 && m < g.M) g.ss_out[(long)m * g.nss_out + tile] = ss;
+        if (fq == 0 && (!MODE || fr < 8) && m < g.M) g.ss_out[(long)m * g.nss_out + tile] = ss;
     }
 }
 
@@ -108,8 +108,10 @@ __device__ __forceinline__ void dg2_epilogue(const DecGemm2Args& g, float (&v)[4
 // A workgroup walks the tiles blockIdx.x, + gridDim.x, ..: its waves split K, keep their (normalised) activation
 // fragments in registers for all tiles, request tile i+1's weights before multiplying tile i, and hand the K-reduction
 // and epilogue of tile i to wave i % NW through a double-buffered LDS slab (one barrier per tile).
-template <int MODE, int NORM, int ACT, int OUTF32, int NW, int NL>
+// WIDE: 9 .. 16 batch rows (two prompts x 8 rollouts per GPU): MODE 0 only (the diagonal tiles hold 8 rows), folded norm or none
+template <int MODE, int NORM, int ACT, int OUTF32, int NW, int NL, int WIDE = 0>
 __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
+    static_assert(!WIDE || (MODE == 0 && NORM != 1), "wide rows: 16-column tiles, statistics applied in the epilogue");
     __shared__ float red[2][NW][64][4];
     constexpr int KS = MODE ? 64 : 32;
     constexpr int NCOL = MODE ? 8 : 16;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
     // NORM == 1 are 3x the weight bytes); wave 0 alone folds the statistics, behind its weight requests, into LDS.
     const int per = NORM ? g.nss_in >> 3 : 0;
     f32x4 pv[8];
-    __shared__ float rs_lds[8];
+    __shared__ float rs_lds[WIDE ? 16 : 8];
     if (NORM == 1) {
         const float* pp = g.ss_in + (long)(lane >> 3) * g.nss_in + (lane & 7) * per;
 #pragma unroll
@@ -184,15 +186,19 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
         sched_fence();                    // every request above is in flight before the first dependent instruction
         dg2_stamp(g, 1);
         if (NORM == 2 && wave == 0) {
-            const float* pp = g.ss_in + (long)(lane >> 3) * g.nss_in + (lane & 7) * per;
-            float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(pp + (4 * i < per ? 4 * i : 0));
-                s += 4 * i < per ? (q[0] + q[1]) + (q[2] + q[3]) : 0.f;
+            for (int pass = 0; pass < (WIDE ? 2 : 1); ++pass) {
+                const int srow = (lane >> 3) + 8 * pass;                                    // (rows past M fold row M - 1 again)
+                const float* pp = g.ss_in + (long)(srow < g.M ? srow : g.M - 1) * g.nss_in + (lane & 7) * per;
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(pp + (4 * i < per ? 4 * i : 0));
+                    s += 4 * i < per ? (q[0] + q[1]) + (q[2] + q[3]) : 0.f;
+                }
+                s += wave_shfl_xor(s, 1); s += wave_shfl_xor(s, 2); s += wave_shfl_xor(s, 4);
+                if ((lane & 7) == 0) rs_lds[srow] = rsqrtf(s / (float)g.K + g.eps);       // visible after the tile barrier
             }
-            s += wave_shfl_xor(s, 1); s += wave_shfl_xor(s, 2); s += wave_shfl_xor(s, 4);
-            if ((lane & 7) == 0) rs_lds[lane >> 3] = rsqrtf(s / (float)g.K + g.eps);       // visible after the tile barrier
         }
         if (NORM == 1) {
 #pragma unroll
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
     }
 }
 
-// sums of squares of the rows of x [M <= 8, K] (after the embedding gather): ss[r][0] = sum, ss[r][1 .. nss) = 0
+// sums of squares of the rows of x [M <= 16, K] (after the embedding gather): ss[r][0] = sum, ss[r][1 .. nss) = 0
 __global__ __launch_bounds__(256) void row_sumsq_kernel(const bf16_t* x, long ldx, int K, float* ss, int nss) {
     __shared__ float part[4];
     const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
@@ -364,19 +370,25 @@ __global__ __launch_bounds__(256) void dec_pack_kernel(const bf16_t* W, long ldw
     st16(out + c * 8, v);
 }
 
-template <int MODE, int NORM, int ACT, int OUTF32>
+template <int MODE, int NORM, int ACT, int OUTF32, int WIDE = 0>
 static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     constexpr int KS = MODE ? 64 : 32;
     const int nsteps = g.K / KS;
-    const int nw = nsteps >= 64 ? 8 : 4;
+    // (wide rows stream K = 6144 of down_proj in 32-deep steps — the 8-row form takes it in 64-deep diagonal steps — so that
+    //  projection runs 16 waves to keep the single register round)
+    const int nw = (WIDE && nsteps >= 128) ? 16 : (nsteps >= 64 ? 8 : 4);
     const int spw = (nsteps + nw - 1) / nw;
     const int nl = (spw >= 12 && spw % 12 == 0) ? 12 : (spw > 4 ? 8 : 4);
     if (NORM == 2 && (nsteps + nw * nl - 1) / (nw * nl) != 1) return BRA_ERR_UNSUPPORTED;     // folded norm: single-round path only
     const int ntiles = MODE ? g.N / 8 : (g.N + 15) / 16;
-    const int gmax = nw == 8 ? 256 : 512;           // one workgroup of 8 waves (two of 4) per CU, looping over the tiles
+    const int gmax = nw >= 8 ? 256 : 512;           // one workgroup of 8 / 16 waves (two of 4) per CU, looping over the tiles
     const dim3 grid(ntiles < gmax ? ntiles : gmax);
-#define BRA_DG2(NW_, NL_) BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_>), grid, dim3(NW_ * 64), 0, st, g)
-    if (nw == 8) { if (nl == 12) BRA_DG2(8, 12); else if (nl == 8) BRA_DG2(8, 8); else BRA_DG2(8, 4); }
+    if (WIDE && (nsteps + nw * nl - 1) / (nw * nl) != 1) return BRA_ERR_UNSUPPORTED;          // wide rows: single-round path only
+#define BRA_DG2(NW_, NL_) BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE>), grid, dim3(NW_ * 64), 0, st, g)
+    if (nw == 16) {
+        if constexpr (WIDE != 0) { if (nl == 12) BRA_DG2(16, 12); else if (nl == 8) BRA_DG2(16, 8); else BRA_DG2(16, 4); }
+    }
+    else if (nw == 8) { if (nl == 12) BRA_DG2(8, 12); else if (nl == 8) BRA_DG2(8, 8); else BRA_DG2(8, 4); }
     else { if (nl == 12) BRA_DG2(4, 12); else if (nl == 8) BRA_DG2(4, 8); else BRA_DG2(4, 4); }
 #undef BRA_DG2
     return BRA_LAUNCH_STATUS();
@@ -400,18 +412,31 @@ extern "C" int bra_dec_gemm2(const void* x, long ldx, const float* ss_in, int ns
 extern "C" int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
                                    const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
                                    int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* probe, void* stream) {
-    if (M <= 0 || M > 8 || N <= 0 || K <= 0 || K % 32 || ldx % 8 || ldw % 8 || !x || !W || !out) return BRA_ERR_ARG;
+    if (M <= 0 || M > 16 || N <= 0 || K <= 0 || K % 32 || ldx % 8 || ldw % 8 || !x || !W || !out) return BRA_ERR_ARG;
     if (act && (N % 16 || out_f32 || res || ss_out)) return BRA_ERR_ARG;
     if (out_f32 && (res || ss_out)) return BRA_ERR_ARG;
     if (norm_w && (!ss_in || nss_in < 32 || nss_in % 32 || nss_in > 256)) return BRA_ERR_ARG;
     if (res && ldres % 4) return BRA_ERR_ARG;
-    const bool diag = !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256;
+    const bool wide = M > 8;                     // 9 .. 16 rows: 16-column tiles everywhere (a diagonal tile holds 8 rows)
+    const bool diag = !wide && !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256;
     if (ss_out && nss_out < (diag ? N / 8 : (N + 15) / 16)) return BRA_ERR_ARG;
     DecGemm2Args g = {(const bf16_t*)x, ldx, ss_in, nss_in, (const bf16_t*)norm_w, eps, (const bf16_t*)W, ldw,
                       (const bf16_t*)res, ldres, out, ldo, ss_out, nss_out, M, N, K, packed, (unsigned long long*)probe};
     if (packed && (N % (diag ? 8 : 16) || K % (diag ? 64 : 32))) return BRA_ERR_ARG;
     bra_stream_t st = (bra_stream_t)stream;
     if ((packed & 2) && !(packed & 1)) return BRA_ERR_ARG;
+    if (wide) {
+        // statistics only in the folded form (rstd in the epilogue); the weights must be packed for 16-column tiles
+        if (norm_w && !(packed & 2)) return BRA_ERR_UNSUPPORTED;
+        if (norm_w) {
+            if (act) return launch_dg2<0, 2, 1, 0, 1>(g, st);
+            if (out_f32) return launch_dg2<0, 2, 0, 1, 1>(g, st);
+            return launch_dg2<0, 2, 0, 0, 1>(g, st);
+        }
+        if (act) return launch_dg2<0, 0, 1, 0, 1>(g, st);
+        if (out_f32) return launch_dg2<0, 0, 0, 1, 1>(g, st);
+        return launch_dg2<0, 0, 0, 0, 1>(g, st);
+    }
     if (norm_w && (packed & 2)) {            // RMSNorm weight folded into the packed weights, rstd applied in the epilogue
         if (act) return launch_dg2<0, 2, 1, 0>(g, st);
         if (out_f32) return launch_dg2<0, 2, 0, 1>(g, st);
@@ -427,10 +452,18 @@ extern "C" int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, 
     return diag ? launch_dg2<1, 0, 0, 0>(g, st) : launch_dg2<0, 0, 0, 0>(g, st);
 }
 
+extern "C" int bra_dec_pack_weights_rows(const void* W, long ldw, int N, int K, int act, int out_f32, const void* norm_w, int rows,
+                                         void* out, void* stream);
 extern "C" int bra_dec_pack_weights(const void* W, long ldw, int N, int K, int act, int out_f32, const void* norm_w, void* out,
                                     void* stream) {
-    if (!W || !out || N <= 0 || K <= 0 || ldw % 8) return BRA_ERR_ARG;
-    const bool diag = !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256;      // bra_dec_gemm2's rule
+    return bra_dec_pack_weights_rows(W, ldw, N, K, act, out_f32, norm_w, 8, out, stream);
+}
+
+// rows = batch rows the copy will be streamed against: more than 8 selects the 16-column tile order for every projection
+extern "C" int bra_dec_pack_weights_rows(const void* W, long ldw, int N, int K, int act, int out_f32, const void* norm_w, int rows,
+                                         void* out, void* stream) {
+    if (!W || !out || N <= 0 || K <= 0 || ldw % 8 || rows <= 0 || rows > 16) return BRA_ERR_ARG;
+    const bool diag = rows <= 8 && !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256;      // bra_dec_gemm2's rule
     if (N % (diag ? 8 : 16) || K % (diag ? 64 : 32)) return BRA_ERR_UNSUPPORTED;
     const long nchunk = (long)N * K / 8;
     const dim3 grid((unsigned)((nchunk + 255) / 256));
@@ -440,7 +473,7 @@ extern "C" int bra_dec_pack_weights(const void* W, long ldw, int N, int K, int a
 }
 
 extern "C" int bra_row_sumsq(const void* x, long ldx, int M, int K, float* ss, int nss, void* stream) {
-    if (M <= 0 || M > 8 || K <= 0 || K % 8 || ldx % 8 || !x || !ss || nss < 1) return BRA_ERR_ARG;
+    if (M <= 0 || M > 16 || K <= 0 || K % 8 || ldx % 8 || !x || !ss || nss < 1) return BRA_ERR_ARG;
     BRA_LAUNCH(row_sumsq_kernel, dim3(M), dim3(256), 0, (bra_stream_t)stream, (const bf16_t*)x, ldx, K, ss, nss);
     return BRA_LAUNCH_STATUS();
 }

@@ -100,7 +100,7 @@ class DecodeState:
 
 
 @torch.no_grad()
-def rollout_weights(model):
+def rollout_weights(model, rows: int = 8):
     """Per-layer weight set of the fused decode step: LoRA merged into the base weight (W + s B A, rounded to bf16 —
     the merge PEFT's merge_and_unload performs, reason.py:428-446) when adapters are enabled, and gate/up rows
     interleaved in blocks of 8 for the SwiGLU epilogue.  Rebuilt when the adapters or base weights changed."""
@@ -108,7 +108,8 @@ def rollout_weights(model):
     arena = model.arena
     pack = os.environ.get("BRA_DEC_PACK", "1") == "1"
     fold = pack and os.environ.get("BRA_DEC_FOLD", "1") == "1"
-    key = (model._packed_sig, model._lora_enabled, pack, fold, None if arena is None or arena.params is None else (arena.step_count, arena.params._version))
+    wide = rows > 8             # 9 .. 16 sequences: every projection is packed for 16-column tiles (ops.dec_pack_weights(rows=16))
+    key = (model._packed_sig, model._lora_enabled, pack, fold, wide, None if arena is None or arena.params is None else (arena.step_count, arena.params._version))
     cached = getattr(eng, "_rollout", None)
     if cached is not None and cached[0] == key:
         return cached[1]
@@ -129,7 +130,8 @@ def rollout_weights(model):
             # (and, `fold`, the RMSNorm weight of the projection's input multiplied in: the kernel then applies rstd to the reduced
             # products and loads no norm weights / statistics ahead of its MFMAs)
             nws = {"Wqkv": L.ln1 if fold else None, "Wgu": L.ln2 if fold else None, "Wo": None, "Wd": None}
-            pk = {nm: ops.dec_pack_weights(rec[nm], act=(nm == "Wgu"), norm_w=nws[nm]) for nm in ("Wqkv", "Wo", "Wgu", "Wd")}
+            pk = {nm: ops.dec_pack_weights(rec[nm], act=(nm == "Wgu"), norm_w=nws[nm], rows=16 if wide else 8)
+                  for nm in ("Wqkv", "Wo", "Wgu", "Wd")}
             if all(v is not None for v in pk.values()):
                 rec.update({nm + "_p": v for nm, v in pk.items()})
                 rec["folded"] = fold
@@ -157,16 +159,16 @@ class FusedDecodeState:
         eng: QwenEngine = model.engine
         dev = eng.device
         self.eng, self.cache, self.B = eng, cache, B
-        self.rw = rollout_weights(model)
-        self.ss_ws, self.nss = _norm_stat_ws(eng, eng.device)
-        use_packed = self.ss_ws is not None and B <= 8 and all("Wqkv_p" in R for R in self.rw)
+        self.rw = rollout_weights(model, rows=B)
+        self.ss_ws, self.nss = _norm_stat_ws(eng, eng.device, rows=B)
+        use_packed = self.ss_ws is not None and _packed_ok(B, self.rw)
         arr = (_LayerDesc * eng.L)()
         for i, (L, R) in enumerate(zip(eng.layers, self.rw)):
             d = arr[i]
             d.ln1, d.ln2, d.qn, d.kn = L.ln1.data_ptr(), L.ln2.data_ptr(), L.qn.data_ptr(), L.kn.data_ptr()
             _set_proj(d, R, use_packed)
             d.kc, d.vc = cache.k[i].data_ptr(), cache.v[i].data_ptr()
-        if use_packed and os.environ.get("BRA_DEC_PACK_HEAD", "1") == "1":
+        if use_packed and (B > 8 or os.environ.get("BRA_DEC_PACK_HEAD", "1") == "1"):      # (above 8 rows only the packed head streams)
             self.head_p, head_folded = packed_head(model)
             if self.head_p is not None:
                 arr[0].head_packed = self.head_p.data_ptr()
@@ -202,7 +204,7 @@ class SharedDecodeState:
         dev = eng.device
         B = R * copies
         self.eng, self.R, self.copies, self.P, self.C, self.B = eng, R, copies, P, C, B
-        self.rw = rollout_weights(model)
+        self.rw = rollout_weights(model, rows=B)
         self.kp, self.vtp = cache_r.k, vtp                       # [R,Hkv,P,hd], [R,Hkv,hd,pitch]
         self.kc = [torch.zeros((B, eng.Hkv, C, eng.hd), dtype=BF16, device=dev) for _ in range(eng.L)]
         # attention of the step: "one" = bra_dec_attn_one (k_decattn.hip: MFMA for the completion keys too, transposed completion
@@ -218,8 +220,8 @@ class SharedDecodeState:
         else:
             self.vc = [torch.zeros((B, eng.Hkv, C, eng.hd), dtype=BF16, device=dev) for _ in range(eng.L)]
         self.vt_pitch = vtp[0].shape[-1]
-        self.ss_ws, self.nss = _norm_stat_ws(eng, dev)
-        use_packed = self.ss_ws is not None and B <= 8 and all("Wqkv_p" in Rw for Rw in self.rw)
+        self.ss_ws, self.nss = _norm_stat_ws(eng, dev, rows=B)
+        use_packed = self.ss_ws is not None and _packed_ok(B, self.rw)
         arr = (_LayerDesc * eng.L)()
         for i, (L, Rw) in enumerate(zip(eng.layers, self.rw)):
             d = arr[i]
@@ -227,7 +229,7 @@ class SharedDecodeState:
             _set_proj(d, Rw, use_packed)
             d.kc, d.vc = self.kc[i].data_ptr(), self.vc[i].data_ptr()
             d.kp, d.vtp = self.kp[i].data_ptr(), self.vtp[i].data_ptr()
-        if use_packed and os.environ.get("BRA_DEC_PACK_HEAD", "1") == "1":
+        if use_packed and (B > 8 or os.environ.get("BRA_DEC_PACK_HEAD", "1") == "1"):
             self.head_p, head_folded = packed_head(model)
             if self.head_p is not None:
                 arr[0].head_packed = self.head_p.data_ptr()
@@ -270,14 +272,21 @@ def _set_proj(d, R, use_packed: bool):
     d.flags = (1 | (2 if R.get("folded") else 0)) if use_packed else 0
 
 
-def _norm_stat_ws(eng, dev):
-    """zeroed workspace [2][8][nss] of RMSNorm partial sums of squares for the bra_dec_gemm2 projections (None, 0: the
+def _packed_ok(B: int, rw) -> bool:
+    """the streaming projections (bra_dec_gemm2) take up to 16 rows; above 8 they need the norm-folded packed weights"""
+    if not all("Wqkv_p" in R for R in rw):
+        return False
+    return B <= 8 or (B <= 16 and all(R.get("folded") for R in rw))
+
+
+def _norm_stat_ws(eng, dev, rows: int = 8):
+    """zeroed workspace [2][8 | 16][nss] of RMSNorm partial sums of squares for the bra_dec_gemm2 projections (None, 0: the
     hidden size has more column workgroups than the 256 partials a consumer folds -> first-generation kernels)"""
     nblk = eng.H // 8 if (eng.H % 8 == 0 and (eng.H + 15) // 16 < 256) else (eng.H + 15) // 16
     nss = (nblk + 31) // 32 * 32
     if nss > 256 or os.environ.get("BRA_DEC_GEMM_V1") == "1":
         return None, 0
-    return torch.zeros((2, 8, nss), dtype=torch.float32, device=dev), nss
+    return torch.zeros((2, 16 if rows > 8 else 8, nss), dtype=torch.float32, device=dev), nss
 
 
 def _uniform_groups(prompt_alias):

@@ -416,8 +416,8 @@ def rope_rows(cosT: torch.Tensor, sinT: torch.Tensor, pos: torch.Tensor, hd: int
 
 
 def row_sumsq(x: torch.Tensor, nss: int = 32) -> torch.Tensor:
-    """partial sums of squares of the rows of x [M<=8, K] in the layout bra_dec_gemm2 consumes: fp32 [8, nss]"""
-    ss = torch.zeros((8, nss), dtype=torch.float32, device=x.device)
+    """partial sums of squares of the rows of x [M<=16, K] in the layout bra_dec_gemm2 consumes: fp32 [8, nss] ([16, nss] for M > 8)"""
+    ss = torch.zeros((16 if x.shape[0] > 8 else 8, nss), dtype=torch.float32, device=x.device)
     get_lib().call("bra_row_sumsq", x, _ld(x), x.shape[0], x.shape[1], ss, nss, current_stream(x))
     return ss
 
@@ -429,19 +429,21 @@ def dec_gemm2(x, W, ss_in=None, norm_w=None, eps=1e-6, res=None, act=False, out_
     N = W.shape[0]
     out = torch.empty((M, N // 2 if act else N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     nss_out = (N // 8 + 32) // 32 * 32
-    ss_out = torch.zeros((8, nss_out), dtype=torch.float32, device=x.device) if want_ss else None
+    ss_out = torch.zeros((16 if M > 8 else 8, nss_out), dtype=torch.float32, device=x.device) if want_ss else None
     get_lib().call("bra_dec_gemm2_probe", x, _ld(x), ss_in, ss_in.shape[1] if ss_in is not None else 0, norm_w, eps, W, _ld(W),
                    res, _ld(res) if res is not None else 0, out, _ld(out), ss_out, nss_out if want_ss else 0, M, N, K,
                    int(act), int(out_f32), int(packed), None, current_stream(x))
     return out, ss_out
 
 
-def dec_pack_weights(W: torch.Tensor, act: bool = False, out_f32: bool = False, norm_w: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+def dec_pack_weights(W: torch.Tensor, act: bool = False, out_f32: bool = False, norm_w: Optional[torch.Tensor] = None,
+                     rows: int = 8) -> Optional[torch.Tensor]:
     """W [N, K] -> fragment-ordered copy for bra_dec_gemm2(packed=1); None when the shape is not a multiple of the tile.
-    norm_w [K]: the input's RMSNorm weight is folded in (stream the copy with packed=3)"""
+    norm_w [K]: the input's RMSNorm weight is folded in (stream the copy with packed=3).  rows: batch rows the copy is streamed
+    against (above 8 every projection uses the 16-column tile order)"""
     N, K = W.shape
     out = torch.empty((N, K), dtype=BF16, device=W.device)
-    rc = get_lib().call_rc("bra_dec_pack_weights", W, _ld(W), N, K, int(act), int(out_f32), norm_w, out, current_stream(W))
+    rc = get_lib().call_rc("bra_dec_pack_weights_rows", W, _ld(W), N, K, int(act), int(out_f32), norm_w, int(rows), out, current_stream(W))
     if rc == -2:
         return None
     if rc != 0:

@@ -196,6 +196,11 @@ int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, int nss_in,
  * norm weights or statistics ahead of the MFMAs (TF:qwen3:59-64 rounds the normalised activation to bf16 instead: the two
  * differ by bf16 rounding placement only; rollout path). */
 int bra_dec_pack_weights(const void* W, long ldw, int N, int K, int act, int out_f32, const void* norm_w, void* out, void* stream);
+/* the same for a given number of batch rows: bra_dec_gemm2 takes up to 16 rows (two prompts x 8 rollouts per GPU); above 8 rows
+ * every projection streams 16-column tiles (the 8-column "diagonal" tiles of the N = hidden projections hold 8 rows), the
+ * RMSNorm must be folded (packed = 3) and the statistics arrays have 16 rows */
+int bra_dec_pack_weights_rows(const void* W, long ldw, int N, int K, int act, int out_f32, const void* norm_w, int rows, void* out,
+                              void* stream);
 int bra_row_sumsq(const void* x, long ldx, int M, int K, float* ss, int nss, void* stream);
 /* `t_dev` / `len_dev` (optional device int): when given, the attention kernels read the current length from it and
  * the host-side `cur_len` / `t` only size the grids (pass the maximum); the launch arguments are then identical for

@@ -8,7 +8,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <atomic>
-#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -164,7 +163,6 @@ const uint32_t* wave_exchange(const uint32_t* mine, int n) {
 
 char* dyn_smem() { return W->smem; }
 
-void host_pause() { std::this_thread::sleep_for(std::chrono::microseconds(100)); }
 
 void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<void()>& body) {
     int T = (int)(block.x * block.y * block.z);

@@ -34,7 +34,6 @@ int wave_live_lanes();
 // until the lane's next exchange.
 const uint32_t* wave_exchange(const uint32_t* mine, int n);   // -> base[lane*16 + i]
 char* dyn_smem();
-void host_pause();                  // a spinning fiber lets the other host threads run (100 us)
 }  // namespace bra_emu
 
 #define threadIdx (bra_emu::t_threadIdx)

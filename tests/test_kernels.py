@@ -841,3 +841,45 @@ def test_gemm_ring_row_split_is_exact(hip_device):
     assert torch.equal(c0, c1)
     ref = (a[-300:].float() @ b.float().T + a2[-300:].float() @ b2.float().T + res[-300:].float())
     assert rel(c1[-300:], ref) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 256, 256), (12, 96, 512), (9, 2048, 2048), (16, 2048, 6144), (16, 4096, 2048)])
+def test_dec_gemm2_wide_rows(backend, M, N, K):
+    """9 .. 16 batch rows (two prompts x 8 rollouts per GPU): 16-column tiles for every projection, weights packed for them
+    (dec_pack_weights(rows=16)), RMSNorm folded into the packed copy with rstd applied in the epilogue, 16-row statistics"""
+    if backend.type == "cpu" and N * K > 3e6:
+        pytest.skip("emulator: large shape covered on the GPU")
+    x, W = rnd(M, K, dev=backend), rnd(N, K, dev=backend, scale=K ** -0.5)
+    res, nw = rnd(M, N, dev=backend), (1 + 0.1 * rnd(K, dev=backend).float()).to(BF)
+    eps = 1e-6
+    xf = x.float()
+    ss = ops.row_sumsq(x, 32)
+    assert ss.shape[0] == 16 and rel(ss[:M, 0], (xf * xf).sum(1)) < 1e-5
+    xn = xf * torch.rsqrt((xf * xf).mean(1, keepdim=True) + eps) * nw.float()
+    # plain projection + residual + output statistics (o_proj / down_proj)
+    Wp = ops.dec_pack_weights(W, rows=16)
+    y, ss_out = ops.dec_gemm2(x, Wp, res=res, want_ss=True, packed=True)
+    want = ((xf @ W.float().T).to(BF).float() + res.float()).to(BF)
+    assert rel(y, want) < 4e-3
+    assert ss_out.shape[0] == 16 and rel(ss_out[:M].sum(1), (y.float() ** 2).sum(1)) < 1e-5
+    # the same against row-major weights (no packing)
+    y_rm, _ = ops.dec_gemm2(x, W, res=res)
+    assert rel(y_rm, want) < 4e-3
+    # folded norm (qkv): y = rstd * (x (W . nw)^T)
+    Wf = ops.dec_pack_weights(W, norm_w=nw, rows=16)
+    yq, _ = ops.dec_gemm2(x, Wf, ss_in=ss, norm_w=nw, packed=3)
+    assert rel(yq, xn @ W.float().T) < 1.5e-2
+    # fp32 logits (lm_head)
+    Wh = ops.dec_pack_weights(W, out_f32=True, norm_w=nw, rows=16)
+    y32, _ = ops.dec_gemm2(x, Wh, ss_in=ss, norm_w=nw, out_f32=True, packed=3)
+    assert rel(y32, xn @ W.float().T) < 1.5e-2
+    # gate / up + SwiGLU
+    if N % 16 == 0:
+        Wa = ops.dec_pack_weights(W, act=True, norm_w=nw, rows=16)
+        a, _ = ops.dec_gemm2(x, Wa, ss_in=ss, norm_w=nw, act=True, packed=3)
+        r3 = (xn @ W.float().T).view(M, N // 16, 2, 8)
+        g, u = r3[:, :, 0].reshape(M, -1), r3[:, :, 1].reshape(M, -1)
+        assert rel(a, torch.nn.functional.silu(g) * u) < 2e-2
+    # unfolded statistics are not available above 8 rows
+    with pytest.raises(RuntimeError):
+        ops.dec_gemm2(x, W, ss_in=ss, norm_w=nw)

@@ -312,6 +312,41 @@ def test_shared_prefix_decode_kernel_matches_per_copy_decode(backend, monkeypatc
     assert (s_u[:, 0] == s_s[:, 0]).all()        # first token comes from the prefill in both
 
 
+def test_decode_with_more_than_eight_sequences(backend):
+    """12 sequences (2 prompts x 6 copies): the streaming projections run their 16-row form (16-column tiles, packed + norm-folded
+    weights, 16-row statistics) under the shared-prefix attention; same choices as the op-by-op decode under teacher forcing"""
+    fix = torch.load(os.path.join(GOLD, "tiny_b.pt"), weights_only=False)
+    cfg = fix["config"]
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    rows = [0] * 6 + [1] * 6
+    ids, mask = b["input_ids"][rows], b["attention_mask"][rows]
+    dna = {k: v[rows] for k, v in b["dna_tokenized"].items()}
+    mm = {"dna_tokenized": dna, "batch_idx_map": list(range(12))}
+    want = fix["fp32_lora"]["greedy_ids"][rows].to(backend)
+    scores = fix["fp32_lora"]["greedy_scores"][rows]
+    kw = dict(max_new_tokens=cfg["gen_tokens"], do_sample=False, eos_token_id=None, force_tokens=want)
+    g_u = m.generate(input_ids=ids, attention_mask=mask, **mm, decode_impl="unfused", **kw)
+    from bioreason_amd import generation
+    made = []
+    orig = generation.SharedDecodeState.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        made.append((self.B, bool(self.arr[0].flags & 1), self.ss_ws.shape[1] if self.ss_ws is not None else 0))
+    generation.SharedDecodeState.__init__ = spy
+    try:
+        g_s = m.generate(input_ids=ids, attention_mask=mask, **mm, prompt_alias=[0] * 6 + [6] * 6, **kw)
+    finally:
+        generation.SharedDecodeState.__init__ = orig
+    assert made == [(12, True, 16)], made                    # the packed projections took the 12 rows
+    diff = (g_u != g_s).nonzero().tolist()
+    for bi, t in diff:
+        a, c = int(g_u[bi, t]), int(g_s[bi, t])
+        assert abs((scores[bi, t, a] - scores[bi, t, c]).item()) < 0.02 * scores[bi, t].abs().max().item() + 0.05
+    assert len(diff) <= 4
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("alias", [None, [0, 0, 2, 2]])
 def test_graph_replayed_rollout_equals_eager_rollout(backend, alias):
