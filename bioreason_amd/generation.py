@@ -430,7 +430,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     # the drawing wave of the sampler also gathers x = E[token] and its RMSNorm statistic for the fused step (not under
     # teacher forcing, where the token fed back is not the sampled one)
     fuse_embed = (dstate is not None and dstate.ss_ws is not None and force_tokens is None and sample_ws is not None
-                  and B <= 8)
+                  and B <= 16)
 
     def sample_():
         if eos_schedule is not None:

@@ -883,3 +883,22 @@ def test_dec_gemm2_wide_rows(backend, M, N, K):
     # unfolded statistics are not available above 8 rows
     with pytest.raises(RuntimeError):
         ops.dec_gemm2(x, W, ss_in=ss, norm_w=nw)
+
+
+def test_sampler_fused_embed_with_twelve_rows(backend):
+    """the sampler's drawing wave gathers x = E[token] and the row statistic for every sequence of a 9 .. 16-row decode
+    (16-row statistics array, as bra_dec_gemm2's 16-row form folds it)"""
+    B, V, H = 12, 4608, 64
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(B, V, generator=g).to(backend)
+    E = rnd(V, H, dev=backend)
+    x = torch.zeros(B, H, dtype=BF, device=backend)
+    ss = torch.full((16, 32), 7.0, device=backend)
+    step = torch.zeros(1, dtype=torch.int32, device=backend)
+    out, out2 = torch.empty(B, dtype=torch.int32, device=backend), torch.empty(B, dtype=torch.int32, device=backend)
+    ops.sample(logits, 1.0, 0, 1.0, False, 0, step, None, 0, out)
+    assert out.tolist() == logits.argmax(-1).tolist()
+    ops.sample(logits, 1.0, 0, 1.0, False, 0, step, None, 0, out2, embed=(E, x, ss))
+    assert out2.tolist() == out.tolist()
+    assert torch.equal(x.cpu(), E[out2.long()].cpu())
+    assert rel(ss[:B, 0], (x.float() ** 2).sum(1)) < 1e-5 and float(ss[:B, 1:].abs().max()) == 0 and float(ss[B:].min()) == 7.0

@@ -345,6 +345,14 @@ def test_decode_with_more_than_eight_sequences(backend):
         a, c = int(g_u[bi, t]), int(g_s[bi, t])
         assert abs((scores[bi, t, a] - scores[bi, t, c]).item()) < 0.02 * scores[bi, t].abs().max().item() + 0.05
     assert len(diff) <= 4
+    # free-running greedy decode: here the sampler's drawing wave also gathers the next input row and its RMSNorm statistic for
+    # the 12 sequences; a wrong row would derail the second token
+    kw2 = dict(max_new_tokens=3, do_sample=False, eos_token_id=None)
+    f_u = m.generate(input_ids=ids, attention_mask=mask, **mm, decode_impl="unfused", **kw2)
+    f_s = m.generate(input_ids=ids, attention_mask=mask, **mm, prompt_alias=[0] * 6 + [6] * 6, **kw2)
+    for bi in range(12):
+        if int(f_u[bi, 0]) == int(f_s[bi, 0]) and not any(d[0] == bi and d[1] <= 1 for d in diff):
+            assert int(f_u[bi, 1]) == int(f_s[bi, 1]), (bi, f_u[bi].tolist(), f_s[bi].tolist())
 
 
 @pytest.mark.gpu
