@@ -932,7 +932,7 @@ static int ring_split_rows(const GemmArgs& g) {
     if (rm <= 0 || rm >= tm) return 0;
     const long rows2 = g.M - rm * 256;
     const long halves = ((rows2 + 255) / 256) * ((g.N + 127) / 128);
-    if (halves < 128) return 0;                                      // the 256 x 128 kernel wants its share of the chip
+    if (halves < 32) return 0;                                       // (a launch for a handful of tiles costs more than it saves)
     const double cost_split = (double)R + 0.55 * (double)((halves + 255) / 256);
     return cost_split < (double)(R + 1) - 0.15 ? (int)(rm * 256) : 0;
 }

@@ -726,7 +726,7 @@ def _rope_rows_ref(x, cos, sin):
     (128, 2, 2, 1, 5, 70, 192, 130, True),       # G = 1, three completion chunks (the last ragged)
     (64, 8, 2, 2, 4, 129, 128, 77, False),       # hd 64, G = 4
 ])
-def test_dec_attn_one_launch(backend, hd, Hq, Hkv, R, copies, P, C, t, use_rows):
+def test_dec_attn_items_and_merge(backend, hd, Hq, Hkv, R, copies, P, C, t, use_rows):
     """bra_dec_attn_one (items kernel + merge kernel): q/k RMSNorm + RoPE, cache append, attention over the shared prompt K / V^T + each sequence's own
     completion keys + the new key, merged in the same launch — against plain fp32 torch (TF:qwen3:231-284 on one token)."""
     from bioreason_amd._lib import get_lib, current_stream
