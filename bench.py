@@ -121,7 +121,7 @@ def cpu_model_name():
 def cpu_baseline(mode: str = "grpo"):
     """The oracle on the host cores, bounded: ONE sample of the workload at full model size, bf16, sdpa, all cores
     (<= 64 threads), 1 warm-up pass + 3 timed passes of every leg, medians reported.
-    GRPO: encoder fwd (2 x 1024) + prefill P=2180 + decode steps (per-step time measured over 4 steps, x255) +
+    GRPO: encoder fwd (2 x 1024) + prefill P=2180 + decode steps (median per-step time of 16 steps, x255) +
     reference log-probs forward + policy forward/backward over P+C.  SFT: forward + backward of one sample."""
     import torch
     from oracle import dna_llm_oracle as O
@@ -187,8 +187,19 @@ def cpu_baseline(mode: str = "grpo"):
         return lambda: model.generate(input_ids=b["input_ids"], attention_mask=b["attention_mask"], **mm, max_new_tokens=n, **gen_kw)
 
     t_r1, n1 = med(roll(1))               # encoder + prefill + first draw
-    t_r5, n5 = med(roll(5), n=2)          # + 4 decode steps
-    per_step = max((t_r5 - t_r1) / 4, 0.0)
+    # decode steps: timed INSIDE one generate call (every call of the text model after the prefill is one token step) — the
+    # difference of two whole-rollout timings is the difference of two noisy 10-second numbers and came out anywhere between
+    # 0 and 1.3 s per step on a shared host
+    NS = 16
+    stamps = []
+    hook = text.register_forward_hook(lambda *_: stamps.append(time.time()))
+    try:
+        roll(1 + NS)()
+    finally:
+        hook.remove()
+    gaps = sorted(b_ - a_ for a_, b_ in zip(stamps[:-1], stamps[1:]))       # stamps[0] = end of the prefill forward
+    n5 = len(gaps)
+    per_step = gaps[len(gaps) // 2] if gaps else 0.0
     t_rollout = t_r1 + per_step * (C - 1)
     comp = torch.randint(0, 151643, (1, C), generator=g)
     ids = torch.cat([b["input_ids"], comp], 1)
@@ -215,8 +226,8 @@ def cpu_baseline(mode: str = "grpo"):
     total = t_rollout + t_ref + t_pol
     return dict(common, value=1.0 / total,
                 sample=f"1 sample of the cfg-3 workload at full model size (bf16, sdpa), medians after 1 warm-up: rollout "
-                       f"{t_rollout:.1f}s (encoder + prefill {t_r1:.1f}s [{n1} runs] + {per_step * 1e3:.0f} ms/decode step measured over "
-                       f"4 steps [{n5} runs] x {C - 1}), ref logps {t_ref:.1f}s [{n_ref}], policy fwd+bwd {t_pol:.1f}s [{n_pol}]; "
+                       f"{t_rollout:.1f}s (encoder + prefill {t_r1:.1f}s [{n1} runs] + {per_step * 1e3:.0f} ms/decode step, median of "
+                       f"{n5} steps timed inside one generate call, x {C - 1}), ref logps {t_ref:.1f}s [{n_ref}], policy fwd+bwd {t_pol:.1f}s [{n_pol}]; "
                        f"model build {build_s:.0f}s not counted")
 
 
