@@ -662,7 +662,6 @@ extern "C" int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, 
 
 static unsigned long long* g_debug_probe = nullptr;
 extern "C" int bra_debug_set_probe(void* p) { g_debug_probe = (unsigned long long*)p; return 0; }
-extern "C" void* bra_debug_get_probe(void) { return g_debug_probe; }
 
 extern "C" int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT,
                                  const float* sinT, const int* pos, const void* kp, long kp_sr, long kp_sh, long kp_ss,
