@@ -86,3 +86,60 @@ def test_grpo_step_two_ranks(emu_lib_path):
         assert abs(mets[0] - 4.0) < 1e-6 and abs(mets[1] - want_reward) < 1e-5
         assert abs(mets[3] - want_loss) < 1e-5 * max(1.0, abs(want_loss))
         assert ncuts >= 1, "the gradient reduction was not cut into overlapped buckets"
+
+
+def _sft_worker(rank, world, port, emu_path, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["BRA_EMU_THREADS"] = "2"
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bioreason_amd import _lib
+    _lib.use_library_for_tests(emu_path)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_model_parity import build, to_dev
+    from bioreason_amd.trainer import SFTStepRunner
+    fix = torch.load(os.path.join(GOLD, "tiny_a.pt"), weights_only=False)
+    m = build(fix, torch.device("cpu"), True)
+    m.train()
+    b = to_dev(fix["batch"], torch.device("cpu"))
+    # each rank trains on its own half of the batch (rows are whole samples with their DNA sequences): DDP semantics
+    nb = b["input_ids"].shape[0]
+    half = list(range(rank * nb // world, (rank + 1) * nb // world))
+    bmap = b["batch_idx_map"]
+    dsel = [i for i, s in enumerate(bmap) if s in half]
+    local = {"input_ids": b["input_ids"][half], "attention_mask": b["attention_mask"][half], "labels": b["labels"][half],
+             "dna_tokenized": {k: v[dsel] for k, v in b["dna_tokenized"].items()}, "batch_idx_map": [bmap[i] - half[0] for i in dsel]}
+    runner = SFTStepRunner(m, learning_rate=1e-3, weight_decay=0.0)
+    p0 = m.arena.params.clone()
+    out = runner.step(local)
+    params = [torch.empty_like(m.arena.params) for _ in range(world)]
+    dist.all_gather(params, m.arena.params)
+    grads = [torch.empty_like(m.arena.grads) for _ in range(world)]
+    dist.all_gather(grads, m.arena.grads)
+    q.put((rank, bool(torch.equal(params[0], params[1])), bool(torch.equal(grads[0], grads[1])),
+           float((m.arena.params - p0).abs().max()), float(out["loss_t"])))
+    dist.destroy_process_group()
+
+
+def test_sft_step_two_ranks(emu_lib_path):
+    """train_dna_qwen.py's DDP step on 2 ranks (gloo, emulator): different local batches, identical replicas after the bucketed
+    gradient mean + AdamW — the path `bench.py --mode sft --gpus N` runs"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sft_worker, args=(r, 2, port, emu_lib_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    losses = []
+    for rank, same_p, same_g, moved, loss in res:
+        assert same_p, "replicas diverged after the optimiser step"
+        assert same_g, "gradient buckets differ across ranks after the all-reduce"
+        assert moved > 0 and loss == loss
+        losses.append(loss)
+    assert losses[0] != losses[1], "the two ranks should have seen different samples"
