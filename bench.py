@@ -361,8 +361,8 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
-    # the objects built so far (model, fixtures, the 152 k-entry id -> text table) leave the collector's young generations: a
-    # full collection over them in the middle of a timed step showed up as a 10-15 ms outlier in one of five steps
+    # the objects built so far (model, fixtures, the 152 k-entry id -> text table) leave the collector's generations, so a full
+    # collection cannot land in the middle of a timed step (candidate cause of 10-15 ms outliers between two collections)
     import gc
     gc.collect()
     gc.freeze()
