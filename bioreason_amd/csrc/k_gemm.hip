@@ -627,25 +627,32 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs g) {
         int ra = m0 + loc; rowA[i] = ra < g.M ? ra : g.M - 1;
     }
     // stream element (K-tile tt relative to kt_begin, half H) -> slot `slot`; H is a compile-time constant at every call
-    // site: phase p always issues half (p + 3) & 3, so no branch and no run-time register indexing surrounds the DMA
+    // site: phase p always issues half (p + 3) & 3, so no branch and no run-time register indexing surrounds the DMA.
+    // Every (half, piece) walks its operand row 64 columns per K-tile, so its source address is a RUNNING pointer (+128 bytes per
+    // issue) instead of base + row * ld + k recomputed per issue: the 64-bit multiplies (quarter-rate v_mul_lo_u32 / v_mad_u64_u32,
+    // 24 per K-tile) sat in the load half of every phase, the part that has to fit under the partner wave's MFMAs.  The pointers
+    // are rebuilt once, when the stream crosses from (A, B) to the second operand pair (A2, B2: the LoRA rank).
+    const bf16_t* src[8];          // [half * 2 + piece]
+    auto src_init = [&](int h, int kt) {
+        const bool main = kt < nk1;
+        const long kcol = (long)(main ? kt : kt - nk1) * BK + lchunk;
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            if (h < 2) src[h * 2 + pc] = (main ? g.B : g.B2) + kcol + (long)rowB[h * 2 + pc] * (main ? g.ldb : g.ldb2);
+            else src[h * 2 + pc] = (main ? g.A : g.A2) + kcol + (long)rowA[(h - 2) * 2 + pc] * (main ? g.lda : g.lda2);
+        }
+    };
+#pragma unroll
+    for (int h = 0; h < 4; ++h) src_init(h, kt_begin);
     auto issue = [&](int tt, auto H, int slot) {
         constexpr int h = decltype(H)::value;
         if (tt >= nt) return;
-        const int kt = kt_begin + tt;
-        const bool main = kt < nk1;
-        const long kcol = (long)(main ? kt : kt - nk1) * BK + lchunk;
+        if (kt_begin + tt == nk1 && tt > 0) src_init(h, nk1);          // (wave-uniform, taken once per half)
         char* dst = smem + slot * HALF + wave * 2048;
-        if (h < 2) {
-            const bf16_t* Bp = (main ? g.B : g.B2) + kcol;
-            const long lb = main ? g.ldb : g.ldb2;
-            glds16(Bp + (long)rowB[h * 2] * lb, dst);
-            glds16(Bp + (long)rowB[h * 2 + 1] * lb, dst + 1024);
-        } else {
-            const bf16_t* Ap = (main ? g.A : g.A2) + kcol;
-            const long la = main ? g.lda : g.lda2;
-            glds16(Ap + (long)rowA[(h - 2) * 2] * la, dst);
-            glds16(Ap + (long)rowA[(h - 2) * 2 + 1] * la, dst + 1024);
-        }
+        glds16(src[h * 2], dst);
+        glds16(src[h * 2 + 1], dst + 1024);
+        src[h * 2] += BK;
+        src[h * 2 + 1] += BK;
     };
     auto wrap = [&](int sl) { return sl >= NSLOT ? sl - NSLOT : sl; };
     // the wait of phase gph: stream indices <= gph + 4 have landed; issued so far = min(gph + 7, nstream - 1)
@@ -933,6 +940,9 @@ static int ring_split_rows(const GemmArgs& g) {
     const long rows2 = g.M - rm * 256;
     const long halves = ((rows2 + 255) / 256) * ((g.N + 127) / 128);
     if (halves < 32) return 0;                                       // (a launch for a handful of tiles costs more than it saves)
+    // short, narrow GEMMs (o_proj and its input gradient: N = 2048, K = 2048 + 64) lose more to the second launch than the
+    // half-empty round costs: measured 822 -> 786 and 910 -> 827 TFLOP/s with the split, every longer / wider shape gains 1-5 %
+    if ((long)g.N * (g.K + g.K2) < 6l * 1024 * 1024) return 0;
     const double cost_split = (double)R + 0.55 * (double)((halves + 255) / 256);
     return cost_split < (double)(R + 1) - 0.15 ? (int)(rm * 256) : 0;
 }

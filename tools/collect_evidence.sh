@@ -9,11 +9,12 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 out=$R/gpurun_out/evidence_$tag; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline"
-if [ "$NOCPU" = "1" ]; then timeout 300 python $R/bench.py --no-cpu-baseline --steps 5 2>/dev/null | tail -1 > $out/${tag}_bench.json
+if [ "$PMC_ONLY" = "1" ]; then :      # only the counter passes (the bench line and the kernel stats of this state exist already)
+elif [ "$NOCPU" = "1" ]; then timeout 300 python $R/bench.py --no-cpu-baseline --steps 5 2>/dev/null | tail -1 > $out/${tag}_bench.json
 else timeout 600 python $R/bench.py --steps 5 2>/dev/null | tail -1 > $out/${tag}_bench.json; fi
-rm -rf /tmp/ev_stats; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ev_stats -o r --output-format csv -- $BENCH > /tmp/ev_stats.log 2>&1
+[ "$PMC_ONLY" = "1" ] || { rm -rf /tmp/ev_stats; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ev_stats -o r --output-format csv -- $BENCH > /tmp/ev_stats.log 2>&1
 f=$(find /tmp/ev_stats -name "*kernel_stats.csv" | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats --output-format csv -- $BENCH   (MI355X, $tag; 3 GRPO steps in the trace: warm-up, timed, instrumented)"; cat $f; } > $out/${tag}_bench_kernel_stats.csv
+{ echo "# rocprofv3 --kernel-trace --stats --output-format csv -- $BENCH   (MI355X, $tag; 3 GRPO steps in the trace: warm-up, timed, instrumented)"; cat $f; } > $out/${tag}_bench_kernel_stats.csv; }
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU"; do
   name=$(echo $pass | awk '{print $1}')
   rm -rf /tmp/ev_pmc; timeout 400 rocprofv3 --pmc $pass --kernel-trace -d /tmp/ev_pmc -o r --output-format csv -- $BENCH > /tmp/ev_pmc_$name.log 2>&1
