@@ -358,6 +358,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int t = 0; t < ntile; ++t) {
         const int kv0 = t * 64;
         const int tl = opaque_i(tid), ll = opaque_i(lane);      // see forward
+        const int hl = ll >> 5;
         const char* sk = smem + (t & 1) * STAGE;
         const char* sv = sk + T::KBYTES;
         const char* skt = sk + 2 * T::KBYTES;
@@ -391,7 +392,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs a) {
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int kl = kb * 32 + crow(r, h);
+                        // (hl: a per-iteration copy of h — with the lane-constant h the compiler precomputes sixteen 64-bit
+                        //  key masks at kernel entry, spills them, and reloads each behind a vmcnt(0) inside this loop)
+                        const int kl = kb * 32 + crow(r, hl);
                         bool ok = (valid >> kl) & 1ull;
                         if (a.causal) ok = ok && (kv0 + kl <= qi + a.q_off);
                         const float p = ok ? fast_exp2(st[r] * sc - lse2) : 0.f;
