@@ -109,7 +109,9 @@ __device__ __forceinline__ void dg2_epilogue(const DecGemm2Args& g, float (&v)[4
 // fragments in registers for all tiles, request tile i+1's weights before multiplying tile i, and hand the K-reduction
 // and epilogue of tile i to wave i % NW through a double-buffered LDS slab (one barrier per tile).
 // WIDE: 9 .. 16 batch rows (two prompts x 8 rollouts per GPU): MODE 0 only (the diagonal tiles hold 8 rows), folded norm or none
-template <int MODE, int NORM, int ACT, int OUTF32, int NW, int NL, int WIDE = 0>
+// PK: the weights are in fragment order (compile-time: with a run-time flag every weight address is built both ways and selected,
+// ~100 VALU instructions between kernel entry and the first weight request of a launch that lasts 5-11 us)
+template <int MODE, int NORM, int ACT, int OUTF32, int NW, int NL, int WIDE = 0, int PK = 0>
 __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
     static_assert(!WIDE || (MODE == 0 && NORM != 1), "wide rows: 16-column tiles, statistics applied in the epilogue");
     __shared__ float red[2][NW][64][4];
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
         int st[NL];
 #pragma unroll
         for (int u = 0; u < NL; ++u)      // MODE 0: a wave takes both 64-byte halves of a 128-byte line back to back;
-            st[u] = g.packed ? wave * NL + u      // packed weights: NL consecutive KiB blocks per wave and tile
+            st[u] = PK ? wave * NL + u            // packed weights: NL consecutive KiB blocks per wave and tile
                              : (MODE ? wave + NW * u : 2 * (wave + NW * (u >> 1)) + (u & 1));
         long so[NL];
 #pragma unroll
@@ -174,9 +176,9 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
         // wave-instruction (full 128-byte lines) instead of 16 row segments of 64 bytes
         long wo[NL];
 #pragma unroll
-        for (int u = 0; u < NL; ++u) wo[u] = g.packed ? (long)(st[u] < nsteps ? st[u] : nsteps - 1) * 512 : so[u];
+        for (int u = 0; u < NL; ++u) wo[u] = PK ? (long)(st[u] < nsteps ? st[u] : nsteps - 1) * 512 : so[u];
         auto tile_base = [&](int t) -> const bf16_t* {
-            if (g.packed) return g.W + (long)t * nsteps * 512 + lane * 8;
+            if (PK) return g.W + (long)t * nsteps * 512 + lane * 8;
             int rnn = t * NCOL + lrow; rnn = rnn < g.N ? rnn : g.N - 1;
             return g.W + (long)rnn * g.ldw + koff;
         };
@@ -384,7 +386,11 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     const int gmax = nw >= 8 ? 256 : 512;           // one workgroup of 8 / 16 waves (two of 4) per CU, looping over the tiles
     const dim3 grid(ntiles < gmax ? ntiles : gmax);
     if (WIDE && (nsteps + nw * nl - 1) / (nw * nl) != 1) return BRA_ERR_UNSUPPORTED;          // wide rows: single-round path only
-#define BRA_DG2(NW_, NL_) BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE>), grid, dim3(NW_ * 64), 0, st, g)
+#define BRA_DG2(NW_, NL_)                                                                                                      \
+    do {                                                                                                                       \
+        if (g.packed & 1) BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 1>), grid, dim3(NW_ * 64), 0, st, g); \
+        else BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 0>), grid, dim3(NW_ * 64), 0, st, g);      \
+    } while (0)
     if (nw == 16) {
         if constexpr (WIDE != 0) { if (nl == 12) BRA_DG2(16, 12); else if (nl == 8) BRA_DG2(16, 8); else BRA_DG2(16, 4); }
     }
