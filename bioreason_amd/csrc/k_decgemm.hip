@@ -43,6 +43,13 @@ __device__ __forceinline__ void dg2_stamp(const DecGemm2Args& g, int slot) {
 
 __device__ __forceinline__ float silu_g(float x) { return x / (1.f + __expf(-x)); }
 
+// full-rate 24-bit multiply (v_mul_u32_u24; the 32- and 64-bit integer multiplies run at quarter rate): row index x leading dimension
+#ifdef BRA_EMU
+__device__ __forceinline__ unsigned dg2_mul24(int a, int b) { return ((unsigned)a & 0xffffffu) * ((unsigned)b & 0xffffffu); }
+#else
+__device__ __forceinline__ unsigned dg2_mul24(int a, int b) { return __umul24((unsigned)a, (unsigned)b); }
+#endif
+
 // epilogue of one column tile, executed by ONE wave on the K-reduced products v (lane: batch row fr, columns 4 fq .. + 3)
 template <int MODE, int ACT, int OUTF32>
 __device__ __forceinline__ void dg2_epilogue(const DecGemm2Args& g, float (&v)[4], int tile, int lane, bool have_res,
@@ -111,32 +118,37 @@ __device__ __forceinline__ void dg2_epilogue(const DecGemm2Args& g, float (&v)[4
 // WIDE: 9 .. 16 batch rows (two prompts x 8 rollouts per GPU): MODE 0 only (the diagonal tiles hold 8 rows), folded norm or none
 // PK: the weights are in fragment order (compile-time: with a run-time flag every weight address is built both ways and selected,
 // ~100 VALU instructions between kernel entry and the first weight request of a launch that lasts 5-11 us)
-template <int MODE, int NORM, int ACT, int OUTF32, int NW, int NL, int WIDE = 0, int PK = 0>
+// FAST (the shapes of the decode step): packed weights, K == NW * NL * KS exactly (one register round, no step is clamped or
+// zeroed), every offset fits 32 bits (host-checked), no probe stamps.  With two waves per SIMD each prologue instruction costs
+// ~8 cycles of the launch's critical path, so the path to the first request is kept to: kernel arguments, one 24-bit multiply
+// per base, scalar base + 32-bit lane offset + immediate per request.
+template <int MODE, int NORM, int ACT, int OUTF32, int NW, int NL, int WIDE = 0, int PK = 0, int FAST = 0>
 __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
     static_assert(!WIDE || (MODE == 0 && NORM != 1), "wide rows: 16-column tiles, statistics applied in the epilogue");
+    static_assert(!FAST || (PK && NORM != 1), "fast form: packed weights, folded norm or none");
     __shared__ float red[2][NW][64][4];
     constexpr int KS = MODE ? 64 : 32;
     constexpr int NCOL = MODE ? 8 : 16;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    dg2_stamp(g, 0);
-    const int nsteps = g.K / KS;
+    if (!FAST) dg2_stamp(g, 0);
+    const int nsteps = FAST ? NW * NL : g.K / KS;
     const int ntiles = (g.N + NCOL - 1) / NCOL;
     const int lrow = MODE ? (fr & 7) : fr;                            // A row = weight row, B row = batch row
     const int koff = MODE ? ((fr >> 3) * 32 + fq * 8) : fq * 8;
     const int xr = lrow < g.M ? lrow : g.M - 1;
-    const bf16_t* xp = g.x + (long)xr * g.ldx + koff;
+    const bf16_t* xp = FAST ? g.x + (dg2_mul24(xr, (int)g.ldx) + (unsigned)koff) : g.x + (long)xr * g.ldx + koff;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    const int rounds = (nsteps + NW * NL - 1) / (NW * NL);
+    const int rounds = FAST ? 1 : (nsteps + NW * NL - 1) / (NW * NL);
     int tile = (int)blockIdx.x;
     int rn = tile * NCOL + lrow; rn = rn < g.N ? rn : g.N - 1;
-    const bf16_t* wp = g.W + (long)rn * g.ldw + koff;
+    const bf16_t* wp = FAST ? g.W : g.W + (long)rn * g.ldw + koff;
 
     // epilogue operand of the first tile requested now (all waves, clamped address: no branch around a load)
     const int em = fr < g.M ? fr : g.M - 1;
     int en = tile * NCOL + 4 * fq; en = en + 3 < g.N ? en : (g.N >= 4 ? g.N - 4 : 0);
     u32x2 resv = {0u, 0u};
-    if (!ACT && !OUTF32 && g.res) resv = ld8(g.res + (long)em * g.ldres + en);
+    if (!FAST && !ACT && !OUTF32 && g.res) resv = ld8(g.res + (long)em * g.ldres + en);
 
     // NORM: lane l folds partials [per * (l & 7), per * (l & 7) + per) of row l >> 3 (per <= 32, fixed order =>
     // run-to-run identical); requested first, they are the smallest and the first thing the MFMAs need
@@ -162,7 +174,8 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
                              : (MODE ? wave + NW * u : 2 * (wave + NW * (u >> 1)) + (u & 1));
         long so[NL];
 #pragma unroll
-        for (int u = 0; u < NL; ++u) so[u] = (long)(st[u] < nsteps ? st[u] : nsteps - 1) * KS;
+        for (int u = 0; u < NL; ++u) so[u] = FAST ? (long)(u * KS) : (long)(st[u] < nsteps ? st[u] : nsteps - 1) * KS;
+        if (FAST) xp += (unsigned)(wave * (NL * KS));
         // request order = arrival order (one in-order counter per wave): statistics, activations, norm weights, then
         // the weight tile, so that the normalisation below runs while the weights are still in flight
         u32x4 w0[NL], w1[NL], x[NL], nv[NL];
@@ -176,8 +189,10 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
         // wave-instruction (full 128-byte lines) instead of 16 row segments of 64 bytes
         long wo[NL];
 #pragma unroll
-        for (int u = 0; u < NL; ++u) wo[u] = PK ? (long)(st[u] < nsteps ? st[u] : nsteps - 1) * 512 : so[u];
+        for (int u = 0; u < NL; ++u) wo[u] = FAST ? (long)(u * 512) : (PK ? (long)(st[u] < nsteps ? st[u] : nsteps - 1) * 512 : so[u]);
+        const unsigned wlane = (unsigned)(wave * (NL * 512) + lane * 8);          // FAST: the lane's offset inside every tile
         auto tile_base = [&](int t) -> const bf16_t* {
+            if (FAST) return g.W + (long)t * (NW * NL * 512) + wlane;           // scalar base + 32-bit lane offset (+ immediates)
             if (PK) return g.W + (long)t * nsteps * 512 + lane * 8;
             int rnn = t * NCOL + lrow; rnn = rnn < g.N ? rnn : g.N - 1;
             return g.W + (long)rnn * g.ldw + koff;
@@ -185,23 +200,47 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
         wp = tile_base(tile);
 #pragma unroll
         for (int u = 0; u < NL; ++u) w0[u] = ld16_nt(wp + wo[u]);
+        if (FAST && !ACT && !OUTF32) {            // needed last (epilogue of the first tile), requested last; no branch around the load
+            const bf16_t* rp = g.res ? g.res : g.x;
+            const unsigned ro = g.res ? dg2_mul24(em, (int)g.ldres) + (unsigned)en : 0u;
+            resv = ld8(rp + ro);
+        }
         sched_fence();                    // every request above is in flight before the first dependent instruction
-        dg2_stamp(g, 1);
+        if (!FAST) dg2_stamp(g, 1);
+        // folded norm: wave 0 requests the statistics partials behind its weights — all of them, unconditionally (a load that
+        // sits under a uniform `4 i < per` test is issued and awaited one at a time: eight serial round trips on the wave
+        // that every other wave then waits for at the first barrier) — and folds them in the shadow of the first tile's MFMAs
+        constexpr int NPASS = WIDE ? 2 : 1;
+        f32x4 sq[NPASS][8];
         if (NORM == 2 && wave == 0) {
 #pragma unroll
-            for (int pass = 0; pass < (WIDE ? 2 : 1); ++pass) {
+            for (int pass = 0; pass < NPASS; ++pass) {
                 const int srow = (lane >> 3) + 8 * pass;                                    // (rows past M fold row M - 1 again)
-                const float* pp = g.ss_in + (long)(srow < g.M ? srow : g.M - 1) * g.nss_in + (lane & 7) * per;
+                const int sr = srow < g.M ? srow : g.M - 1;
+                const float* pp = FAST ? g.ss_in + (dg2_mul24(sr, g.nss_in) + (unsigned)((lane & 7) * per))
+                                       : g.ss_in + (long)sr * g.nss_in + (lane & 7) * per;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sq[pass][i] = *reinterpret_cast<const f32x4*>(pp + (4 * i < per ? 4 * i : 0));
+            }
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) reg_fence(sq[pass][i]);
+        }
+        auto fold_stats = [&]() {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int srow = (lane >> 3) + 8 * pass;
                 float s = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const f32x4 q = *reinterpret_cast<const f32x4*>(pp + (4 * i < per ? 4 * i : 0));
+                    const f32x4 q = sq[pass][i];
                     s += 4 * i < per ? (q[0] + q[1]) + (q[2] + q[3]) : 0.f;
                 }
                 s += wave_shfl_xor(s, 1); s += wave_shfl_xor(s, 2); s += wave_shfl_xor(s, 4);
                 if ((lane & 7) == 0) rs_lds[srow] = rsqrtf(s / (float)g.K + g.eps);       // visible after the tile barrier
             }
-        }
+        };
         if (NORM == 1) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) reg_fence(pv[i]);
@@ -220,7 +259,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < NL; ++u) if (st[u] >= nsteps) x[u] = zero4;        // steps past K contribute zero
+        for (int u = 0; u < NL; ++u) if (!FAST && st[u] >= nsteps) x[u] = zero4;        // steps past K contribute zero
         // weight registers ping-pong (w0 / w1): tile i+1 is requested before tile i is multiplied.  The requests sit
         // in straight-line code (no branch around a load: the compiler would wait for them at the join), so the last
         // one or two tiles are peeled.
@@ -235,12 +274,13 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < NL; ++u) acc = mfma_16x16x32(wc[u], x[u], acc);
+            if (NORM == 2 && it == 0 && wave == 0) fold_stats();
             float (*slab)[64][4] = red[it & 1];
 #pragma unroll
             for (int r = 0; r < 4; ++r) slab[wave][lane][r] = acc[r];
-            if (it == 0) dg2_stamp(g, 2);
+            if (!FAST && it == 0) dg2_stamp(g, 2);
             __syncthreads();
-            if (it == 0) dg2_stamp(g, 3);
+            if (!FAST && it == 0) dg2_stamp(g, 3);
             if (wave == it % NW) {
                 float v[4];
 #pragma unroll
@@ -258,8 +298,12 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
                 }
                 dg2_epilogue<MODE, ACT, OUTF32>(g, v, t, lane, it == 0, resv);
             }
-            if (it == 0) dg2_stamp(g, 4);
+            if (!FAST && it == 0) dg2_stamp(g, 4);
         };
+        if (NW == 16) {                   // 16 waves x 12 chunks: no registers for a second weight set; the host launches one
+            compute(w0, tile, 0);         // workgroup per tile (launch_dg2)
+            return;
+        }
         int it = 0;
         for (; it + 2 < nmine; it += 2) {
             issue(w1, tile + (it + 1) * G); compute(w0, tile + it * G, it);
@@ -383,11 +427,23 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     const int nl = (spw >= 12 && spw % 12 == 0) ? 12 : (spw > 4 ? 8 : 4);
     if (NORM == 2 && (nsteps + nw * nl - 1) / (nw * nl) != 1) return BRA_ERR_UNSUPPORTED;     // folded norm: single-round path only
     const int ntiles = MODE ? g.N / 8 : (g.N + 15) / 16;
-    const int gmax = nw >= 8 ? 256 : 512;           // one workgroup of 8 / 16 waves (two of 4) per CU, looping over the tiles
+    // one workgroup of 8 waves (two of 4) per CU, looping over the tiles; the 16-wave form takes one tile per workgroup
+    const int gmax = nw == 16 ? ntiles : (nw >= 8 ? 256 : 512);
     const dim3 grid(ntiles < gmax ? ntiles : gmax);
     if (WIDE && (nsteps + nw * nl - 1) / (nw * nl) != 1) return BRA_ERR_UNSUPPORTED;          // wide rows: single-round path only
+    // fast form: see the kernel; everything it assumes is checked here
+    const bool fits32 = g.ldx < (1 << 24) && g.ldres < (1 << 24) && 16 * g.ldx < (1L << 30) && 16 * g.ldres + g.N < (1L << 30) &&
+                        16L * g.nss_in < (1L << 24);
+    const bool fast = NORM != 1 && (g.packed & 1) && nsteps == nw * nl && !g.probe && fits32;
+    (void)fast;
 #define BRA_DG2(NW_, NL_)                                                                                                      \
     do {                                                                                                                       \
+        if constexpr (NORM != 1) {                                                                                             \
+            if (fast) {                                                                                                        \
+                BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 1, 1>), grid, dim3(NW_ * 64), 0, st, g); \
+                break;                                                                                                         \
+            }                                                                                                                  \
+        }                                                                                                                      \
         if (g.packed & 1) BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 1>), grid, dim3(NW_ * 64), 0, st, g); \
         else BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 0>), grid, dim3(NW_ * 64), 0, st, g);      \
     } while (0)

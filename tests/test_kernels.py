@@ -466,11 +466,14 @@ def test_sampler_distribution_matches_oracle_warpers(backend):
 
 
 @pytest.mark.parametrize("M,N,K,act,f32", [(8, 2048, 2048, 0, 0), (8, 4096, 2048, 0, 0), (5, 512, 256, 1, 0), (8, 4112, 128, 0, 1),
-                                            (8, 256, 384, 0, 0), (3, 64, 64, 0, 0)])
+                                            (8, 256, 384, 0, 0), (3, 64, 64, 0, 0),
+                                            # K == waves x chunks x k-step exactly: the "fast" instantiations of the decode step
+                                            (8, 64, 2048, 1, 0), (6, 80, 2048, 0, 1), (8, 64, 6144, 0, 0), (8, 256, 1024, 0, 0),
+                                            (7, 48, 2048, 0, 0), (8, 8208, 512, 0, 1), (8, 12288, 2048, 1, 0)])
 def test_dec_gemm2_packed_weights(backend, M, N, K, act, f32):
     """fragment-packed weight stream (bra_dec_pack_weights) == the row-major stream: same products, the K-reduction only
     visits the k-steps in a different wave order"""
-    if backend.type == "cpu" and N * K > 600000:
+    if backend.type == "cpu" and N * K > 9000000:
         pytest.skip("emulator: small shapes only")
     x, W = rnd(M, K, dev=backend), rnd(N, K, dev=backend, scale=0.1)
     nw = (1.0 + 0.1 * torch.randn(K)).to(BF).to(backend)
