@@ -39,7 +39,22 @@ struct DecOneArgs {
     int R, copies, Hq, Hkv, P, C, t, nslot, npc, ncc_grid;
     float eps, scale;
     const int* t_ptr;                       // optional device-side t (graph replay: constant launch arguments)
+    float inv_Hq, inv_npc, inv_Hkv, inv_ncc, inv_copies;   // reciprocals for the item decomposition (da_div)
 };
+
+// The launch is latency-bound (one wave per item, a few microseconds in all): every instruction between kernel entry and the
+// last K / V^T request is on its critical path.  So: item decomposition by reciprocal multiplication instead of integer
+// division (~25 scalar instructions each), 24-bit multiplies and 32-bit offsets instead of 64-bit address arithmetic
+// (v_mul_lo_u32 / v_mad_u64_u32 run at quarter rate), no load under a branch (the compiler waits for it at the join — the
+// padding-mask byte used to cost every prompt item a full memory round trip before its first K request).
+// w / d for 0 <= w < 2^21, inv = 1 / d rounded to float: (w + 0.5) / d is at least 0.5 / d away from an integer, the float
+// error is below (w / d) 2^-22
+__device__ __forceinline__ int da_div(int w, float inv) { return (int)(((float)w + 0.5f) * inv); }
+#ifdef BRA_EMU
+__device__ __forceinline__ unsigned da_mul24(int a, int b) { return ((unsigned)a & 0xffffffu) * ((unsigned)b & 0xffffffu); }
+#else
+__device__ __forceinline__ unsigned da_mul24(int a, int b) { return __umul24((unsigned)a, (unsigned)b); }
+#endif
 
 // per-head RMSNorm (weight nw) + rotate-half RoPE of the 8-dim slice this lane owns (dims 8 dl .. 8 dl + 7); the HD / 8 lanes
 // of a row are consecutive, the rotation partner (dims +- HD / 2) is lane ^ (HD / 16)
@@ -73,7 +88,7 @@ __device__ __forceinline__ void nr_slice(float (&x)[8], const bf16_t* nw, const 
 // so that the eight contraction slots a lane feeds into the PV product (its four scores of block 2 kk, then of block 2 kk + 1)
 // are eight CONSECUTIVE keys: the V^T fragment of a lane is one 16-byte load.
 template <int HD, int G>
-__device__ __forceinline__ void one_item(const DecOneArgs& a, const bf16_t* kbase, long kss, const bf16_t* vbase, long vsd,
+__device__ __forceinline__ void one_item(const DecOneArgs& a, const bf16_t* kbase, const int kss, const bf16_t* vbase, const int vsd,
                                          const int key0, const int nkeys, const uint8_t* mask, const int r, const int hkv,
                                          const int row_lo, const int row_hi, const int slot) {
     constexpr int DS = HD / 32;           // 32-deep contraction steps over the head dim
@@ -82,17 +97,17 @@ __device__ __forceinline__ void one_item(const DecOneArgs& a, const bf16_t* kbas
     const int fr = lane & 15, fq = lane >> 4;
     const int rows = a.copies * G;
     const int qrow = fr < rows ? fr : rows - 1;
-    const int copy = qrow / G, g = qrow % G;
+    const int copy = (int)((unsigned)qrow / (unsigned)G), g = (int)((unsigned)qrow % (unsigned)G);
     const int b = r * a.copies + copy, hq = hkv * G + g;
     // ---- the query row first: its norm / rotate chain runs while the K and V^T requests are in flight
-    const bf16_t* qp = a.qkv + (long)b * a.ldqkv + (long)hq * HD;
+    const bf16_t* qp = a.qkv + (da_mul24(b, (int)a.ldqkv) + (unsigned)(hq * HD));
     u32x4 qraw[DS], qwv[DS];
 #pragma unroll
     for (int s = 0; s < DS; ++s) qraw[s] = ld16(qp + s * 32 + fq * 8);
 #pragma unroll
     for (int s = 0; s < DS; ++s) qwv[s] = ld16(a.qw + s * 32 + fq * 8);
     const float* cosr; const float* sinr;
-    if (a.rope_rows) { cosr = a.rope_rows + (long)b * HD; sinr = cosr + HD / 2; }
+    if (a.rope_rows) { cosr = a.rope_rows + (unsigned)(b * HD); sinr = cosr + HD / 2; }
     else { const int p = a.pos[b]; cosr = a.cosT + (long)p * (HD / 2); sinr = a.sinT + (long)p * (HD / 2); }
     f32x4 cs[DS / 2][4];                  // [half-dim slice][cos lo, cos hi, sin lo, sin hi]
 #pragma unroll
@@ -101,10 +116,13 @@ __device__ __forceinline__ void one_item(const DecOneArgs& a, const bf16_t* kbas
         cs[s][0] = *reinterpret_cast<const f32x4*>(cosr + hb); cs[s][1] = *reinterpret_cast<const f32x4*>(cosr + hb + 4);
         cs[s][2] = *reinterpret_cast<const f32x4*>(sinr + hb); cs[s][3] = *reinterpret_cast<const f32x4*>(sinr + hb + 4);
     }
+    // validity byte of this lane's position: requested unconditionally (without a mask: some readable byte, ignored below)
+    const bool nomask = mask == nullptr;
     uint8_t mb;
     {
         const int key = key0 + lane;
-        mb = mask ? mask[key < nkeys ? key : nkeys - 1] : (uint8_t)1;
+        const uint8_t* mp = nomask ? reinterpret_cast<const uint8_t*>(a.qw) : mask + (unsigned)(key < nkeys ? key : nkeys - 1);
+        mb = *mp;
     }
     // ---- K rows straight into MFMA A fragments: lane (fr, fq) holds K[key rel(kb, fr)][32 s + 8 fq .. +8]
     u32x4 kf[4][DS];
@@ -112,20 +130,24 @@ __device__ __forceinline__ void one_item(const DecOneArgs& a, const bf16_t* kbas
     for (int kb = 0; kb < 4; ++kb) {
         int key = key0 + 32 * (kb >> 1) + 8 * (fr >> 2) + 4 * (kb & 1) + (fr & 3);
         key = key < nkeys ? key : nkeys - 1;
+        const bf16_t* kr = kbase + (da_mul24(key, kss) + (unsigned)(fq * 8));
 #pragma unroll
-        for (int s = 0; s < DS; ++s) kf[kb][s] = ld16(kbase + (long)key * kss + s * 32 + fq * 8);
+        for (int s = 0; s < DS; ++s) kf[kb][s] = ld16(kr + s * 32);
     }
     // ---- V^T fragments: lane (fr = d within block, fq) holds keys key0 + 32 kk + 8 fq .. +8 of row d
     u32x4 vf[DB][2];
+    const unsigned vlane = da_mul24(fr, vsd) + (unsigned)(key0 + fq * 8);        // lane part; the 16-row block steps a scalar base
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
+    for (int db = 0; db < DB; ++db) {
+        const bf16_t* vr = vbase + (long)db * 16 * vsd + vlane;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) vf[db][kk] = ld16(vbase + (long)(db * 16 + fr) * vsd + key0 + kk * 32 + fq * 8);
+        for (int kk = 0; kk < 2; ++kk) vf[db][kk] = ld16(vr + kk * 32);
+    }
     // ---- validity of the 64 positions of this chunk (bit = offset inside the chunk)
     uint64_t vbits;
     {
         const int key = key0 + lane;
-        vbits = wave_ballot(key < nkeys && mb != 0);
+        vbits = wave_ballot((key < nkeys) & (nomask | (mb != 0)));
     }
     sched_fence();
     // ---- q: RMSNorm, RoPE, scale
@@ -193,7 +215,7 @@ __device__ __forceinline__ void one_item(const DecOneArgs& a, const bf16_t* kbas
     l += wave_shfl_xor(l, 16);
     l += wave_shfl_xor(l, 32);
     // ---- O^T[d][row] = V^T . P
-    const long base = ((long)b * a.Hq + hq) * a.nslot + slot;
+    const unsigned base = da_mul24((int)da_mul24(b, a.Hq) + hq, a.nslot) + (unsigned)slot;
     const bool live = fr < rows && fr >= row_lo && fr < row_hi;
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
@@ -262,31 +284,60 @@ __global__ __launch_bounds__(64) void dec_attn_items_kernel(DecOneArgs a) {
     // dispatch order = workgroup id: the new-key items go first (their q / k / v -> norm -> rotate -> dot chain is the longest
     // dependent chain of the launch), then the prompt chunks, then the completion chunks
     int w = (int)blockIdx.x;
-    const int t = a.t_ptr ? a.t_ptr[0] : a.t;
     const int nK = a.R * a.copies * a.Hq;
     const int nP = a.npc * a.Hkv * a.R;
-    if (w < nK) {
-        one_newkey<HD, G>(a, w / a.Hq, w % a.Hq, t);
+    if (w >= nK && w < nK + nP) {              // prompt chunk: does not depend on t (no wait for the device-side step counter)
+        w -= nK;
+        const int q1 = da_div(w, a.inv_npc), c = w - q1 * a.npc;
+        const int r = da_div(q1, a.inv_Hkv), hkv = q1 - r * a.Hkv;
+        one_item<HD, G>(a, a.kp + r * a.kp_sr + hkv * a.kp_sh, (int)a.kp_ss, a.vtp + r * a.vt_sr + hkv * a.vt_sh, (int)a.vt_sd,
+                        c * 64, a.P, a.pmask ? a.pmask + (long)r * a.P : nullptr, r, hkv, 0, 16, c);
         return;
     }
-    w -= nK;
-    if (w < nP) {
-        const int c = w % a.npc, hkv = (w / a.npc) % a.Hkv, r = w / (a.npc * a.Hkv);
-        one_item<HD, G>(a, a.kp + r * a.kp_sr + hkv * a.kp_sh, a.kp_ss, a.vtp + r * a.vt_sr + hkv * a.vt_sh, a.vt_sd, c * 64, a.P,
-                        a.pmask ? a.pmask + (long)r * a.P : nullptr, r, hkv, 0, 16, c);
-    } else {
-        const int v = w - nP;
-        const int c = v % a.ncc_grid, copy = (v / a.ncc_grid) % a.copies, hkv = (v / (a.ncc_grid * a.copies)) % a.Hkv;
-        const int r = v / (a.ncc_grid * a.copies * a.Hkv);
+    const int t = a.t_ptr ? a.t_ptr[0] : a.t;
+    if (w < nK) {
+        const int b = da_div(w, a.inv_Hq);
+        one_newkey<HD, G>(a, b, w - b * a.Hq, t);
+        return;
+    }
+    {
+        const int v = w - nK - nP;
+        const int q1 = da_div(v, a.inv_ncc), c = v - q1 * a.ncc_grid;
+        const int q2 = da_div(q1, a.inv_copies), copy = q1 - q2 * a.copies;
+        const int r = da_div(q2, a.inv_Hkv), hkv = q2 - r * a.Hkv;
         if (c * 64 >= t) return;                                 // (graph replay sizes the grid for the longest completion)
         const int b = r * a.copies + copy;
-        one_item<HD, G>(a, a.kc + ((long)b * a.Hkv + hkv) * a.C * HD, HD, a.vct + ((long)b * a.Hkv + hkv) * HD * a.cp, a.cp, c * 64, t,
-                        nullptr, r, hkv, copy * G, copy * G + G, a.npc + c);
+        one_item<HD, G>(a, a.kc + ((long)b * a.Hkv + hkv) * a.C * HD, HD, a.vct + ((long)b * a.Hkv + hkv) * HD * a.cp, (int)a.cp,
+                        c * 64, t, nullptr, r, hkv, copy * G, copy * G + G, a.npc + c);
     }
 }
 
 // one wave per (sequence, q-head): slots [0, npc + ceil(t / 64)] -> o.  Lane (p = lane / LR, d4 = lane % LR) owns dims
 // 4 d4 .. 4 d4 + 3 of partial rows p, p + PR, ...: PR rows per 16-byte-per-lane instruction, all requested up front.
+#ifdef BRA_EMU
+__device__ __forceinline__ void da_pin(uint32_t&) {}
+#else
+__device__ __forceinline__ void da_pin(uint32_t& v) { asm volatile("" : "+v"(v)); }
+#endif
+
+// all-lanes maximum / sum over the wave: the four in-row steps are DPP row rotations (VALU moves), only the two cross-row steps
+// go through the LDS crossbar.  Every lane ends with the same bits (each step adds the same two partial sums in either order).
+__device__ __forceinline__ float da_ror_f(float v, int n) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    const uint32_t r = n == 8 ? row_ror_u32<8>(u) : (n == 4 ? row_ror_u32<4>(u) : (n == 2 ? row_ror_u32<2>(u) : row_ror_u32<1>(u)));
+    return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float da_wave_max(float v) {
+    v = fmaxf(v, da_ror_f(v, 8)); v = fmaxf(v, da_ror_f(v, 4)); v = fmaxf(v, da_ror_f(v, 2)); v = fmaxf(v, da_ror_f(v, 1));
+    v = fmaxf(v, wave_shfl_xor(v, 16));
+    return fmaxf(v, wave_shfl_xor(v, 32));
+}
+__device__ __forceinline__ float da_wave_sum(float v) {
+    v += da_ror_f(v, 8); v += da_ror_f(v, 4); v += da_ror_f(v, 2); v += da_ror_f(v, 1);
+    v += wave_shfl_xor(v, 16);
+    return v + wave_shfl_xor(v, 32);
+}
+
 template <int HD>
 __global__ __launch_bounds__(64) void dec_attn_merge_kernel(DecOneArgs a) {
     constexpr int LR = HD / 4, PR = 64 / LR, PRE = 24;
@@ -296,20 +347,35 @@ __global__ __launch_bounds__(64) void dec_attn_merge_kernel(DecOneArgs a) {
     const int nsl = a.npc + (t + 63) / 64 + 1;
     const int p = lane / LR, d4 = lane % LR;
     const long base = ((long)b * a.Hq + hq) * a.nslot;
-    float mc[4], lc[4];
+    // uniform row bases + 32-bit lane offsets (nslot <= 256 rows of HD floats); every request of the launch is issued before
+    // anything is consumed (sched_fence: the compiler otherwise waits for the (max, sum) pairs, starts the reduction and only
+    // then — one quarter-rate 64-bit multiply each — requests the partial rows: two memory round trips in series)
+    const float* pml = a.part_ml + base * 2;
+    const float* pob = a.part_o + base * HD;
+    u32x2 mlw[4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
         const int c = lane + 64 * q4;
-        const u32x2 w = ld8(a.part_ml + (base + (c < nsl ? c : nsl - 1)) * 2);
-        const uint32_t wm = w.x, wl = w.y;       // (a bit_cast applied to `w.y` directly reads element 0 with this clang)
-        mc[q4] = __builtin_bit_cast(float, wm);
-        lc[q4] = __builtin_bit_cast(float, wl);
+        mlw[q4] = ld8(pml + (unsigned)((c < nsl ? c : nsl - 1) * 2));
     }
     u32x4 v0[PRE];
 #pragma unroll
     for (int u = 0; u < PRE; ++u) {
         const int c = u * PR + p;
-        v0[u] = ld16(a.part_o + (base + (c < nsl ? c : nsl - 1)) * HD + d4 * 4);
+        v0[u] = ld16(pob + (unsigned)((c < nsl ? c : nsl - 1) * HD + d4 * 4));
+    }
+    // sched_fence is ordered behind the requests, but pure arithmetic is not ordered behind IT: instruction selection orders a
+    // block bottom-up by register pressure and would still start the reduction above the fence, each partial-row request sunk
+    // to its first use.  Passing the (max, sum) words through an (empty) volatile asm ties everything derived from them to a
+    // point behind the fence; it waits for those four loads only (in-order return counter), not for the partial rows.
+    sched_fence();
+    float mc[4], lc[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        uint32_t wm = mlw[q4].x, wl = mlw[q4].y;             // (a bit_cast applied to `w.y` directly reads element 0 with this clang)
+        da_pin(wm); da_pin(wl);
+        mc[q4] = __builtin_bit_cast(float, wm);
+        lc[q4] = __builtin_bit_cast(float, wl);
     }
     float m = kNegA;
 #pragma unroll
@@ -317,11 +383,11 @@ __global__ __launch_bounds__(64) void dec_attn_merge_kernel(DecOneArgs a) {
         if (lane + 64 * q4 >= nsl) { mc[q4] = kNegA; lc[q4] = 0.f; }
         m = fmaxf(m, mc[q4]);
     }
-    m = wave_max<64>(m);
+    m = da_wave_max(m);
     float l = 0.f;
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) { mc[q4] = fast_exp2(mc[q4] - m); l += lc[q4] * mc[q4]; }      // mc now holds the slot weight
-    l = wave_sum<64>(l);
+    l = da_wave_sum(l);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < PRE; ++u) {
@@ -385,9 +451,16 @@ extern "C" int bra_dec_attn_one(const void* qkv, long ldqkv, const void* qw, con
     DecOneArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, rope_rows,
                     (const bf16_t*)kp, kp_sr, kp_sh, kp_ss, (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask,
                     (bf16_t*)kc, (bf16_t*)vct, cp, part_o, part_ml, (bf16_t*)o, ldo,
-                    R, copies, Hq, Hkv, P, C, t, nslot, npc, ncc, eps, scale, t_dev};
+                    R, copies, Hq, Hkv, P, C, t, nslot, npc, ncc, eps, scale, t_dev,
+                    1.f / (float)Hq, 1.f / (float)npc, 1.f / (float)Hkv, 1.f / (float)(ncc > 0 ? ncc : 1), 1.f / (float)copies};
     bra_stream_t st = (bra_stream_t)stream;
     const int nitems = npc * Hkv * R + ncc * copies * Hkv * R + R * copies * Hq;
+    // 24-bit factors / 32-bit element offsets inside one (prompt, kv-head) block, one activation matrix, the partial buffers
+    const long lim = 1L << 30, f24 = 1L << 24;
+    const long Bq = (long)R * copies;
+    if (nitems >= (1 << 21) || kp_ss >= f24 || vt_sd >= f24 || cp >= f24 || ldqkv >= f24 || (long)(npc * 64) * kp_ss >= lim ||
+        (long)hd * vt_sd >= lim || (long)hd * cp >= lim || Bq * ldqkv >= lim || Bq * Hq * nslot * hd >= lim || Bq * hd >= lim)
+        return BRA_ERR_UNSUPPORTED;
 #define BRA_DO(HD_, G_)                                                                                   \
     if (hd == HD_ && G == G_) {                                                                           \
         BRA_LAUNCH((dec_attn_items_kernel<HD_, G_>), dim3(nitems), dim3(64), 0, st, a);                   \

@@ -722,14 +722,16 @@ def _rope_rows_ref(x, cos, sin):
     return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], -1)
 
 
-@pytest.mark.parametrize("hd,Hq,Hkv,R,copies,P,C,t,use_rows", [
-    (128, 4, 2, 1, 8, 200, 256, 0, True),        # first decode step: no completion keys yet
-    (128, 4, 2, 1, 8, 200, 256, 1, True),
-    (128, 4, 2, 2, 3, 150, 192, 64, False),      # two prompts, completion exactly one full chunk
-    (128, 2, 2, 1, 5, 70, 192, 130, True),       # G = 1, three completion chunks (the last ragged)
-    (64, 8, 2, 2, 4, 129, 128, 77, False),       # hd 64, G = 4
+@pytest.mark.parametrize("hd,Hq,Hkv,R,copies,P,C,t,use_rows,use_mask", [
+    (128, 4, 2, 1, 8, 200, 256, 0, True, True),        # first decode step: no completion keys yet
+    (128, 4, 2, 1, 8, 200, 256, 1, True, True),
+    (128, 4, 2, 2, 3, 150, 192, 64, False, True),      # two prompts, completion exactly one full chunk
+    (128, 2, 2, 1, 5, 70, 192, 130, True, True),       # G = 1, three completion chunks (the last ragged)
+    (64, 8, 2, 2, 4, 129, 128, 77, False, True),       # hd 64, G = 4
+    (128, 8, 2, 3, 2, 333, 128, 65, True, False),      # no padding mask passed; 3 prompts x 2 copies, G = 4
+    (128, 16, 8, 1, 8, 2180, 256, 200, True, True),    # the cfg-3 geometry: 35 prompt chunks x 8 kv-heads, 4 completion chunks
 ])
-def test_dec_attn_items_and_merge(backend, hd, Hq, Hkv, R, copies, P, C, t, use_rows):
+def test_dec_attn_items_and_merge(backend, hd, Hq, Hkv, R, copies, P, C, t, use_rows, use_mask):
     """bra_dec_attn_one (items kernel + merge kernel): q/k RMSNorm + RoPE, cache append, attention over the shared prompt K / V^T + each sequence's own
     completion keys + the new key, merged in the same launch — against plain fp32 torch (TF:qwen3:231-284 on one token)."""
     from bioreason_amd._lib import get_lib, current_stream
@@ -763,8 +765,10 @@ def test_dec_attn_items_and_merge(backend, hd, Hq, Hkv, R, copies, P, C, t, use_
     part_o = torch.full((B * Hq, nslot, hd), float("nan"), dtype=torch.float32, device=dev)
     part_ml = torch.full((B * Hq, nslot, 2), float("nan"), dtype=torch.float32, device=dev)
     o = torch.zeros(B, Nq, dtype=BF, device=dev)
+    if not use_mask:
+        pmask[:] = 1
     get_lib().call("bra_dec_attn_one", qkv, Nq + 2 * Nkv, qw, kw, cosT, sinT, pos, rope_rows, kp, Hkv * P * hd, P * hd, hd, vtp,
-                   Hkv * hd * pitch, hd * pitch, pitch, pmask, kc, vct, cp, part_o, part_ml, nslot, o, Nq, R, copies,
+                   Hkv * hd * pitch, hd * pitch, pitch, pmask if use_mask else None, kc, vct, cp, part_o, part_ml, nslot, o, Nq, R, copies,
                    Hq, Hkv, hd, P, C, t, eps, scale, None, current_stream(qkv))
     # ---- reference
     f = qkv.float().cpu()
