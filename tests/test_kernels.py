@@ -430,6 +430,15 @@ def test_sampler_greedy_and_topk(backend):
     pos, a_, b_ = torch.arange(5, dtype=torch.int32, device=backend), torch.zeros(1, dtype=torch.int32, device=backend), torch.full((1,), 9, dtype=torch.int32, device=backend)
     ops.advance_counters(pos, a_, b_)
     assert pos.tolist() == [1, 2, 3, 4, 5] and a_.item() == 1 and b_.item() == 10
+    # with the rotary rows of the advanced positions (token loop: one launch bumps the counters and refreshes cos | sin rows)
+    for n, hd in ((3, 32), (8, 128), (16, 128)):
+        cosT, sinT = torch.rand(40, hd // 2, device=backend), torch.rand(40, hd // 2, device=backend)
+        pos = (torch.arange(n, dtype=torch.int32, device=backend) * 2) % 7 + 3
+        want_pos = pos + 1
+        rows = torch.zeros(n, hd, device=backend)
+        ops.advance_counters(pos, a_, b_, rope=(cosT, sinT, hd, rows))
+        assert torch.equal(pos.cpu(), want_pos.cpu())
+        assert torch.equal(rows.cpu(), torch.cat([cosT[want_pos.long()], sinT[want_pos.long()]], -1).cpu())
 
 
 def test_sampler_distribution_matches_oracle_warpers(backend):
