@@ -50,11 +50,22 @@ __global__ __launch_bounds__(256) void topk_slices_kernel(const float* logits, l
     const int per = (V + kSlices - 1) / kSlices;
     const int lo = sl * per, hi = (lo + per) < V ? (lo + per) : V;
     const float* lr = logits + (long)row * ldl;
+    // all EPT requests first, from clamped addresses: `i < hi ? cand_key(lr[i], i) : 0` compiles to EPT branches with one load
+    // and a full wait each — ten memory round trips in series at Qwen3's vocabulary
     uint64_t key[EPT];
+    float val[EPT];
+    const int last = hi > lo ? hi - 1 : (V > 0 ? V - 1 : 0);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = lo + tid + 256 * e;
-        key[e] = i < hi ? cand_key(lr[i], i) : 0ull;
+        val[e] = lr[i < hi ? i : last];
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = lo + tid + 256 * e;
+        const uint64_t kk = cand_key(val[e], i);
+        const uint64_t live = i < hi ? ~0ull : 0ull;
+        key[e] = kk & live;
     }
     uint64_t best = 0ull;
 #pragma unroll
