@@ -30,6 +30,13 @@ __device__ __forceinline__ float uniform01(uint32_t seed, uint32_t step, uint32_
 // no LDS), then one row merges the 16 sorted lists the same way.  (First form: k rounds of a block-wide arg-max with two barriers
 // and a serial section each, 26 us per token at Qwen3's vocabulary.)
 constexpr int kSlices = 64;
+#ifdef BRA_EMU
+__device__ __forceinline__ void pin_u32(uint32_t&) {}
+__device__ __forceinline__ void pin_u32x4(u32x4&) {}
+#else
+__device__ __forceinline__ void pin_u32x4(u32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin_u32(uint32_t& v) { asm volatile("" : "+v"(v)); }
+#endif
 __device__ __forceinline__ uint32_t ord_f32(float v) {
     const uint32_t u = __builtin_bit_cast(uint32_t, v);
     return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
@@ -106,9 +113,11 @@ __global__ __launch_bounds__(256) void topk_slices_kernel(const float* logits, l
 // (HF: TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper, multinomial — TF:generation/logits_process.py, utils.py:2905-2925)
 // `p` = k floats of LDS scratch (a per-thread array indexed at run time would live in scratch memory: every access a
 // round trip through the memory system, in a single-thread serial section)
-__device__ inline void sample_pick(float* p, const float* top_v, const int* top_i, int k, int row, float temperature, float top_p,
-                                   int do_sample, uint32_t seed, const int* step_ptr, uint8_t* finished, int pad_id, int eos_id, int eos_id2,
-                                   int* out_ids, float* out_logp, int* tokens_out, long ldt) {
+// `step` / `was_finished`: the step word and the row's finished flag, read by the caller (the merge kernel requests them with its
+// first loads: read here they were two more memory round trips in the single-thread tail of every token).  Returns the token.
+__device__ inline int sample_pick(float* p, const float* top_v, const int* top_i, int k, int row, float temperature, float top_p,
+                                  int do_sample, uint32_t seed, int step, int was_finished, uint8_t* finished, int pad_id, int eos_id,
+                                  int eos_id2, int* out_ids, float* out_logp, int* tokens_out, long ldt) {
     int choice = top_i[0];
     float lp = 0.f;
     if (do_sample) {
@@ -129,18 +138,19 @@ __device__ inline void sample_pick(float* p, const float* top_v, const int* top_
         }
         float z2 = 0.f;
         for (int j = 0; j < keep; ++j) z2 += p[j];
-        const float u = uniform01(seed, (uint32_t)(step_ptr ? step_ptr[0] : 0), (uint32_t)row) * z2;
+        const float u = uniform01(seed, (uint32_t)step, (uint32_t)row) * z2;
         float acc = 0.f;
         int pick = keep - 1;
         for (int j = 0; j < keep; ++j) { acc += p[j]; if (u < acc) { pick = j; break; } }
         choice = top_i[pick];
         lp = __logf(p[pick] / z2);
     }
-    if (finished && finished[row]) choice = pad_id;   // HF: finished sequences emit pad_token_id
+    if (was_finished) choice = pad_id;                // HF: finished sequences emit pad_token_id
     out_ids[row] = choice;
     if (out_logp) out_logp[row] = lp;
-    if (tokens_out) tokens_out[(long)row * ldt + (step_ptr ? step_ptr[0] : 0)] = choice;
+    if (tokens_out) tokens_out[(long)row * ldt + step] = choice;
     if (finished && ((eos_id >= 0 && choice == eos_id) || (eos_id2 >= 0 && choice == eos_id2))) finished[row] = 1;   // unfinished &= (token != eos)
+    return choice;
 }
 
 template <int NT>
@@ -186,8 +196,8 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* logits, long ld
     }
     __shared__ float pick_ws[64];
     if (tid == 0)
-        sample_pick(pick_ws, top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr, finished, pad_id, eos_id, eos_id2, out_ids,
-                    out_logp, tokens_out, ldt);
+        sample_pick(pick_ws, top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr ? step_ptr[0] : 0,
+                    finished ? (int)finished[row] : 0, finished, pad_id, eos_id, eos_id2, out_ids, out_logp, tokens_out, ldt);
 }
 
 // stage 2 of the sampler when stage 1 ran: ONE wave per sequence merges the 64 slice lists (each already in the
@@ -208,6 +218,9 @@ __global__ __launch_bounds__(64) void sample_merge_kernel(const float* cand_v, c
     int* si = reinterpret_cast<int*>(smem) + kSlices * k;
     const int row = (int)blockIdx.x, lane = lane_id();
     const long base = (long)row * kSlices * k;
+    // the step word and the finished flag travel with the candidate loads (clamped pointers: no branch around a load)
+    uint32_t step_w = *reinterpret_cast<const uint32_t*>(step_ptr ? (const void*)step_ptr : (const void*)cand_i);
+    uint32_t fin_w = *(finished ? finished + row : reinterpret_cast<const uint8_t*>(cand_i));
     if ((k & 3) == 0) {
         // lane = slice: its k candidates are contiguous; all 16-byte loads are requested before the first is used
         const f32x4* gv = reinterpret_cast<const f32x4*>(cand_v + base + (long)lane * k);
@@ -225,6 +238,8 @@ __global__ __launch_bounds__(64) void sample_merge_kernel(const float* cand_v, c
     } else {
         for (int j = lane; j < kSlices * k; j += 64) { sv[j] = cand_v[base + j]; si[j] = cand_i[base + j]; }
     }
+    pin_u32(step_w); pin_u32(fin_w);              // (keeps the two loads up there: instruction selection sinks a load to its first use)
+    const int step_v = step_ptr ? (int)step_w : 0, fin_v = finished ? (int)(fin_w & 0xffu) : 0;
     __syncthreads();
     int ptr = 0;
     uint64_t head = si[lane * k] != 0x7fffffff ? cand_key(sv[lane * k], si[lane * k]) : 0ull;
@@ -240,17 +255,34 @@ __global__ __launch_bounds__(64) void sample_merge_kernel(const float* cand_v, c
         }
     }
     __syncthreads();
-    if (lane == 0) {
-        sample_pick(pick_ws, top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_ptr, finished, pad_id, eos_id, eos_id2,
-                    out_ids, out_logp, tokens_out, ldt);
-        s_choice = out_ids[row];
-    }
+    if (lane == 0)
+        s_choice = sample_pick(pick_ws, top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_v, fin_v, finished, pad_id,
+                               eos_id, eos_id2, out_ids, out_logp, tokens_out, ldt);
     __syncthreads();
     if (!E) return;
     const int tok = s_choice;
     float acc = 0.f;
-    for (int j = lane; j < H / 8; j += 64) {
-        const u32x4 v = ld16(E + (long)tok * lde + j * 8);
+    // the embedding row (H <= 2048: four 16-byte chunks per lane) is requested in one go, then stored
+    const int nch = H / 8;
+    const bf16_t* er = E + (long)tok * lde;
+    u32x4 ev[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int j = lane + 64 * u; ev[u] = ld16(er + (j < nch ? j : 0) * 8); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pin_u32x4(ev[u]);          // (or the load of a chunk is sunk under its `j < nch` test again)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = lane + 64 * u;
+        if (j < nch) {
+            st16(x + (long)row * ldx + j * 8, ev[u]);
+            float f[8];
+            unpack8(ev[u], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += f[i] * f[i];
+        }
+    }
+    for (int j = lane + 256; j < nch; j += 64) {
+        const u32x4 v = ld16(er + j * 8);
         st16(x + (long)row * ldx + j * 8, v);
         float f[8];
         unpack8(v, f);
