@@ -101,8 +101,10 @@ def pmc_traffic():
     except Exception:
         return None, "no PMC summary committed for this round (profiles/r2_pmc_gemm.json)"
     if d.get("kernel_source_sha") != kernel_source_sha():
-        return None, "profiles/r2_pmc_gemm.json was collected from different kernel sources (sha %s, running %s): not reported" % (
-            d.get("kernel_source_sha"), kernel_source_sha())
+        return None, ("profiles/r2_pmc_gemm.json was collected from different kernel sources (sha %s, running %s): not reported. "
+                      "Last collected value, for sha %s: %.0f bytes per launch" % (
+                          d.get("kernel_source_sha"), kernel_source_sha(), d.get("kernel_source_sha"),
+                          float(d.get("traffic_bytes_per_launch", 0.0))))
     return float(d["traffic_bytes_per_launch"]), ("HBM-side bytes per launch, rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + "
                                                   "WRITE_SIZE, separate passes) on this command: profiles/r2_pmc_gemm.json")
 

@@ -58,10 +58,104 @@ __device__ __forceinline__ int swz_chunk(int row, int c) {
     return BK == 64 ? (c ^ (row & 7)) : (c ^ ((row >> 2) & 3));
 }
 
+// ---- EPI_BF16 for a wave whose MI x 4 fragments all lie inside the matrix (every tile but the last tile row / column).
+// The generic epilogues below walk the fragments one by one under `m < M` / `n < N` tests, and a load under a branch is issued
+// and awaited alone: with a residual that was MI x 4 = 32 memory round trips in series at the end of every tile (one workgroup
+// per CU: nothing else runs meanwhile), each with two 64-bit multiplies for its addresses.  Here: one base pointer per operand,
+// row steps by addition, column steps as immediates, every residual word requested before the first is used.
+#ifdef BRA_EMU
+__device__ __forceinline__ void epi_pin(u32x2&) {}
+#else
+__device__ __forceinline__ void epi_pin(u32x2& v) { asm volatile("" : "+v"(v)); }
+#endif
+// alpha * acc, then + bias: two roundings, as the generic epilogue computes it (its add sits under `if (g.bias)`); -ffast-math
+// would contract this into one fma here and the two epilogues would differ in the last bit
+// (the backend fuses under the global fusion mode whatever a contract pragma says: an empty asm on the product separates them)
+template <bool BIAS>
+__device__ __forceinline__ float epi_scale_bias(float a, float alpha, float b) {
+    float t = a * alpha;
+    if (BIAS) {
+#ifndef BRA_EMU
+        asm volatile("" : "+v"(t));
+#endif
+        t = t + b;
+    }
+    return t;
+}
+template <int MI, bool BIAS>
+__device__ __forceinline__ void epi_bf16_interior_b(const GemmArgs& g, f32x4 (&acc)[4][MI], int mw0, int nw0, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const float alpha = g.alpha;
+    const int col = nw0 + 4 * fq;
+    bf16_t* cp = (bf16_t*)g.C + ((long)(mw0 + fr) * g.ldc + col);
+    const long cstep = 16 * g.ldc;
+    float bz[4][4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bz[ni][r] = 0.f;
+    if (BIAS) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const u32x2 b = ld8(g.bias + col + 16 * ni);
+            bz[ni][0] = bf_lo(b.x); bz[ni][1] = bf_hi(b.x); bz[ni][2] = bf_lo(b.y); bz[ni][3] = bf_hi(b.y);
+        }
+    }
+    if (g.res) {
+        const bf16_t* rp = g.res + ((long)(mw0 + fr) * g.ldres + col);
+        const long rstep = 16 * g.ldres;
+        u32x2 rv[MI][4];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) rv[mi][ni] = ld8(rp + mi * rstep + ni * 16);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) epi_pin(rv[mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = epi_scale_bias<BIAS>(acc[ni][mi][r], alpha, bz[ni][r]);
+                const u32x2 w = rv[mi][ni];
+                v[0] = round_bf(v[0]) + bf_lo(w.x); v[1] = round_bf(v[1]) + bf_hi(w.x);
+                v[2] = round_bf(v[2]) + bf_lo(w.y); v[3] = round_bf(v[3]) + bf_hi(w.y);
+                u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                st8(cp + mi * cstep + ni * 16, o);
+            }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = epi_scale_bias<BIAS>(acc[ni][mi][r], alpha, bz[ni][r]);
+            u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+            st8(cp + mi * cstep + ni * 16, o);
+        }
+}
+template <int MI>
+__device__ __forceinline__ void epi_bf16_interior(const GemmArgs& g, f32x4 (&acc)[4][MI], int mw0, int nw0, int lane) {
+    if (g.bias) epi_bf16_interior_b<MI, true>(g, acc, mw0, nw0, lane);
+    else epi_bf16_interior_b<MI, false>(g, acc, mw0, nw0, lane);
+}
+__device__ __forceinline__ bool epi_interior(const GemmArgs& g, int mw0, int nw0, int rows) {
+    return mw0 + rows <= g.M && nw0 + 64 <= g.N && !(g.ldc & 3) && !(g.ldres & 3);
+}
+
 // ---- epilogue: lane owns C[m][n..n+3], m = m0 + wm*64 + 16*mi + fr, n = n0 + wn*64 + 16*ni + 4*fq
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn,
                                               int lane, int tile_n) {
+    if (EPI == EPI_BF16 && epi_interior(g, m0 + wm * 64, n0 + wn * 64, 64)) {
+        epi_bf16_interior<4>(g, acc, m0 + wm * 64, n0 + wn * 64, lane);
+        return;
+    }
     const int fr = lane & 15, fq = lane >> 4;
     const float alpha = g.alpha;
     if (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_ATOMIC || EPI == EPI_DLOGIT) {
@@ -168,6 +262,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
 // the same epilogues for a wave that owns MI x 4 fragments at (mw0, nw0): lane owns C[mw0 + 16 mi + fr][nw0 + 16 ni + 4 fq ..+3]
 template <int EPI, int MI>
 __device__ __forceinline__ void gemm_epilogue_w(const GemmArgs& g, f32x4 (&acc)[4][MI], int mw0, int nw0, int lane) {
+    if (EPI == EPI_BF16 && epi_interior(g, mw0, nw0, 16 * MI)) {
+        epi_bf16_interior<MI>(g, acc, mw0, nw0, lane);
+        return;
+    }
     const int fr = lane & 15, fq = lane >> 4;
     const float alpha = g.alpha;
     if (EPI == EPI_LSE) {

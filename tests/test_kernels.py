@@ -590,6 +590,35 @@ def test_lmhead_lse_at_full_vocab(hip_device):
     assert rel(logp, ref_lp) < 2e-3
 
 
+@pytest.mark.parametrize("variant", [0, 5, 7])
+def test_gemm_bf16_epilogue_interior_and_edge_waves(backend, variant):
+    """k_gemm.hip epi_bf16_interior: a wave whose fragments all lie inside the matrix takes the batched epilogue (one base
+    pointer per operand, every residual word requested up front), the others the generic one: every bias / residual combination
+    on a matrix made of interior tiles only, on one with ragged edges, and with a residual whose row pitch is not a multiple of
+    four elements (generic path everywhere).  The two paths must agree bit for bit on the rows they share."""
+    from bioreason_amd._lib import get_lib
+    get_lib().call("bra_gemm_set_variant", variant)
+    try:
+        K = 128
+        for (M, N) in [(512, 256), (530, 300)]:
+            a, b = rnd(M, K, dev=backend, seed=11), rnd(N, K, dev=backend, seed=12)
+            bias, res = rnd(N, dev=backend, seed=13), rnd(M, N, dev=backend, seed=14)
+            acc = a.float() @ b.float().T
+            for use_bias in (False, True):
+                for use_res in (False, True):
+                    c = ops.gemm_nt(a, b, bias=bias if use_bias else None, res=res if use_res else None, alpha=0.25)
+                    want = 0.25 * acc + (bias.float() if use_bias else 0)
+                    want = want.to(BF).float() + res.float() if use_res else want
+                    assert rel(c, want.to(BF)) < 4e-3, (M, N, use_bias, use_res)
+                    if use_res:
+                        wide = torch.zeros(M, N + 2, dtype=BF, device=backend)       # row pitch N + 2: not 8-byte aligned rows
+                        wide[:, :N] = res
+                        c2 = ops.gemm_nt(a, b, bias=bias if use_bias else None, res=wide[:, :N], alpha=0.25)
+                        assert torch.equal(c, c2), (M, N, use_bias)
+    finally:
+        get_lib().call("bra_gemm_set_variant", -1)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_gemm_tile_variants(backend, variant):
     """every tile variant (128/256-row tiles x register prefetch depth 1/2) against the fp32 statement"""
