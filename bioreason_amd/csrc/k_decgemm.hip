@@ -51,12 +51,14 @@ __device__ __forceinline__ unsigned dg2_mul24(int a, int b) { return __umul24((u
 #endif
 
 // epilogue of one column tile, executed by ONE wave on the K-reduced products v (lane: batch row fr, columns 4 fq .. + 3)
-template <int MODE, int ACT, int OUTF32>
+// FULLN: N is a multiple of the tile width (always so with packed weights): no ragged last tile, every column test folds away
+template <int MODE, int ACT, int OUTF32, int FULLN = 0>
 __device__ __forceinline__ void dg2_epilogue(const DecGemm2Args& g, float (&v)[4], int tile, int lane, bool have_res,
                                              const u32x2& resv) {
     constexpr int NCOL = MODE ? 8 : 16;
     const int fr = lane & 15, fq = lane >> 4;
     const int n0 = tile * NCOL;
+    const int N = FULLN ? 0x7fffffff : g.N;       // (column tests below read `N`)
     if (MODE) {                                   // second K-half of (n, m) sits at (n + 8, m + 8) = lane + 40
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += wave_shfl(v[r], lane + 40);
@@ -78,30 +80,32 @@ __device__ __forceinline__ void dg2_epilogue(const DecGemm2Args& g, float (&v)[4
         return;
     }
     const int n = n0 + 4 * fq;
-    const bool live = m < g.M && n < g.N && 4 * fq < NCOL && (!MODE || fr < 8);
+    const bool live = m < g.M && n < N && 4 * fq < NCOL && (!MODE || fr < 8);
     if (OUTF32) {
         if (live) {
             float* cp = (float*)g.out + (long)m * g.ldo + n;
-            if (n + 3 < g.N && (g.ldo & 3) == 0) { f32x4 o = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(cp) = o; }
-            else for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = v[r];
+            if (n + 3 < N && (g.ldo & 3) == 0) { f32x4 o = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(cp) = o; }
+            else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = v[r];
         }
         return;
     }
     float ss = 0.f;
     if (g.res) {
-        if (have_res && n + 3 < g.N) {
-            v[0] = round_bf(v[0]) + bf_lo(resv.x); v[1] = round_bf(v[1]) + bf_hi(resv.x);
-            v[2] = round_bf(v[2]) + bf_lo(resv.y); v[3] = round_bf(v[3]) + bf_hi(resv.y);
+        if ((have_res || live) && n + 3 < N) {
+            u32x2 rr = resv;                              // first tile of the workgroup: requested with the weights
+            if (!have_res) rr = ld8(g.res + (long)m * g.ldres + n);         // later tiles (host: ldres % 4 == 0)
+            v[0] = round_bf(v[0]) + bf_lo(rr.x); v[1] = round_bf(v[1]) + bf_hi(rr.x);
+            v[2] = round_bf(v[2]) + bf_lo(rr.y); v[3] = round_bf(v[3]) + bf_hi(rr.y);
         } else if (live) {
-            for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] = round_bf(v[r]) + bf2f(g.res[(long)m * g.ldres + n + r]);
+            for (int r = 0; r < 4; ++r) if (n + r < N) v[r] = round_bf(v[r]) + bf2f(g.res[(long)m * g.ldres + n + r]);
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { v[r] = round_bf(v[r]); if (live && n + r < g.N) ss += v[r] * v[r]; }
+    for (int r = 0; r < 4; ++r) { v[r] = round_bf(v[r]); if (live && n + r < N) ss += v[r] * v[r]; }
     if (live) {
         bf16_t* cp = (bf16_t*)g.out + (long)m * g.ldo + n;
-        if (n + 3 < g.N) { u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); st8(cp, o); }
-        else for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = f2bf(v[r]);
+        if (n + 3 < N) { u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); st8(cp, o); }
+        else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(v[r]);
     }
     if (g.ss_out) {
         if (!live) ss = 0.f;
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= rsf;
                 }
-                dg2_epilogue<MODE, ACT, OUTF32>(g, v, t, lane, it == 0, resv);
+                dg2_epilogue<MODE, ACT, OUTF32, PK>(g, v, t, lane, it == 0, resv);
             }
             if (!FAST && it == 0) dg2_stamp(g, 4);
         };
