@@ -25,6 +25,9 @@ for name, M, N, K, K2 in shapes:
     a = torch.randn(M, K, device=dev).to(BF); b = torch.randn(N, K, device=dev).to(BF)
     a2 = torch.randn(M, K2, device=dev).to(BF) if K2 else None; b2 = torch.randn(N, K2, device=dev).to(BF) if K2 else None
     c = torch.empty(M, N, dtype=BF, device=dev)
+    # GV_RES=1: with a residual operand, as the o / down projections and every input-gradient GEMM of the model run (the tile
+    # epilogue then reads M x N more elements; round 2's last change batches those loads per wave)
+    rs = torch.randn(M, N, device=dev).to(BF) if os.environ.get("GV_RES") == "1" and M * N <= (1 << 29) else None
     res = {}
     if os.environ.get("GV_CHECK") == "1":            # variant 6 against variant 5 on the same operands (both fp32-accumulated)
         get_lib().call("bra_gemm_set_variant", 5); c5 = ops.gemm_nt(a, b, a2=a2, b2=b2).float()
@@ -33,7 +36,7 @@ for name, M, N, K, K2 in shapes:
         del c5, c6
     for v in ((5, 6, 7) if os.environ.get('GV_FAST') == '1' else (0, 4, 5, 6, 7)):
         get_lib().call("bra_gemm_set_variant", v)
-        ms = timeit(lambda: ops.gemm_nt(a, b, a2=a2, b2=b2, out=c))
+        ms = timeit(lambda: ops.gemm_nt(a, b, a2=a2, b2=b2, out=c, res=rs))
         res[v] = round(2.0 * M * N * (K + K2) / ms / 1e9)
     get_lib().call("bra_gemm_set_variant", -1)
     ms = timeit(lambda: torch.matmul(a, b.T))
