@@ -42,52 +42,62 @@ __global__ __launch_bounds__(256) void lora_down_drop_kernel(LoraDownArgs g) {
     const int m0 = (int)blockIdx.x * 32;
     const int nstep = (g.K + KS - 1) / KS;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // issue = requests only (raw values), commit zeroes what lies past K / R: a select on the loaded value inside issue, with
+    // issue under `if (s + 1 < nstep)`, made the compiler wait for the next tile before the MFMAs of the current one
     u32x4 rx[2], ra[2 * NL];
     auto issue = [&](int s) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = tid + 256 * i, row = c >> 4, k = KS * s + 8 * (c & 15);
             int m = m0 + row; m = m < g.M ? m : g.M - 1;
-            const u32x4 v = ld16(g.x + (long)m * g.ldx + (k < g.K ? k : 0));
-            rx[i] = k < g.K ? v : zero4;
+            rx[i] = ld16(g.x + (long)m * g.ldx + (k < g.K ? k : 0));
         }
 #pragma unroll
         for (int i = 0; i < 2 * NL; ++i) {                       // rows of the live blocks only
             const int c = tid + 256 * i, row = c >> 4, k = KS * s + 8 * (c & 15);
-            const u32x4 v = ld16(g.A + (long)(row < g.R ? row : g.R - 1) * g.lda + (k < g.K ? k : 0));
-            ra[i] = (k < g.K && row < g.R) ? v : zero4;
+            ra[i] = ld16(g.A + (long)(row < g.R ? row : g.R - 1) * g.lda + (k < g.K ? k : 0));
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, int s) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { const int c = tid + 256 * i; st16(&xs[buf * 32 * XP + (c >> 4) * XP + 8 * (c & 15)], rx[i]); }
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, k = KS * s + 8 * (c & 15);
+            st16(&xs[buf * 32 * XP + (c >> 4) * XP + 8 * (c & 15)], k < g.K ? rx[i] : zero4);
+        }
 #pragma unroll
-        for (int i = 0; i < 2 * NL; ++i) { const int c = tid + 256 * i; st16(&as[buf * 32 * NL * XP + (c >> 4) * XP + 8 * (c & 15)], ra[i]); }
+        for (int i = 0; i < 2 * NL; ++i) {
+            const int c = tid + 256 * i, row = c >> 4, k = KS * s + 8 * (c & 15);
+            st16(&as[buf * 32 * NL * XP + (c >> 4) * XP + 8 * (c & 15)], (k < g.K && row < g.R) ? ra[i] : zero4);
+        }
     };
     f32x16 acc[NL];
 #pragma unroll
     for (int rb = 0; rb < NL; ++rb)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[rb][q] = 0.f;
-    issue(0); commit(0);
+    issue(0); commit(0, 0);
     __syncthreads();
     const int mrow = m0 + (lane & 31);                           // this lane's row of x (A-operand row)
     for (int s = 0; s < nstep; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nstep) issue(s + 1);
+        // requests without a branch around them (the last step re-requests its own tile and drops it); the fragment reads are
+        // tied behind the fence through `lrow` so that the requests are not sunk to the commit behind the MFMAs
+        issue(s + 1 < nstep ? s + 1 : s);
+        sched_fence();
+        const int lrow = opaque_i(lane & 31);
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             const int kk = 2 * wave + k2;
-            const u32x4 xf = ld16(&xs[buf * 32 * XP + (lane & 31) * XP + 16 * kk + 8 * h]);
+            const u32x4 xf = ld16(&xs[buf * 32 * XP + lrow * XP + 16 * kk + 8 * h]);
             const uint32_t e0 = (uint32_t)mrow * (uint32_t)g.K + (uint32_t)(KS * s + 16 * kk + 8 * h);
 #pragma unroll
             for (int rb = 0; rb < NL; ++rb) {
                 const u32x4 af = drop_apply8(xf, g.d.seed[rb], e0, g.d.thr16, g.d.inv_keep);
-                const u32x4 bf = ld16(&as[buf * 32 * NL * XP + (32 * rb + (lane & 31)) * XP + 16 * kk + 8 * h]);
+                const u32x4 bf = ld16(&as[buf * 32 * NL * XP + (32 * rb + lrow) * XP + 16 * kk + 8 * h]);
                 acc[rb] = mfma_32x32x16(af, bf, acc[rb]);
             }
         }
-        if (s + 1 < nstep) commit(buf ^ 1);
+        if (s + 1 < nstep) commit(buf ^ 1, s + 1);
         __syncthreads();
     }
     if (wave != 0) {

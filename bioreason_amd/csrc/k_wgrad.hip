@@ -29,7 +29,9 @@ constexpr int WG_YP = 128 + 8;      // LDS row pitch of the Y tile (elements): 2
 // one workgroup: 128 columns of Y x all R, over m in [blockIdx.y * m_chunk, + m_chunk); 4 waves x 32 columns
 // NL = live rank blocks (<= RB; the padding blocks of a fused projection hold zeros in T): compile-time, so that no branch
 // sits between the accumulators and their MFMAs
-template <int RB, int DROP, int NL = RB>
+// RM: C is [R, N] (dA: n is its contiguous index) — the accumulator lanes then run along n.  Compile-time: as a run-time select
+// between mfma(bf, af) and mfma(af, bf) it cost 16 accumulator-register moves and a full MFMA drain behind every MFMA
+template <int RB, int DROP, int NL = RB, int RM = 0>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
     // plain: the Y tile double-buffered.  DROP: one MASKED copy of the tile per live rank block (the mask is applied where a
     // thread holds 8 consecutive elements of a row — one hash per element pair, no exchange between lanes — and the fragment
@@ -49,6 +51,9 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
     // staging roles: Y tile 32 x 128 = 512 chunks of 16 bytes (2 per thread), T tile 32 x (32 RB) = 128 RB chunks
     const int yr = tid >> 4, yc = (tid & 15) * 8;                 // rows yr and yr + 16, column chunk yc
     const bool ycol_ok = n0 + yc + 8 <= g.N;
+    // issue = requests only, raw values; the out-of-range zeroing happens in commit.  (A `cond ? v : 0` on the loaded value
+    // inside issue, with issue under `if (s + 1 < nstep)`, made the compiler wait for the tile right there: the "prefetch" of
+    // step s + 1 completed before the MFMAs of step s started, i.e. latency + compute per step instead of their maximum.)
     u32x4 ry[2], rt[TPT];
     auto issue = [&](int s) {
         const int m0 = m_lo + 32 * s;
@@ -56,35 +61,38 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + yr + 16 * i;
             const int mc = m < g.M ? m : g.M - 1;
-            const u32x4 v = ld16(g.Y + (long)mc * g.ldy + (ycol_ok ? n0 + yc : 0));
-            ry[i] = (m < m_hi && ycol_ok) ? v : zero4;
+            ry[i] = ld16(g.Y + (long)mc * g.ldy + (ycol_ok ? n0 + yc : 0));
         }
 #pragma unroll
         for (int i = 0; i < TPT; ++i) {
             const int c = tid + 256 * i, tr = c / (4 * RB), tc = (c % (4 * RB)) * 8;
             const int m = m0 + (tr < 32 ? tr : 0);
             const int mc = m < g.M ? m : g.M - 1;
-            const u32x4 v = ld16(g.T + (long)mc * g.ldt + tc);
-            rt[i] = (m < m_hi && tr < 32) ? v : zero4;
+            rt[i] = ld16(g.T + (long)mc * g.ldt + tc);
         }
     };
     auto commit = [&](int buf, int s) {
+        const int m0 = m_lo + 32 * s;
+        u32x4 yv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) yv[i] = (m0 + yr + 16 * i < m_hi && ycol_ok) ? ry[i] : zero4;
         if (DROP) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const uint32_t e0 = (uint32_t)(m_lo + 32 * s + yr + 16 * i) * (uint32_t)g.N + (uint32_t)(n0 + yc);
 #pragma unroll
                 for (int rb = 0; rb < NL; ++rb)
-                    st16(&ys[rb][(yr + 16 * i) * WG_YP + yc], drop_apply8(ry[i], g.d.seed[rb], e0, g.d.thr16, g.d.inv_keep));
+                    st16(&ys[rb][(yr + 16 * i) * WG_YP + yc], drop_apply8(yv[i], g.d.seed[rb], e0, g.d.thr16, g.d.inv_keep));
             }
         } else {
-            st16(&ys[buf][yr * WG_YP + yc], ry[0]);
-            st16(&ys[buf][(yr + 16) * WG_YP + yc], ry[1]);
+            st16(&ys[buf][yr * WG_YP + yc], yv[0]);
+            st16(&ys[buf][(yr + 16) * WG_YP + yc], yv[1]);
         }
 #pragma unroll
         for (int i = 0; i < TPT; ++i) {
             const int c = tid + 256 * i, tr = c / (4 * RB), tc = (c % (4 * RB)) * 8;
-            if (tr < 32) st16(&ts[buf][tr * WG_TP + tc], rt[i]);
+            const int m = m0 + (tr < 32 ? tr : 0);
+            if (tr < 32) st16(&ts[buf][tr * WG_TP + tc], m < m_hi ? rt[i] : zero4);
         }
     };
 
@@ -96,11 +104,16 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
 
     if (nstep > 0) { issue(0); commit(0, 0); }
     __syncthreads();
-    const int ncol = wave * 32 + (lane & 31);       // this lane's Y column inside the tile (A row)
-    const bool r_major = g.c_sn == 1;               // C is [R, N] (dA): n is its contiguous index -> lanes along n in the epilogue
+    const int ncol0 = wave * 32 + (lane & 31);      // this lane's Y column inside the tile (A row)
+    constexpr bool r_major = RM != 0;               // C is [R, N] (dA): n is its contiguous index -> lanes along n in the epilogue
     for (int s = 0; s < nstep; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nstep) issue(s + 1);
+        // no branch around the requests (the last step re-requests its own tile and drops it); the fence is ordered behind them,
+        // and the fragment reads below are tied behind the fence through `ncol` (instruction selection would otherwise sink
+        // the requests to their first use, the commit after the MFMAs)
+        issue(s + 1 < nstep ? s + 1 : s);
+        sched_fence();
+        const int ncol = opaque_i(ncol0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int mb = 16 * kk + 8 * h;          // this lane's 8 consecutive m of the k = 16 step
@@ -173,10 +186,13 @@ static int wgrad_launch(WgradArgs& g, int m_chunk, bool drop, void* stream) {
     g.m_chunk = (m_chunk + 31) / 32 * 32;
     const dim3 grid((g.N + 127) / 128, (g.M + g.m_chunk - 1) / g.m_chunk);
     bra_stream_t st = (bra_stream_t)stream;
+    const bool rm = g.c_sn == 1;
 #define BRA_WG(RB_, NL_)                                                                          \
     do {                                                                                          \
-        if (drop) BRA_LAUNCH((wgrad_tn_kernel<RB_, 1, NL_>), grid, dim3(256), 0, st, g);          \
-        else BRA_LAUNCH((wgrad_tn_kernel<RB_, 0, RB_>), grid, dim3(256), 0, st, g);               \
+        if (drop && rm) BRA_LAUNCH((wgrad_tn_kernel<RB_, 1, NL_, 1>), grid, dim3(256), 0, st, g); \
+        else if (drop) BRA_LAUNCH((wgrad_tn_kernel<RB_, 1, NL_, 0>), grid, dim3(256), 0, st, g);  \
+        else if (rm) BRA_LAUNCH((wgrad_tn_kernel<RB_, 0, RB_, 1>), grid, dim3(256), 0, st, g);    \
+        else BRA_LAUNCH((wgrad_tn_kernel<RB_, 0, RB_, 0>), grid, dim3(256), 0, st, g);            \
     } while (0)
     if (g.R == 32) BRA_WG(1, 1);
     else if (g.R == 64) { if (drop && g.nb_live == 1) BRA_WG(2, 1); else BRA_WG(2, 2); }
