@@ -8,6 +8,15 @@ free functions (the trainer class itself cannot be imported: trl / peft / deepsp
   repeat_sampler_indices grpo_trainer.py:72-119 (RepeatRandomSampler)
   sample_next_token      HF warpers as configured at grpo_trainer.py:384-391
                          (TF:generation/logits_process.py:238 temperature, :473 top-p, :542 top-k)
+
+PINNED (round 3): tests/test_oracle_pinned.py holds every function above bit-equal to the reference's OWN statements — the
+cited lines are ast-extracted from grpo_trainer.py and executed unmodified against a stub `self` (oracle/ref_exec.py; whole
+`compute_loss` incl. its buffering branch and `_get_per_token_logps`, the EOS-mask and advantage statements of
+`_generate_and_score_completions`) on seeded inputs incl. num_iterations > 1, beta = 0, a row masked after its first token, a
+zero-std group and a group spanning two ranks — and `warp_probs` equal to softmax(TemperatureLogitsWarper -> TopKLogitsWarper ->
+TopPLogitsWarper) of the installed transformers (ties at the k-th value, top_p boundary, k > support).  The outputs of the
+reference statements are committed as tests/golden/grpo_ref.pt (oracle/make_grpo_golden.py), so the pin also holds on the GPU
+box, where /root/reference does not exist.
 """
 from __future__ import annotations
 
