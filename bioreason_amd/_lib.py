@@ -50,6 +50,19 @@ def parse_header(path: str = _HEADER) -> Dict[str, List[Tuple[str, str]]]:
     return protos
 
 
+BRA_ERR_ARG, BRA_ERR_UNSUPPORTED = -1, -2          # include/bioreason_hip.h
+
+
+class KernelError(RuntimeError):
+    """a C-ABI entry point returned a non-zero status; `.status` is the integer (negative: BRA_ERR_*, positive: hipError_t)"""
+
+    def __init__(self, name: str, status: int):
+        kind = {BRA_ERR_ARG: " (argument error)", BRA_ERR_UNSUPPORTED: " (unsupported shape / option)"}.get(
+            status, " (argument error)" if status < 0 else " (hipError_t)")
+        super().__init__(f"{name} failed with status {status}{kind}")
+        self.name, self.status = name, int(status)
+
+
 class KernelLibrary:
     def __init__(self, path: str, emulated: bool = False):
         if not os.path.exists(path):
@@ -76,9 +89,9 @@ class KernelLibrary:
         """like call(), but hands BRA_ERR_UNSUPPORTED (-2) back to the caller instead of raising"""
         try:
             return self.call(name, *args)
-        except RuntimeError as e:
-            if "status -2" in str(e):
-                return -2
+        except KernelError as e:
+            if e.status == BRA_ERR_UNSUPPORTED:
+                return BRA_ERR_UNSUPPORTED
             raise
 
     def call(self, name: str, *args) -> int:
@@ -103,7 +116,7 @@ class KernelLibrary:
                 conv.append(int(a))
         rc = f(*conv)
         if rc != 0:
-            raise RuntimeError(f"{name} failed with status {rc}" + (" (argument error)" if rc < 0 else " (hipError_t)"))
+            raise KernelError(name, rc)
         return rc
 
 

@@ -198,6 +198,11 @@ def _torch_load(path: str, trust_checkpoint: bool):
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
     except (pickle.UnpicklingError, RuntimeError, AttributeError) as e:
+        # only a refusal of the SAFE unpickler (non-tensor globals in the file) is an invitation to trust_checkpoint; a truncated
+        # or corrupt file must not steer the user towards arbitrary-code unpickling
+        refused = isinstance(e, pickle.UnpicklingError) or "weights_only" in str(e).lower() or "unsupported global" in str(e).lower()
+        if not refused:
+            raise
         if not trust_checkpoint:
             raise RuntimeError(f"bioreason_amd: '{path}' holds pickled objects besides tensors (a Lightning / DeepSpeed checkpoint). "
                                "Pass trust_checkpoint=True to load it with the full unpickler if you trust the file.") from e

@@ -53,12 +53,22 @@ def assistant_label_mask(input_ids: torch.Tensor, assistant_marker_ids: Sequence
 def qwen_dna_collate_fn(examples, processor, max_length_text: int, max_length_dna: int, return_answer_in_batch: bool = False):
     """`qwen_dna_collate_fn` of the reference (bioreason/dataset/kegg.py:223-333): chat template over each example's
     conversation -> DLProcessor (left padding) -> labels on the assistant sections only (`assistant_label_mask`) [-> answers].
-    trl's `maybe_apply_chat_template` is restated for the one shape the reference feeds it (a {"prompt": messages} example):
-    `apply_chat_template(messages, tokenize=False)` with the processor's template."""
+    trl's `maybe_apply_chat_template` (-> `apply_chat_template`, trl/data_utils.py) is restated for the shape the reference
+    feeds it, a {"prompt": messages} example: the last message decides — `continue_final_message=True` when it is the
+    assistant's (the SFT / kegg shape: the text ends AT the assistant content, no closing `<|im_end|>`), and
+    `add_generation_prompt=True` when it is the user's."""
     tok = processor.tokenizer
     kw = {"chat_template": processor.chat_template} if getattr(processor, "chat_template", None) is not None else {}
-    prompts_text = [ex["prompt"] if isinstance(ex["prompt"], str) else tok.apply_chat_template(ex["prompt"], tokenize=False, **kw)
-                    for ex in examples]
+
+    def render(messages):
+        last = messages[-1]["role"] if len(messages) else None
+        if last == "assistant":
+            return tok.apply_chat_template(messages, tokenize=False, continue_final_message=True, **kw)
+        if last == "user":
+            return tok.apply_chat_template(messages, tokenize=False, add_generation_prompt=True, **kw)
+        return tok.apply_chat_template(messages, tokenize=False, **kw)
+
+    prompts_text = [ex["prompt"] if isinstance(ex["prompt"], str) else render(ex["prompt"]) for ex in examples]
     batch = processor(text=prompts_text, batch_dna_sequences=[ex["dna_sequences"] for ex in examples], return_tensors="pt",
                       padding=True, padding_side="left", add_special_tokens=False, max_length_text=max_length_text,
                       max_length_dna=max_length_dna)

@@ -5,6 +5,8 @@ What is kept: the constructor arguments `reason.py:566-577` passes, the config f
 text path of a training step (dataset rows -> `dna_module.prepare_prompt` -> `prepare_model_inputs` (DLProcessor) -> rollout
 -> batch_decode -> python reward functions -> gathered advantages -> loss), rollout buffering across
 gradient-accumulation slots and `num_iterations`, the metric names of `log`, `train()`, `save_model()`.
+The learning rate follows HF `Trainer.create_scheduler`: `args.lr_scheduler_type` (default linear decay to 0), `warmup_steps` /
+`warmup_ratio`, over `max_steps` or epochs x optimiser steps per epoch — computed with transformers' own `get_scheduler`.
 What is not re-created (SURVEY §8b / §2 out of scope): the HF `Trainer` base class (callback bus, wandb, hub, evaluation
 loop, deepspeed / accelerate wrappers, model cards) and reward *models* (`reward_funcs` entries must be callables).
 LoRA: `peft_config` may be a peft `LoraConfig` or any object / dict with `r`, `lora_alpha`, `lora_dropout`
@@ -258,6 +260,26 @@ class DNALLMGRPOTrainer:
         os.makedirs(output_dir, exist_ok=True)
         torch.save(self.model.state_dict(), os.path.join(output_dir, "pytorch_model.bin"))
 
+    def _lr_schedule(self, num_training_steps: int) -> Callable[[int], float]:
+        """optimiser step -> learning rate exactly as HF `Trainer.create_scheduler` would set it: transformers' own
+        `get_scheduler(args.lr_scheduler_type, ..., args.get_warmup_steps(n), n)` stepped on a one-parameter stand-in
+        optimiser (the real update is the fused arena AdamW, which takes the rate per call)"""
+        from transformers.optimization import get_scheduler
+        a = self.args
+        opt = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=a.learning_rate)
+        sched = get_scheduler(a.lr_scheduler_type, optimizer=opt, num_warmup_steps=a.get_warmup_steps(num_training_steps),
+                              num_training_steps=num_training_steps,
+                              scheduler_specific_kwargs=getattr(a, "lr_scheduler_kwargs", None) or {})
+        rates: List[float] = []
+
+        def at(step: int) -> float:
+            while len(rates) <= step:                # rate in force for optimiser step len(rates), then advance as HF does
+                rates.append(float(sched.get_last_lr()[0]))
+                opt.step()
+                sched.step()
+            return rates[step]
+        return at
+
     def train(self, resume_from_checkpoint=None):
         a = self.args
         per_rank = a.per_device_train_batch_size
@@ -266,8 +288,14 @@ class DNALLMGRPOTrainer:
         t0 = time.time()
         done = False
         epochs = int(a.num_train_epochs) if max_steps is None else 10 ** 9
+        # ONE sampler for the whole run (Trainer.get_train_dataloader builds it once): its torch.Generator carries over, so every
+        # epoch is a new permutation of the same seeded stream, as in the reference
+        sampler = self._get_train_sampler()
+        gmb_ = per_rank * self.world
+        steps_per_epoch = max(1, (len(sampler) // gmb_) // ga)
+        total = max_steps if max_steps is not None else max(1, int(a.num_train_epochs * steps_per_epoch))
+        self.runner.lr_schedule = self._lr_schedule(total)
         for epoch in range(epochs):
-            sampler = self._get_train_sampler()
             stream = list(iter(sampler))
             # accelerate's sharding of the sampler stream: consecutive global micro-batches, rank r takes slice r
             gmb = per_rank * self.world
@@ -279,7 +307,8 @@ class DNALLMGRPOTrainer:
                 if self.runner.global_step != step_before:
                     gs = self.runner.global_step
                     if a.logging_steps and (gs % max(1, int(a.logging_steps)) == 0 or (a.logging_first_step and gs == 1)):
-                        self.log({"loss": float(loss), "epoch": epoch + lo / max(1, len(stream))})
+                        self.log({"loss": float(loss), "learning_rate": self.runner.last_lr,
+                                  "epoch": epoch + lo / max(1, len(stream))})
                     if a.save_steps and a.save_strategy != "no" and gs % int(a.save_steps) == 0:
                         for cb in self.callbacks:
                             if hasattr(cb, "on_save"):

@@ -75,10 +75,17 @@ def token_stat_rewards(completion_ids: torch.Tensor, completion_mask: torch.Tens
 
 def text_reward_fn(processing_class, reward_funcs: List[Callable], prompts=None, extra: Optional[Dict[str, list]] = None) -> Callable:
     """The reference's reward hop (grpo_trainer.py:643-676): completion ids -> host -> batch_decode -> python reward
-    functions on conversational completions -> [B, F] fp32 back on the device."""
+    functions -> [B, F] fp32 back on the device.  Completions are wrapped as one-message conversations only for conversational
+    prompts (`is_conversational(inputs[0])`, :646-649: the prompt is a list of role / content messages); plain-string prompts
+    hand the reward functions plain strings."""
+    conversational = bool(prompts) and isinstance(prompts[0], (list, tuple)) and len(prompts[0]) > 0 \
+        and isinstance(prompts[0][0], dict) and "role" in prompts[0][0] and "content" in prompts[0][0]
+    if prompts is None:
+        conversational = True              # synthetic runs without a prompt column: the shape reason.py's reward functions take
+
     def fn(completion_ids: torch.Tensor, completion_mask: torch.Tensor) -> torch.Tensor:
         texts = processing_class.batch_decode(completion_ids.cpu(), skip_special_tokens=True)
-        completions = [[{"role": "assistant", "content": t}] for t in texts]
+        completions = [[{"role": "assistant", "content": t}] for t in texts] if conversational else texts
         cols = [f(prompts=prompts, completions=completions, **(extra or {})) for f in reward_funcs]
         return torch.tensor(cols, dtype=torch.float32).t().contiguous().to(completion_ids.device)
     return fn
@@ -185,6 +192,9 @@ class GRPOStepRunner(_DataParallelStep):
         if hasattr(model.text_model, "set_dropout_seed"):          # every rank draws its own LoRA dropout masks, as separate
             model.text_model.set_dropout_seed(cfg.seed * 1000003 + self.rank)   # processes with their own RNG streams do
         self.rollout_profile: Dict[str, float] = {}      # filled by step(timing=True): phases inside generate(), ms
+        # optimiser step index -> learning rate (HF Trainer.create_scheduler, set by DNALLMGRPOTrainer); None = constant cfg.learning_rate
+        self.lr_schedule: Optional[Callable[[int], float]] = None
+        self.last_lr = cfg.learning_rate
 
     # ---- _generate_and_score_completions (:535-749) ---------------------------------------------------------------
     def generate_and_score(self, batch: Dict, timing: bool = False, mark=lambda n: None) -> Dict:
@@ -290,7 +300,9 @@ class GRPOStepRunner(_DataParallelStep):
                 local3 = m.arena.grad(METRIC_SLOT).view(-1)[:3] * scale
             else:
                 local3 = stats
-            m.arena.adamw_step(c.learning_rate, (c.adam_beta1, c.adam_beta2), c.adam_epsilon, c.weight_decay,
+            lr = c.learning_rate if self.lr_schedule is None else float(self.lr_schedule(self.global_step))
+            self.last_lr = lr
+            m.arena.adamw_step(lr, (c.adam_beta1, c.adam_beta2), c.adam_epsilon, c.weight_decay,
                                max_grad_norm=c.max_grad_norm, grad_scale=scale)
             self.global_step += 1
             out["metrics_t"] = torch.cat([inputs["roll_metrics"], local3.detach().clone()])

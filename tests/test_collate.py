@@ -132,3 +132,35 @@ def test_qwen_dna_collate_fn_end_to_end(tmp_path):
     lab_tokens = [tok.convert_ids_to_tokens(int(t)) for t in labels[0][labels[0] != -100]]
     assert "ALS" in lab_tokens and "Answer:" in lab_tokens and "Q" not in lab_tokens and "<|im_end|>" not in lab_tokens
     assert (labels[ids == tok.pad_token_id] == -100).all()
+
+
+def test_collate_renders_like_trl_maybe_apply_chat_template(tmp_path):
+    """trl's apply_chat_template on a {"prompt": messages} example: last role assistant -> continue_final_message (the text
+    ends at the assistant content, no closing <|im_end|>), last role user -> add_generation_prompt"""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import EsmTokenizer, GPT2TokenizerFast
+    from bioreason_amd.chat_template import CHAT_TEMPLATE
+    from bioreason_amd.collate import qwen_dna_collate_fn
+    from bioreason_amd.processing import DLProcessor
+    words = ["<|endoftext|>", "[UNK]", "<|im_start|>", "<|im_end|>", "user", "assistant", "Q", "ALS", "<think>", "</think>"]
+    tk = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="[UNK]"))
+    tk.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    tok = GPT2TokenizerFast(tokenizer_object=tk, eos_token="<|endoftext|>", unk_token="[UNK]")
+    tok.add_special_tokens({"additional_special_tokens": ["<|dna_start|>", "<|dna_pad|>", "<|dna_end|>", "<|im_start|>", "<|im_end|>"]})
+    tok.chat_template = CHAT_TEMPLATE
+    vf = tmp_path / "vocab.txt"
+    vf.write_text("\n".join(["<cls>", "<pad>", "<eos>", "<unk>", "A", "C", "G", "T", "N", "<mask>"]))
+    proc = DLProcessor(tokenizer=tok, dna_tokenizer=EsmTokenizer(str(vf)))
+    sft = [{"role": "user", "content": [{"type": "text", "text": " Q "}]}, {"role": "assistant", "content": [{"type": "text", "text": " ALS "}]}]
+    usr = sft[:1]
+    out = qwen_dna_collate_fn([{"prompt": sft, "dna_sequences": []}, {"prompt": usr, "dna_sequences": []}], proc, 64, 8)
+    im_end, im_start, als = (tok.convert_tokens_to_ids(t) for t in ("<|im_end|>", "<|im_start|>", "ALS"))
+    row0 = out["input_ids"][0][out["attention_mask"][0].bool()].tolist()
+    row1 = out["input_ids"][1][out["attention_mask"][1].bool()].tolist()
+    assert row0[-1] == als and row0.count(im_end) == 1                 # ends AT the assistant content: only the user turn is closed
+    want0 = tok.apply_chat_template(sft, tokenize=False, continue_final_message=True)
+    want1 = tok.apply_chat_template(usr, tokenize=False, add_generation_prompt=True)
+    assert row0 == tok(want0, add_special_tokens=False)["input_ids"] and row1 == tok(want1, add_special_tokens=False)["input_ids"]
+    assert row1.count(im_start) == 2 and tok.convert_tokens_to_ids("assistant") in row1[-3:]      # generation prompt appended
+    lab = out["labels"][0]
+    assert lab[lab != -100].tolist()[-1] == als

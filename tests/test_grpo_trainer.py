@@ -177,3 +177,89 @@ def test_old_logps_path_matches_oracle_math(backend):
     want, _, _ = GM.grpo_loss(lp, old, ref, adv, mask.float(), 0.2, 0.3, 0.04)
     got, stats = grpo.grpo_loss(lp.to(dev).requires_grad_(True), old.to(dev), ref.to(dev), adv.to(dev), mask.to(dev), 0.2, 0.3, 0.04)
     assert abs(got.item() - want.item()) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- host logic of the trainer shell
+class _Args:
+    """the TrainingArguments fields `_lr_schedule` reads"""
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def get_warmup_steps(self, n):
+        import math
+        return self.warmup_steps if self.warmup_steps > 0 else math.ceil(n * self.warmup_ratio)
+
+
+@pytest.mark.parametrize("kind,warmup_steps,warmup_ratio", [("linear", 0, 0.0), ("linear", 3, 0.0), ("cosine", 0, 0.1),
+                                                            ("constant", 0, 0.0), ("constant_with_warmup", 2, 0.0)])
+def test_lr_schedule_equals_hf_get_scheduler(kind, warmup_steps, warmup_ratio):
+    """the rate handed to the fused AdamW at optimiser step s is the one HF Trainer's scheduler has in force at s
+    (Trainer.create_scheduler -> get_scheduler; default `linear`: decay to 0 over the run, after warm-up)"""
+    from transformers.optimization import get_scheduler
+    from bioreason_amd.grpo_trainer import DNALLMGRPOTrainer
+    a = _Args(learning_rate=2e-4, lr_scheduler_type=kind, warmup_steps=warmup_steps, warmup_ratio=warmup_ratio, lr_scheduler_kwargs={})
+    n = 20
+    sched = DNALLMGRPOTrainer._lr_schedule(type("T", (), {"args": a})(), n)
+    opt = torch.optim.AdamW([torch.zeros(1, requires_grad=True)], lr=a.learning_rate)
+    ref = get_scheduler(kind, optimizer=opt, num_warmup_steps=a.get_warmup_steps(n), num_training_steps=n)
+    want = []
+    for _ in range(n):
+        want.append(opt.param_groups[0]["lr"])      # the rate the optimiser uses for this step
+        opt.step()
+        ref.step()
+    got = [sched(s) for s in range(n)]
+    assert got == pytest.approx(want, rel=0, abs=1e-12)
+    assert sched(7) == got[7]                        # random access after the fact
+    if kind == "linear" and warmup_steps == 0:
+        assert got[0] == a.learning_rate and got[-1] == pytest.approx(a.learning_rate / n) and got[10] < got[5]
+    if kind == "constant":
+        assert all(g == a.learning_rate for g in got)
+
+
+def test_sampler_generator_state_carries_across_epochs():
+    """ONE sampler per run: iterating it again continues its generator (a new permutation per epoch, as the reference's
+    dataloader does); re-creating it per epoch would replay the first permutation"""
+    from bioreason_amd.grpo_trainer import RepeatRandomSampler
+    s = RepeatRandomSampler(range(16), 1, 1, 1, seed=5)
+    e0, e1 = list(s), list(s)
+    assert sorted(e0) == sorted(e1) == list(range(16)) and e0 != e1
+    assert list(RepeatRandomSampler(range(16), 1, 1, 1, seed=5)) == e0
+    import inspect
+    from bioreason_amd import grpo_trainer as GT
+    src = inspect.getsource(GT.DNALLMGRPOTrainer.train)
+    assert src.index("_get_train_sampler()") < src.index("for epoch in range")
+
+
+def test_text_reward_fn_wraps_only_conversational_prompts():
+    """grpo_trainer.py:643-650: `is_conversational(inputs[0])` decides whether completions are [{role, content}] or strings"""
+    from bioreason_amd.trainer import text_reward_fn
+
+    class Proc:
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return [f"t{int(r[0])}" for r in ids]
+    seen = []
+
+    def rf(prompts, completions, **kw):
+        seen.append(completions)
+        return [1.0] * len(completions)
+    ids = torch.tensor([[3, 1], [4, 1]])
+    conv = [[{"role": "user", "content": "q"}]] * 2
+    out = text_reward_fn(Proc(), [rf], prompts=conv)(ids, torch.ones_like(ids))
+    assert seen[-1] == [[{"role": "assistant", "content": "t3"}], [{"role": "assistant", "content": "t4"}]] and out.shape == (2, 1)
+    text_reward_fn(Proc(), [rf], prompts=["plain q", "plain q"])(ids, torch.ones_like(ids))
+    assert seen[-1] == ["t3", "t4"]
+
+
+def test_call_rc_compares_the_status_for_equality():
+    from bioreason_amd._lib import BRA_ERR_UNSUPPORTED, KernelError, KernelLibrary
+    lib = KernelLibrary.__new__(KernelLibrary)
+    for status, raises in [(-2, False), (-20, True), (-1, True), (2, True)]:
+        def call(name, *a, _s=status):
+            raise KernelError(name, _s)
+        lib.call = call
+        if raises:
+            with pytest.raises(KernelError) as ei:
+                lib.call_rc("bra_x")
+            assert ei.value.status == status
+        else:
+            assert lib.call_rc("bra_x") == BRA_ERR_UNSUPPORTED
