@@ -1,14 +1,14 @@
 #!/bin/bash
-# Evidence of the bench configuration, collected on the GPU box:  tools/collect_evidence.sh <tag>   (e.g. r2_c)
+# Evidence of the bench configuration, collected on the GPU box:  tools/collect_evidence.sh <tag>   (e.g. r3_a)
 #   profiles/<tag>_bench.json                 the bench line (default command, CPU baseline included unless NOCPU=1)
 #   profiles/<tag>_bench_kernel_stats.csv     rocprofv3 --kernel-trace --stats of `bench.py --steps 1 --warmup 1` (3 steps in the trace)
 #   profiles/<tag>_pmc_*.csv                  separate rocprofv3 --pmc passes on the SAME command (FETCH_SIZE | WRITE_SIZE | SQ busy counters)
 #   profiles/<tag>_pmc_gemm.json              dominant-kernel traffic per launch + the kernel-source hash bench.py checks
-tag=${1:-r2_x}
+tag=${1:-r3_x}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 out=$R/gpurun_out/evidence_$tag; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary"
 if [ "$PMC_ONLY" = "1" ]; then :      # only the counter passes (the bench line and the kernel stats of this state exist already)
 elif [ "$NOCPU" = "1" ]; then timeout 300 python $R/bench.py --no-cpu-baseline --steps 5 2>/dev/null | tail -1 > $out/${tag}_bench.json
 else timeout 600 python $R/bench.py --steps 5 2>/dev/null | tail -1 > $out/${tag}_bench.json; fi
@@ -31,7 +31,7 @@ def pick(rs, counter, key):
 h = hashlib.sha256()
 for f in ("k_gemm.hip", "bra_device.h"):
     h.update(open(os.path.join(R, "bioreason_amd", "csrc", f), "rb").read())
-res = {"kernel_source_sha": h.hexdigest()[:16], "command": "bench.py --steps 1 --warmup 1 --no-cpu-baseline (the timed configuration, 3 steps traced)",
+res = {"kernel_source_sha": h.hexdigest()[:16], "command": "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary (the timed configuration, 3 GRPO steps traced)",
        "fetch_correction": 2.0, "kernels": {}}
 tot_b, tot_n = 0.0, 0
 for key in ("gemm_ring_kernel<0", "gemm_glds_kernel<0"):
@@ -42,8 +42,21 @@ for key in ("gemm_ring_kernel<0", "gemm_glds_kernel<0"):
         res["kernels"][key] = {"dispatches": n, "fetch_kb_raw": fk, "write_kb_raw": wk, "traffic_bytes_per_launch": b}
         tot_b += b * n; tot_n += n
 if tot_n:
-    res["traffic_bytes_per_launch"] = tot_b / tot_n
+    # ONE denominator: bench.py's `algorithmic_bytes_per_launch` is per API call (bra_gemm_bf16_nt; a row-split call = one ring
+    # dispatch + one 256x128 dispatch), so the traffic is divided by API calls too: calls per step from the bench line of this tag
+    # (roofline.launches / steps) x the 3 steps in the trace.  The per-dispatch figure is kept beside it, labelled.
+    res["traffic_bytes_total_3_steps"] = tot_b
     res["dispatches"] = tot_n
+    res["traffic_bytes_per_dispatch"] = tot_b / tot_n
+    try:
+        bl = json.load(open(os.path.join(out, f"{tag}_bench.json")))
+        calls_per_step = bl["roofline"]["launches"] / bl["steps"]
+        res["api_calls_per_step"] = calls_per_step
+        res["traffic_bytes_per_call"] = tot_b / (3.0 * calls_per_step)
+        res["algorithmic_bytes_per_call"] = bl["roofline"]["algorithmic_bytes_per_launch"]
+        res["traffic_over_algorithmic"] = res["traffic_bytes_per_call"] / max(res["algorithmic_bytes_per_call"], 1.0)
+    except Exception as e:
+        res["traffic_bytes_per_call_error"] = repr(e)
 sq = rows("SQ_BUSY_CYCLES")
 for key in ("gemm_ring_kernel<0", "gemm_glds_kernel<0", "attn_fwd_kernel<128", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel<128, 2", "dec_gemm2_kernel<0, 2, 1", "dec_attn_items_kernel", "dec_attn_merge_kernel"):
     busy, mfma = pick(sq, "SQ_BUSY_CYCLES", key), pick(sq, "SQ_VALU_MFMA_BUSY_CYCLES", key)
