@@ -143,6 +143,9 @@ def cpu_baseline(mode: str = "grpo"):
               num_key_value_heads=8, head_dim=128, rope_theta=1e6, max_position_embeddings=40960)
     dc = dict(vocab_size=4107, hidden_size=1024, intermediate_size=4096, num_hidden_layers=29, num_attention_heads=16,
               max_position_embeddings=2050)
+    if os.environ.get("BENCH_CPU_TINY") == "1":           # code-path smoke test of this leg (tests/): 2-layer modules, same shapes of input
+        tc.update(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=16)
+        dc.update(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2)
     from transformers.initialization import no_init_weights
     with no_init_weights():
         text = O.make_qwen3(tc, "sdpa").to(torch.bfloat16)

@@ -660,7 +660,11 @@ extern "C" int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, 
     return BRA_ERR_UNSUPPORTED;
 }
 
+#ifdef BRA_EMU
 static unsigned long long* g_debug_probe = nullptr;
+#else
+static std::atomic<unsigned long long*> g_debug_probe{nullptr};        // diagnostics knob (include/bioreason_hip.h)
+#endif
 extern "C" int bra_debug_set_probe(void* p) { g_debug_probe = (unsigned long long*)p; return 0; }
 
 extern "C" int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT,
@@ -676,9 +680,9 @@ extern "C" int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, co
     const int npc = (P + 63) / 64, ncc = (t + 64) / 64, ntot = npc + ncc;
     DecSharedArgs s = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, cosT, sinT, pos, (const bf16_t*)kp, kp_sr, kp_sh, kp_ss,
                        (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask, part_o, part_ml, R, copies, Hq, Hkv, P,
-                       ntot, eps, scale, t_dev, g_debug_probe, rope_rows};
+                       ntot, eps, scale, t_dev, (unsigned long long*)g_debug_probe, rope_rows};
     DecAttnArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, (bf16_t*)kc,
-                     (bf16_t*)vc, nullptr, part_o, part_ml, B, Hq, Hkv, C, t, ncc, eps, scale, npc, ntot, t_dev, g_debug_probe, rope_rows};
+                     (bf16_t*)vc, nullptr, part_o, part_ml, B, Hq, Hkv, C, t, ncc, eps, scale, npc, ntot, t_dev, (unsigned long long*)g_debug_probe, rope_rows};
     bra_stream_t st = (bra_stream_t)stream;
     const dim3 grid(npc * Hkv * R + ncc * Hq * B);
 #define BRA_DB(HD_, G_)                                                                         \

@@ -945,13 +945,24 @@ static int launch_skinny(const GemmArgs& g, int out_f32, bra_stream_t stream) {
 
 // tile variant: bit 0 = register prefetch depth 2, bit 1 = 256-row tiles (8 waves).  Chosen per call by
 // pick_variant(); bra_gemm_set_variant(v >= 0) pins it (tuning / A-B measurements only).
-static int g_forced_variant = -1;
-static int ring_min_fill_pct = 75;
-static int ring_two_phase = 1;
-static int ring_row_split = 1;
+// process-wide test / benchmark knobs (include/bioreason_hip.h): atomics, so that a launch racing a setter reads a whole value
+#ifdef BRA_EMU
+template <typename T> struct knob_t { T v; explicit knob_t(T x) : v(x) {} operator T() const { return v; } knob_t& operator=(T x) { v = x; return *this; } };
+#else
+template <typename T> struct knob_t {
+    std::atomic<T> v;
+    explicit knob_t(T x) : v(x) {}
+    operator T() const { return v.load(std::memory_order_relaxed); }
+    knob_t& operator=(T x) { v.store(x, std::memory_order_relaxed); return *this; }
+};
+#endif
+static knob_t<int> g_forced_variant(-1);
+static knob_t<int> ring_min_fill_pct(75);
+static knob_t<int> ring_two_phase(1);
+static knob_t<int> ring_row_split(1);
 
 static int pick_variant(const GemmArgs& g) {
-    if (g_forced_variant >= 0) return g_forced_variant >= 6 ? 6 : g_forced_variant;
+    { const int fv = g_forced_variant; if (fv >= 0) return fv >= 6 ? 6 : fv; }
     // measured on MI355X (profiles/r1_gemm_variants.txt): the LDS-DMA kernel with skewed fragment reads wins on every
     // large-M shape of the path (850-1130 TFLOP/s vs 640-870 for the register-staged 128x128 kernel); it needs
     // K % 64 == 0 and enough 256x128 tiles to fill the chip, otherwise the 128x128 kernel keeps more CUs busy

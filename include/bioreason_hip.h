@@ -14,7 +14,11 @@
  *   - every function returns 0 on success, a positive hipError_t if the launch
  *     failed, or a negative BRA_ERR_* for a rejected argument; nothing throws,
  *     nothing allocates, nothing synchronises; workspaces come from the caller.
- *   - all functions are re-entrant (no global mutable state).
+ *   - all compute entry points are re-entrant and thread-safe.  The ONLY process-wide mutable state is four test /
+ *     benchmark knobs — bra_gemm_set_variant, bra_gemm_set_ring_fill, bra_gemm_set_row_split, bra_debug_set_probe —
+ *     held in atomics (a concurrent launch sees the old or the new value, never a torn one), an init-once
+ *     "dynamic LDS opted in" flag per kernel and device, and an init-once device-properties cache.  The knobs select
+ *     between bit-identical tilings (results do not depend on them); production callers never touch them.
  */
 #ifndef BIOREASON_HIP_H
 #define BIOREASON_HIP_H
@@ -333,6 +337,17 @@ int bra_group_advantage(const float* rewards, int N, int F, int G, float* adv, f
 /* compute_loss (grpo_trainer.py:786-814): out3 = {loss, mean_kl, clip_ratio}; dlogp = dloss/dlogp */
 int bra_grpo_loss(const float* logp, const float* old_logp, const float* ref_logp, const float* adv, const int* mask,
                   int B, int C, float eps_lo, float eps_hi, float beta, float* out3, float* dlogp, void* stream);
+
+/* ---- persistent-grid building blocks (k_persist.hip, bra_gridsync.h) -------------------------------------------------
+ * In-launch grid barrier + write-through hand-off used by the persistent decode step (the body of HF's `_sample` loop,
+ * TF:generation/utils.py:2876-2925, kept inside one launch).  bra_gridsync_bytes: size of the synchronisation record the
+ * caller provides.  bra_gridbar_probe: `iters` x {publish 128 B per workgroup, grid barrier, read and word-check every slot}
+ * on `nwg` resident workgroups (mode 0 barrier only, 1 sc1 write-through protocol, 2 fence protocol, 3 protocol 1 with
+ * `wchunks` x 16 B per thread of a read-once stream prefetched across the barrier); errs[0] = mismatching words, errs[1] =
+ * barriers completed; every spin is bounded by `timeout_us` (the record's error word is set instead of hanging). */
+int bra_gridsync_bytes(void);
+int bra_gridbar_probe(void* sync, void* buf, void* errs, const void* wts, long wts_bytes, int nwg, int iters, int mode,
+                      int wchunks, int timeout_us, void* stream);
 
 #ifdef __cplusplus
 }

@@ -947,3 +947,36 @@ def test_sampler_fused_embed_with_twelve_rows(backend):
     assert out2.tolist() == out.tolist()
     assert torch.equal(x.cpu(), E[out2.long()].cpu())
     assert rel(ss[:B, 0], (x.float() ** 2).sum(1)) < 1e-5 and float(ss[:B, 1:].abs().max()) == 0 and float(ss[B:].min()) == 7.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,R,nlive,what", [(2048, 128, 3, "q/k/v"), (2048, 64, 1, "o"), (2048, 64, 2, "gate/up"), (6144, 64, 1, "down")])
+def test_lora_dropout_kernels_at_bench_shapes(hip_device, K, R, nlive, what):
+    """the dropout kernels of the policy pass at the shapes bench.py runs them (M = 8 x 2436 = 19 488 rows, p = 0.05, rank padded to
+    64 / 128 with 1-3 live 32-column blocks): lora_down_drop / lora_up_drop / wgrad_tn(drop=...) against fp32 torch ON THE GPU with the
+    masks the kernels regenerate exported by bra_dropout_mask (the small-M parametrisations above top out at M = 130)"""
+    dev = hip_device
+    M, p = 8 * 2436, 0.05
+    seeds = [101, 202, 303][:nlive]
+    x, A, dts = rnd(M, K, dev=dev, seed=1), rnd(R, K, dev=dev, scale=K ** -0.5, seed=2), rnd(M, R, dev=dev, seed=3)
+    A[32 * nlive:] = 0
+    dts[:, 32 * nlive:] = 0
+    masks = [ops.dropout_mask(M, K, p, seeds[j], dev).float() for j in range(nlive)]
+    keep = torch.stack(masks).mean().item()
+    assert abs(keep - (1 - p)) < 2e-3, keep                              # 40-120 M draws: the keep rate is tight
+    xd = [(x.float() * mk / (1 - p)).to(BF).float() for mk in masks]     # torch: scale in fp32, round once
+    Af = A.float()
+    t = ops.lora_down_drop(x, A, 2.0, p, seeds)
+    want_t = torch.zeros(M, R, device=dev)
+    for j in range(nlive):
+        want_t[:, 32 * j:32 * j + 32] = 2.0 * xd[j] @ Af[32 * j:32 * j + 32].T
+    assert rel(t, want_t.to(BF)) < 4e-3 and (t[:, 32 * nlive:] == 0).all(), what
+    up = ops.lora_up_drop(dts, A.T.contiguous(), p, seeds)
+    want_up = sum((dts.float()[:, 32 * j:32 * j + 32] @ Af[32 * j:32 * j + 32]) * masks[j] / (1 - p) for j in range(nlive))
+    assert rel(up, want_up.to(BF)) < 4e-3, what
+    dA = torch.zeros(R, K, device=dev)
+    ops.wgrad_tn(x, dts, dA, transposed_out=True, drop=(p, seeds))
+    want_dA = torch.zeros(R, K, device=dev)
+    for j in range(nlive):
+        want_dA[32 * j:32 * j + 32] = dts.float()[:, 32 * j:32 * j + 32].T @ xd[j]
+    assert rel(dA, want_dA) < 2e-4 and (dA[32 * nlive:] == 0).all(), what       # fp32 atomics over 19 488 rows: summation order
