@@ -9,8 +9,7 @@ from bioreason_amd._lib import get_lib, current_stream
 dev = torch.device("cuda:0")
 lib = get_lib()
 nwg = torch.cuda.get_device_properties(0).multi_processor_count
-sync = torch.zeros(lib.call_rc("bra_gridsync_bytes") or 2048, dtype=torch.uint8, device=dev)
-sync = torch.zeros(2048, dtype=torch.uint8, device=dev)
+sync = torch.zeros(2048, dtype=torch.uint8, device=dev)          # >= bra_gridsync_bytes() = 1152
 buf = torch.zeros(2 * nwg * 32, dtype=torch.int32, device=dev)
 errs = torch.zeros(4, dtype=torch.int32, device=dev)
 wts = torch.randint(0, 2 ** 31 - 1, (1 << 28,), dtype=torch.int32, device=dev)      # 1 GiB: past the 256 MiB Infinity Cache
