@@ -98,4 +98,44 @@ __device__ __forceinline__ bool grid_barrier(GridSync* gs, unsigned& epoch, int 
 }
 #endif  // !BRA_EMU
 
+// Access policy of code shared between the launched kernels and the persistent step: XS = 0 plain accesses (the operand was
+// produced by an EARLIER launch), XS = 1 sc1 accesses (produced / consumed by other workgroups of THIS launch).  `base` must be
+// wave-uniform (it becomes a buffer resource), `byte_off` < 2^31 is the lane's offset.
+template <int XS> __device__ __forceinline__ u32x4 xld16(const void* base, unsigned byte_off) {
+#ifndef BRA_EMU
+    if constexpr (XS != 0) return xs_load16(xs_rsrc(base), byte_off);
+#endif
+    return ld16(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <int XS> __device__ __forceinline__ u32x2 xld8(const void* base, unsigned byte_off) {
+#ifndef BRA_EMU
+    if constexpr (XS != 0) return xs_load8(xs_rsrc(base), byte_off);
+#endif
+    return ld8(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <int XS> __device__ __forceinline__ float xld4f(const void* base, unsigned byte_off) {
+#ifndef BRA_EMU
+    if constexpr (XS != 0) return xs_load4f(xs_rsrc(base), byte_off);
+#endif
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <int XS> __device__ __forceinline__ void xst16(void* base, unsigned byte_off, const u32x4& v) {
+#ifndef BRA_EMU
+    if constexpr (XS != 0) { xs_store16(xs_rsrc(base), byte_off, v); return; }
+#endif
+    st16(reinterpret_cast<char*>(base) + byte_off, v);
+}
+template <int XS> __device__ __forceinline__ void xst8(void* base, unsigned byte_off, const u32x2& v) {
+#ifndef BRA_EMU
+    if constexpr (XS != 0) { xs_store8(xs_rsrc(base), byte_off, v); return; }
+#endif
+    st8(reinterpret_cast<char*>(base) + byte_off, v);
+}
+template <int XS> __device__ __forceinline__ void xst4f(void* base, unsigned byte_off, float v) {
+#ifndef BRA_EMU
+    if constexpr (XS != 0) { xs_store4f(xs_rsrc(base), byte_off, v); return; }
+#endif
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 }  // namespace bra

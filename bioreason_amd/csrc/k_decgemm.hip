@@ -13,107 +13,10 @@
 //   * N = hidden projections (o_proj, down_proj) use 8-column workgroups so that 256 workgroups exist, and fill the
 //     16x16x32 MFMA by putting two K-halves on the two row halves of A and B ("diagonal" mode): the products
 //     C[j][b] and C[j+8][b+8] are the two K-halves of output (b, j); all 64 lanes stream weights.
-#include "bra_device.h"
+#include "bra_decgemm.h"
 #include "bra_api_internal.h"
 
 namespace bra {
-
-struct DecGemm2Args {
-    const bf16_t* x; long ldx;          // [M, K]
-    const float* ss_in; int nss_in;     // NORM: partial sums of squares of the rows of x, [8][nss_in] ([16][nss_in] for M > 8)
-    const bf16_t* nw; float eps;        // NORM: RMSNorm weight [K]
-    const bf16_t* W; long ldw;          // [N, K]
-    const bf16_t* res; long ldres;      // [M, N] or null
-    void* out; long ldo;                // bf16 [M, N] | bf16 [M, N/2] (ACT) | f32 [M, N]
-    float* ss_out; int nss_out;         // partial sums of squares of the bf16 outputs, [8 | 16][nss_out], column = workgroup
-    int M, N, K;
-    int packed;                         // W is in fragment order (bra_dec_pack_weights): [tile][k-step][lane][8]
-    unsigned long long* probe;          // optional timing probe (tools/dec_overhead_probe.py): 8 stamps per probed workgroup
-};
-
-// 100 MHz wall clock (s_memrealtime); the probe is compiled in but costs one uniform branch per stamp when unused
-#ifdef BRA_EMU
-__device__ __forceinline__ void dg2_stamp(const DecGemm2Args&, int) {}
-#else
-__device__ __forceinline__ void dg2_stamp(const DecGemm2Args& g, int slot) {
-    if (g.probe && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
-        g.probe[(blockIdx.x == 0 ? 0 : 8) + slot] = __builtin_amdgcn_s_memrealtime();
-}
-#endif
-
-__device__ __forceinline__ float silu_g(float x) { return x / (1.f + __expf(-x)); }
-
-// full-rate 24-bit multiply (v_mul_u32_u24; the 32- and 64-bit integer multiplies run at quarter rate): row index x leading dimension
-#ifdef BRA_EMU
-__device__ __forceinline__ unsigned dg2_mul24(int a, int b) { return ((unsigned)a & 0xffffffu) * ((unsigned)b & 0xffffffu); }
-#else
-__device__ __forceinline__ unsigned dg2_mul24(int a, int b) { return __umul24((unsigned)a, (unsigned)b); }
-#endif
-
-// epilogue of one column tile, executed by ONE wave on the K-reduced products v (lane: batch row fr, columns 4 fq .. + 3)
-// FULLN: N is a multiple of the tile width (always so with packed weights): no ragged last tile, every column test folds away
-template <int MODE, int ACT, int OUTF32, int FULLN = 0>
-__device__ __forceinline__ void dg2_epilogue(const DecGemm2Args& g, float (&v)[4], int tile, int lane, bool have_res,
-                                             const u32x2& resv) {
-    constexpr int NCOL = MODE ? 8 : 16;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = tile * NCOL;
-    const int N = FULLN ? 0x7fffffff : g.N;       // (column tests below read `N`)
-    if (MODE) {                                   // second K-half of (n, m) sits at (n + 8, m + 8) = lane + 40
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += wave_shfl(v[r], lane + 40);
-    }
-    const int m = fr;
-    if (ACT) {
-        // tile rows = [8 gate | 8 up] of features 8*tile .. 8*tile+7: lanes fq < 2 own gate, partners (lane ^ 32) up
-        float up[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) up[r] = wave_shfl_xor(v[r], 32);
-        if (fq < 2 && m < g.M) {
-            const int f0 = tile * 8 + 4 * fq;
-            float a[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = round_bf(silu_g(round_bf(v[r]))) * round_bf(up[r]);
-            u32x2 o; o.x = pack_bf2(a[0], a[1]); o.y = pack_bf2(a[2], a[3]);
-            st8((bf16_t*)g.out + (long)m * g.ldo + f0, o);
-        }
-        return;
-    }
-    const int n = n0 + 4 * fq;
-    const bool live = m < g.M && n < N && 4 * fq < NCOL && (!MODE || fr < 8);
-    if (OUTF32) {
-        if (live) {
-            float* cp = (float*)g.out + (long)m * g.ldo + n;
-            if (n + 3 < N && (g.ldo & 3) == 0) { f32x4 o = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(cp) = o; }
-            else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = v[r];
-        }
-        return;
-    }
-    float ss = 0.f;
-    if (g.res) {
-        if ((have_res || live) && n + 3 < N) {
-            u32x2 rr = resv;                              // first tile of the workgroup: requested with the weights
-            if (!have_res) rr = ld8(g.res + (long)m * g.ldres + n);         // later tiles (host: ldres % 4 == 0)
-            v[0] = round_bf(v[0]) + bf_lo(rr.x); v[1] = round_bf(v[1]) + bf_hi(rr.x);
-            v[2] = round_bf(v[2]) + bf_lo(rr.y); v[3] = round_bf(v[3]) + bf_hi(rr.y);
-        } else if (live) {
-            for (int r = 0; r < 4; ++r) if (n + r < N) v[r] = round_bf(v[r]) + bf2f(g.res[(long)m * g.ldres + n + r]);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { v[r] = round_bf(v[r]); if (live && n + r < N) ss += v[r] * v[r]; }
-    if (live) {
-        bf16_t* cp = (bf16_t*)g.out + (long)m * g.ldo + n;
-        if (n + 3 < N) { u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); st8(cp, o); }
-        else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(v[r]);
-    }
-    if (g.ss_out) {
-        if (!live) ss = 0.f;
-        ss += wave_shfl_xor(ss, 16);
-        ss += wave_shfl_xor(ss, 32);
-        if (fq == 0 && (!MODE || fr < 8) && m < g.M) g.ss_out[(long)m * g.nss_out + tile] = ss;
-    }
-}
 
 // MODE 0: 16 output columns per tile, 32 k per step.  MODE 1: 8 columns, 64 k per step (diagonal).
 // A workgroup walks the tiles blockIdx.x, + gridDim.x, ..: its waves split K, keep their (normalised) activation
