@@ -285,24 +285,34 @@ __device__ __forceinline__ void one_newkey(const DecOneArgs& a, const int b, con
 }
 
 // item `w` of the step, in dispatch order: the new-key items first (their q / k / v -> norm -> rotate -> dot chain is the longest
-// dependent chain), then the prompt chunks, then the completion chunks
-template <int HD, int G, int XS = 0>
-__device__ __forceinline__ void dec_attn_item(const DecOneArgs& a, int w) {
-    u32x4 kf[4][HD / 32], vf[HD / 16][2];
+// dependent chain), then the prompt chunks, then the completion chunks.  Everything in the descriptor is wave-uniform.
+struct DecItem {
+    int kind;                              // 0 nothing to do, 1 new key of (b, hq), 2 one 64-key chunk
+    int b, hq;                             // kind 1
+    const bf16_t* kbase; int kss; const bf16_t* vbase; int vsd; int key0, nkeys; const uint8_t* mask;      // kind 2
+    int r, hkv, row_lo, row_hi, slot;
+};
+
+template <int HD, int G>
+__device__ __forceinline__ void dec_item_decode(const DecOneArgs& a, int w, const int t, DecItem& d) {
     const int nK = a.R * a.copies * a.Hq;
     const int nP = a.npc * a.Hkv * a.R;
-    if (w >= nK && w < nK + nP) {              // prompt chunk: does not depend on t (no wait for the device-side step counter)
+    d.kind = 0;
+    if (w >= nK && w < nK + nP) {              // prompt chunk: does not depend on t
         w -= nK;
         const int q1 = da_div(w, a.inv_npc), c = w - q1 * a.npc;
         const int r = da_div(q1, a.inv_Hkv), hkv = q1 - r * a.Hkv;
-        one_item<HD, G, XS>(a, a.kp + r * a.kp_sr + hkv * a.kp_sh, (int)a.kp_ss, a.vtp + r * a.vt_sr + hkv * a.vt_sh, (int)a.vt_sd,
-                            c * 64, a.P, a.pmask ? a.pmask + (long)r * a.P : nullptr, r, hkv, 0, 16, c, kf, vf);
+        d.kind = 2;
+        d.kbase = a.kp + r * a.kp_sr + hkv * a.kp_sh; d.kss = (int)a.kp_ss;
+        d.vbase = a.vtp + r * a.vt_sr + hkv * a.vt_sh; d.vsd = (int)a.vt_sd;
+        d.key0 = c * 64; d.nkeys = a.P; d.mask = a.pmask ? a.pmask + (long)r * a.P : nullptr;
+        d.r = r; d.hkv = hkv; d.row_lo = 0; d.row_hi = 16; d.slot = c;
         return;
     }
-    const int t = a.t_ptr ? a.t_ptr[0] : a.t;
     if (w < nK) {
-        const int b = da_div(w, a.inv_Hq);
-        one_newkey<HD, G, XS>(a, b, w - b * a.Hq, t);
+        d.kind = 1;
+        d.b = da_div(w, a.inv_Hq);
+        d.hq = w - d.b * a.Hq;
         return;
     }
     {
@@ -310,11 +320,34 @@ __device__ __forceinline__ void dec_attn_item(const DecOneArgs& a, int w) {
         const int q1 = da_div(v, a.inv_ncc), c = v - q1 * a.ncc_grid;
         const int q2 = da_div(q1, a.inv_copies), copy = q1 - q2 * a.copies;
         const int r = da_div(q2, a.inv_Hkv), hkv = q2 - r * a.Hkv;
-        if (c * 64 >= t) return;                                 // (graph replay sizes the grid for the longest completion)
+        if (c * 64 >= t || r >= a.R) return;                     // (graph replay sizes the grid for the longest completion)
         const int b = r * a.copies + copy;
-        one_item<HD, G, XS>(a, a.kc + ((long)b * a.Hkv + hkv) * a.C * HD, HD, a.vct + ((long)b * a.Hkv + hkv) * HD * a.cp, (int)a.cp,
-                            c * 64, t, nullptr, r, hkv, copy * G, copy * G + G, a.npc + c, kf, vf);
+        d.kind = 2;
+        d.kbase = a.kc + ((long)b * a.Hkv + hkv) * a.C * HD; d.kss = HD;
+        d.vbase = a.vct + ((long)b * a.Hkv + hkv) * HD * a.cp; d.vsd = (int)a.cp;
+        d.key0 = c * 64; d.nkeys = t; d.mask = nullptr;
+        d.r = r; d.hkv = hkv; d.row_lo = copy * G; d.row_hi = copy * G + G; d.slot = a.npc + c;
     }
+}
+
+// PRE = 1: the chunk's K / V^T fragments were requested earlier (item_kv_issue on the same descriptor)
+template <int HD, int G, int XS, int PRE>
+__device__ __forceinline__ void dec_item_run(const DecOneArgs& a, const DecItem& d, const int t, u32x4 (&kf)[4][HD / 32], u32x4 (&vf)[HD / 16][2]) {
+    if (d.kind == 2)
+        one_item<HD, G, XS, PRE>(a, d.kbase, d.kss, d.vbase, d.vsd, d.key0, d.nkeys, d.mask, d.r, d.hkv, d.row_lo, d.row_hi, d.slot, kf, vf);
+    else if (d.kind == 1)
+        one_newkey<HD, G, XS>(a, d.b, d.hq, t);
+}
+
+template <int HD, int G, int XS = 0>
+__device__ __forceinline__ void dec_attn_item(const DecOneArgs& a, int w) {
+    u32x4 kf[4][HD / 32], vf[HD / 16][2];
+    const int nK = a.R * a.copies * a.Hq, nP = a.npc * a.Hkv * a.R;
+    // (a prompt chunk does not wait for the device-side step counter)
+    const int t = (w >= nK && w < nK + nP) ? 0 : (a.t_ptr ? a.t_ptr[0] : a.t);
+    DecItem d;
+    dec_item_decode<HD, G>(a, w, t, d);
+    dec_item_run<HD, G, XS, 0>(a, d, t, kf, vf);
 }
 
 // one wave per (sequence, q-head): slots [0, npc + ceil(t / 64)] -> o.  Lane (p = lane / LR, d4 = lane % LR) owns dims

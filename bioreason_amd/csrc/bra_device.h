@@ -81,7 +81,13 @@ __device__ __forceinline__ uint64_t wave_ballot(bool p) {
     return m;
 }
 #else
+#ifdef BRA_LANE_OPAQUE
+// (k_persist.hip) every call yields a value the optimiser cannot relate to the others: inside a loop over decoder layers hipcc
+// otherwise hoists ALL lane-derived address arithmetic of every phase to kernel entry and spills it around the loop (NOTES.md)
+__device__ __forceinline__ int lane_id() { int l = (int)(threadIdx.x & 63); asm volatile("" : "+v"(l)); return l; }
+#else
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+#endif
 __device__ __forceinline__ uint32_t wave_shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 __device__ __forceinline__ uint32_t wave_shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
 __device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p); }

@@ -211,3 +211,33 @@ extern "C" int bra_qwen_decode_step_one(const void* layers_host, int L, int R, i
 #undef CK
     return 0;
 }
+
+// bra_qwen_decode_step_one with the layer loop as ONE persistent launch (k_persist.hip: bra_qwen_layers_persist) — embed +
+// statistics (unless the sampler left them), one launch for all decoder layers, lm_head: 2-3 launches per token instead of ~170.
+// `layers_host` as above (its record 0 supplies the packed lm_head); `layers_dev` the device table of the persistent kernel.
+// Returns BRA_ERR_UNSUPPORTED where the persistent kernel does (callers fall back to bra_qwen_decode_step_one).
+extern "C" int bra_qwen_decode_step_persist(const void* layers_host, const void* layers_dev, int L, int R, int copies, int H, int Hq,
+                                            int Hkv, int hd, int F, int P, long vt_pitch, int C, long cp, int V, float eps, float scale,
+                                            const void* E, const void* norm_w, const float* cosT, const float* sinT, const int* tok,
+                                            const int* pos, const void* pmask, int t, const int* t_dev, int embed_done, void* x,
+                                            void* qkv, void* o, void* h, void* act, float* ss_ws, int nss, float* part_o,
+                                            float* part_ml, int nslot, float* logits, void* sync, int prefetch, int stop_after,
+                                            int timeout_us, void* stream) {
+    const Layer* ls = (const Layer*)layers_host;
+    const int B = R * copies;
+    const int Nq = Hq * hd, Nkv = Hkv * hd, Nqkv = Nq + 2 * Nkv;
+    int rc;
+#define CK(call) do { rc = (call); if (rc) return rc; } while (0)
+    const StepGemms sg = step_gemms(ss_ws, nss, B, H, Nq, Nqkv, F, V, eps, stream);
+    if (!sg.v2 || L <= 0 || !(ls[0].flags & 1) || !(ls[0].flags & 2)) return BRA_ERR_UNSUPPORTED;     // packed + folded weights only
+    if (!(embed_done && sg.v2)) {
+        CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));
+        CK(sg_begin(sg, x));
+    }
+    CK(bra_qwen_layers_persist(layers_dev, L, R, copies, H, Hq, Hkv, hd, F, P, vt_pitch, C, cp, eps, scale, cosT, sinT, pos,
+                               ls[0].rope_rows, pmask, t, t_dev, x, qkv, o, h, act, ss_ws, nss, part_o, part_ml, nslot, sync,
+                               prefetch, stop_after, timeout_us, stream));
+    if (logits) CK(sg_head(sg, x, norm_w, E, ls[0].head_packed, ls[0].flags & 4, logits));
+#undef CK
+    return 0;
+}

@@ -1,7 +1,10 @@
 // k_persist.hip — persistent-grid building blocks of the rollout's token loop (HF `_sample` loop body,
 // TF:generation/utils.py:2876-2925): the in-launch grid barrier / hand-off protocol of bra_gridsync.h and a probe that
 // measures and word-checks it on the device (tools/gridbar_probe.py).
+#define BRA_LANE_OPAQUE 1
 #include "bra_gridsync.h"
+#include "bra_decattn.h"
+#include "bra_decgemm.h"
 #include "bra_api_internal.h"
 
 namespace bra {
@@ -75,6 +78,303 @@ __global__ __launch_bounds__(NT) void gridbar_probe_kernel(GridSync* gs, unsigne
 }
 #endif
 
+
+// =====================================================================================================================
+// The decode step of the shared-prefix rollout as ONE launch: all decoder layers of Qwen3DecoderLayer.forward with a KV cache
+// (TF:qwen3:294-323) for the new token of every sequence — what bra_qwen_decode_step_one issues as six launches per layer.
+// One workgroup per CU (grid = number of 16-column qkv tiles = number of 8-column o / down tiles), eight waves; a layer is six
+// phases separated by grid barriers (bra_gridsync.h):
+//     qkv projection | attention items | merge | o projection + residual | gate/up + SwiGLU | down projection + residual
+// Every phase runs the SAME tiles, K split, reduction order and epilogue as the launched kernels (dec_gemm2_kernel FAST shapes,
+// dec_attn_item, dec_attn_merge_one): the step is bit-identical to the launched path and is tested against it.  What the single
+// launch buys is not cheaper synchronisation (a barrier + hand-off costs about what a launch boundary does: ~3.8 us measured,
+// tools/gridbar_probe.py) but that the weight stream no longer stops at the boundaries: with PF the fragment-packed weights of
+// the NEXT phases are requested before the barrier that hands over their activations and sit in registers when it opens.
+// Activations, statistics and attention partials cross workgroups through sc1 stores / sc1 loads; the K/V caches, weights and
+// rope rows come from earlier launches (plain / non-temporal loads).
+struct PLayer {                           // device-side layer table (one record per decoder layer)
+    const bf16_t *Wqkv, *Wo, *Wgu, *Wd;     // fragment-packed rollout weights (ln1 folded into Wqkv, ln2 into Wgu)
+    const bf16_t *qn, *kn;                  // per-head RMSNorm weights
+    const bf16_t *kp, *vtp;                 // prompt K [R, Hkv, P, hd] and V^T [R, Hkv, hd, pitch]
+    bf16_t *kc, *vct;                       // completion K cache and transposed completion V cache
+};
+
+struct PersistArgs {
+    const PLayer* layers; int L, M;
+    DecOneArgs att;                         // per-layer pointer fields are patched from the table
+    bf16_t *x, *h, *act; float *ssx, *ssh; int nss; float eps;
+    GridSync* sync; unsigned timeout_ticks; int stop_after;
+};
+
+#ifndef BRA_EMU
+template <int NL> struct Frag { u32x4 v[NL]; };
+
+// the wave's NL consecutive KiB blocks of one packed column tile (dec_gemm2_kernel FAST: tile_base + wo[u])
+template <int NW, int NL>
+__device__ __forceinline__ void pw_issue(Frag<NL>& w, const bf16_t* W, const int tile, const int wave, const int lane) {
+    // (every path DEFINES the fragment: a fragment left untouched on one path would be carried around the layer loop)
+    if (NW < 8 && wave >= NW) {
+#pragma unroll
+        for (int u = 0; u < NL; ++u) w.v[u] = u32x4{0u, 0u, 0u, 0u};
+        return;
+    }
+    const bf16_t* p = W + (long)tile * (NW * NL * 512) + (unsigned)(wave * (NL * 512) + lane * 8);
+#pragma unroll
+    for (int u = 0; u < NL; ++u) w.v[u] = ld16_nt(p + u * 512);
+}
+
+// the wave's activation fragments (rows of another workgroup's output: sc1)
+template <int MODE, int NW, int NL>
+__device__ __forceinline__ void px_load(Frag<NL>& x, const bf16_t* X, const int ldx, const int M, const int wave, const int lane) {
+    if (NW < 8 && wave >= NW) {
+#pragma unroll
+        for (int u = 0; u < NL; ++u) x.v[u] = u32x4{0u, 0u, 0u, 0u};
+        return;
+    }
+    constexpr int KS = MODE ? 64 : 32;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int lrow = MODE ? (fr & 7) : fr;
+    const int koff = MODE ? ((fr >> 3) * 32 + fq * 8) : fq * 8;
+    const int xr = lrow < M ? lrow : M - 1;
+    const unsigned off = dg2_mul24(xr, ldx) + (unsigned)(koff + wave * (NL * KS));
+#pragma unroll
+    for (int u = 0; u < NL; ++u) x.v[u] = xld16<1>(X, (off + (unsigned)(u * KS)) * 2u);
+}
+
+// RMSNorm statistics partials of the input rows (wave 0; dec_gemm2_kernel NORM == 2)
+__device__ __forceinline__ void ps_load(f32x4 (&sq)[8], const float* ss, const int nss, const int M, const int wave, const int lane) {
+    if (wave != 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const int per = nss >> 3;
+    const int srow = lane >> 3;
+    const int sr = srow < M ? srow : M - 1;
+    const unsigned off = dg2_mul24(sr, nss) + (unsigned)((lane & 7) * per);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sq[i] = __builtin_bit_cast(f32x4, xld16<1>(ss, (off + (unsigned)(4 * i < per ? 4 * i : 0)) * 4u));
+}
+
+// residual words of the epilogue lanes of (tile): dec_gemm2_kernel's `resv`
+template <int MODE>
+__device__ __forceinline__ u32x2 pr_load(const bf16_t* res, const int ldres, const int M, const int N, const int tile, const int lane) {
+    constexpr int NCOL = MODE ? 8 : 16;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int em = fr < M ? fr : M - 1;
+    int en = tile * NCOL + 4 * fq; en = en + 3 < N ? en : N - 4;
+    return xld8<1>(res, (dg2_mul24(em, ldres) + (unsigned)en) * 2u);
+}
+
+// one column tile: MFMA chain over the wave's K slice, K-reduction through LDS in wave order, epilogue by wave it % NW —
+// the body of dec_gemm2_kernel's compute()
+template <int MODE, int NORM, int ACT, int NW, int NL>
+__device__ __forceinline__ void pg_tile(const Frag<NL>& w, const Frag<NL>& x, const DecGemm2Args& g, const int tile, const int it,
+                                        const u32x2& resv, const f32x4 (&sq)[8], float (&red)[2][8][64][4], float (&rs_lds)[8],
+                                        const int wave, const int lane) {
+    const int fr = lane & 15;
+    if (wave < NW) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NL; ++u) acc = mfma_16x16x32(w.v[u], x.v[u], acc);
+        if (NORM == 2 && it == 0 && wave == 0) {
+            const int per = g.nss_in >> 3;
+            const int srow = lane >> 3;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 q = sq[i];
+                s += 4 * i < per ? (q[0] + q[1]) + (q[2] + q[3]) : 0.f;
+            }
+            s += wave_shfl_xor(s, 1); s += wave_shfl_xor(s, 2); s += wave_shfl_xor(s, 4);
+            if ((lane & 7) == 0) rs_lds[srow] = rsqrtf(s / (float)g.K + g.eps);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[it & 1][wave][lane][r] = acc[r];
+    }
+    raw_barrier();
+    if (wave == it % NW) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sum = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) sum += red[it & 1][wv][lane][r];
+            v[r] = sum;
+        }
+        if (NORM == 2) {
+            const int mrow = MODE ? (fr & 7) : fr;
+            const float rsf = rs_lds[mrow < g.M ? mrow : g.M - 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= rsf;
+        }
+        dg2_epilogue<MODE, ACT, 0, 1, 1>(g, v, tile, lane, true, resv);
+    }
+}
+
+// PF: 0 = every phase requests its weights when it starts (the launched path inside one launch); 1 = weights of the following
+// phases requested ahead (see the schedule in the loop); 2 = also the K / V^T fragments of the wave's attention item
+template <int H, int NQ, int NKV, int F, int HD, int G, int PF>
+__global__ __launch_bounds__(512) void decode_persist_kernel(PersistArgs a) {
+    constexpr int NQKV = NQ + 2 * NKV;
+    constexpr int NWG = NQKV / 16;                               // workgroups = qkv tiles
+    constexpr int NL_QKV = H / 256;                              // 8 waves x NL x 32-deep steps
+    constexpr int NW_O = (NQ / 64 >= 64) ? 8 : 4, NL_O = NQ / 64 / NW_O;
+    constexpr int NL_D = F / 64 / 8;
+    constexpr int NT_GU = 2 * F / 16 / NWG;
+    static_assert(H % 256 == 0 && (NL_QKV == 4 || NL_QKV == 8 || NL_QKV == 12), "qkv / gate-up: one register round of 8 waves");
+    static_assert(H / 8 == NWG && (2 * F / 16) % NWG == 0 && NT_GU == 3, "tiles per workgroup: 1 qkv, 1 o, 3 gate/up, 1 down");
+    static_assert(NQ % (64 * NW_O) == 0 && (NL_O == 4 || NL_O == 8 || NL_O == 12) && F % 512 == 0 && (NL_D == 4 || NL_D == 8 || NL_D == 12), "o / down");
+    __shared__ float red[2][8][64][4];
+    __shared__ float rs_lds[8];
+    __shared__ unsigned bar_flag;
+    // wave / workgroup ids are re-derived behind an (empty) volatile asm at the top of every phase: the optimiser otherwise treats
+    // every id-derived offset of every phase as invariant of the layer loop, computes all of them at kernel entry and spills them
+    // around the loop (several hundred dwords of scratch traffic inside the phases)
+#define BRA_PIDS()                                                                                             \
+    int wave, wg;                                                                                              \
+    { int tw_ = (int)threadIdx.x >> 6; asm volatile("" : "+v"(tw_)); wave = __builtin_amdgcn_readfirstlane(tw_);   \
+      wg = (int)blockIdx.x; asm volatile("" : "+s"(wg)); }
+    unsigned epoch = 0;
+    int phases = 0;
+    const int M = a.M;
+    DecOneArgs at = a.att;
+    const int t = at.t_ptr ? at.t_ptr[0] : at.t;
+    at.t = t; at.t_ptr = nullptr;
+    {
+        const int ncc = (t + 63) / 64;
+        at.ncc_grid = ncc; at.inv_ncc = 1.f / (float)(ncc > 0 ? ncc : 1);
+    }
+    const int nitems = at.R * at.copies * at.Hq + at.npc * at.Hkv * at.R + at.ncc_grid * at.copies * at.Hkv * at.R;
+    const u32x2 zero2 = {0u, 0u};
+    f32x4 sq0[8];                             // (phases without a norm)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sq0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Frag<NL_QKV> wq;                          // the only fragment carried from one layer to the next (PF)
+#define BRA_PBAR()                                                                            \
+    do {                                                                                      \
+        if (a.stop_after > 0 && ++phases >= a.stop_after) return;                             \
+        if (!grid_barrier(a.sync, epoch, NWG, a.timeout_ticks, &bar_flag)) return;            \
+    } while (0)
+    const PLayer* Ls = a.layers;
+    if (PF) { BRA_PIDS(); pw_issue<8, NL_QKV>(wq, Ls[0].Wqkv, wg, wave, lane_id()); sched_fence(); }
+    for (int l = 0; l < a.L; ++l) {
+        const PLayer Lr = Ls[l];
+        Frag<NL_QKV> wg0, wg1;                // requested and consumed inside one layer: declared here, undefined at its start
+        Frag<NL_O> wo;
+        Frag<NL_D> wd;
+        at.qw = Lr.qn; at.kw = Lr.kn; at.kp = Lr.kp; at.vtp = Lr.vtp; at.kc = Lr.kc; at.vct = Lr.vct;
+        // ------------------------------------------------------------------ qkv = rmsnorm(x) Wqkv^T   (ln1 folded, rstd in the epilogue)
+        {
+            BRA_PIDS();
+            DecGemm2Args g = {a.x, H, a.ssx, a.nss, nullptr, a.eps, Lr.Wqkv, H, nullptr, 0, (void*)at.qkv, NQKV, nullptr, 0, M, NQKV, H, 3, nullptr};
+            u32x4 kf[4][HD / 32], vf[HD / 16][2];
+            DecItem it0;
+            it0.kind = 0;
+            if (PF >= 2) {                  // the wave's attention item: its K / V^T chunk does not depend on the new token
+                const int iw = wg + NWG * wave;
+                if (iw < nitems) dec_item_decode<HD, G>(at, iw, t, it0);
+                if (it0.kind == 2) item_kv_issue<HD>(it0.kbase, it0.kss, it0.vbase, it0.vsd, it0.key0, it0.nkeys, kf, vf);
+                sched_fence();
+            }
+            if (!PF) pw_issue<8, NL_QKV>(wq, Lr.Wqkv, wg, wave, lane_id());
+            Frag<NL_QKV> xf;
+            px_load<0, 8, NL_QKV>(xf, a.x, H, M, wave, lane_id());
+            f32x4 sq[8];
+            ps_load(sq, a.ssx, a.nss, M, wave, lane_id());
+            pg_tile<0, 2, 0, 8, NL_QKV>(wq, xf, g, wg, 0, zero2, sq, red, rs_lds, wave, lane_id());
+            if (wave == 0) gs_drain();
+            BRA_PBAR();
+            // -------------------------------------------------------------- attention items: q/k norm + RoPE, cache append, partials
+          {
+            BRA_PIDS();
+            if (PF >= 2) {
+                if (wg + NWG * wave < nitems) dec_item_run<HD, G, 1, 1>(at, it0, t, kf, vf);
+                for (int i = wg + NWG * (wave + 8); i < nitems; i += NWG * 8) {
+                    DecItem d;
+                    dec_item_decode<HD, G>(at, i, t, d);
+                    dec_item_run<HD, G, 1, 0>(at, d, t, kf, vf);
+                }
+            } else {
+                for (int i = wg + NWG * wave; i < nitems; i += NWG * 8) {
+                    DecItem d;
+                    dec_item_decode<HD, G>(at, i, t, d);
+                    dec_item_run<HD, G, 1, 0>(at, d, t, kf, vf);
+                }
+            }
+            gs_drain();
+          }
+            BRA_PBAR();
+        }
+        // ------------------------------------------------------------------ merge of the partials -> o
+        {
+        BRA_PIDS();
+        if (PF) {                           // weights of the next two phases: o, and the first two gate/up tiles
+            pw_issue<NW_O, NL_O>(wo, Lr.Wo, wg, wave, lane_id());
+            pw_issue<8, NL_QKV>(wg0, Lr.Wgu, wg, wave, lane_id());
+            sched_fence();
+        }
+        for (int i = wg + NWG * wave; i < M * at.Hq; i += NWG * 8) {
+            const int b = da_div(i, at.inv_Hq);
+            dec_attn_merge_one<HD, 1>(at, i - b * at.Hq, b);
+        }
+        gs_drain();
+        }
+        BRA_PBAR();
+        // ------------------------------------------------------------------ h = x + o Wo^T  (+ statistics of h)
+        {
+            BRA_PIDS();
+            DecGemm2Args g = {at.o, NQ, nullptr, 0, nullptr, 0.f, Lr.Wo, NQ, a.x, H, (void*)a.h, H, a.ssh, a.nss, M, H, NQ, 1, nullptr};
+            if (PF) {                       // the second gate/up tile and the down projection
+                pw_issue<8, NL_QKV>(wg1, Lr.Wgu, wg + NWG, wave, lane_id());
+                pw_issue<8, NL_D>(wd, Lr.Wd, wg, wave, lane_id());
+                sched_fence();
+            } else pw_issue<NW_O, NL_O>(wo, Lr.Wo, wg, wave, lane_id());
+            Frag<NL_O> xf;
+            px_load<1, NW_O, NL_O>(xf, at.o, NQ, M, wave, lane_id());
+            const u32x2 resv = pr_load<1>(a.x, H, M, H, wg, lane_id());
+            pg_tile<1, 0, 0, NW_O, NL_O>(wo, xf, g, wg, 0, resv, sq0, red, rs_lds, wave, lane_id());
+            if (wave == 0) gs_drain();
+            BRA_PBAR();
+        }
+        // ------------------------------------------------------------------ act = silu(gate) * up of rmsnorm(h) Wgu^T  (ln2 folded)
+        {
+            BRA_PIDS();
+            DecGemm2Args g = {a.h, H, a.ssh, a.nss, nullptr, a.eps, Lr.Wgu, H, nullptr, 0, (void*)a.act, F, nullptr, 0, M, 2 * F, H, 3, nullptr};
+            if (!PF) {
+                pw_issue<8, NL_QKV>(wg0, Lr.Wgu, wg, wave, lane_id());
+                pw_issue<8, NL_QKV>(wg1, Lr.Wgu, wg + NWG, wave, lane_id());
+            }
+            Frag<NL_QKV> xf;
+            px_load<0, 8, NL_QKV>(xf, a.h, H, M, wave, lane_id());
+            f32x4 sq[8];
+            ps_load(sq, a.ssh, a.nss, M, wave, lane_id());
+            pg_tile<0, 2, 1, 8, NL_QKV>(wg0, xf, g, wg, 0, zero2, sq, red, rs_lds, wave, lane_id());
+            pw_issue<8, NL_QKV>(wg0, Lr.Wgu, wg + 2 * NWG, wave, lane_id());
+            pg_tile<0, 2, 1, 8, NL_QKV>(wg1, xf, g, wg + NWG, 1, zero2, sq, red, rs_lds, wave, lane_id());
+            if (PF && l + 1 < a.L) { pw_issue<8, NL_QKV>(wq, Ls[l + 1].Wqkv, wg, wave, lane_id()); sched_fence(); }
+            pg_tile<0, 2, 1, 8, NL_QKV>(wg0, xf, g, wg + 2 * NWG, 2, zero2, sq, red, rs_lds, wave, lane_id());
+            if (wave < 3) gs_drain();
+            BRA_PBAR();
+        }
+        // ------------------------------------------------------------------ x = h + act Wd^T  (+ statistics of x)
+        {
+            BRA_PIDS();
+            DecGemm2Args g = {a.act, F, nullptr, 0, nullptr, 0.f, Lr.Wd, F, a.h, H, (void*)a.x, H, a.ssx, a.nss, M, H, F, 1, nullptr};
+            if (!PF) pw_issue<8, NL_D>(wd, Lr.Wd, wg, wave, lane_id());
+            Frag<NL_D> xf;
+            px_load<1, 8, NL_D>(xf, a.act, F, M, wave, lane_id());
+            const u32x2 resv = pr_load<1>(a.h, H, M, H, wg, lane_id());
+            pg_tile<1, 0, 0, 8, NL_D>(wd, xf, g, wg, 0, resv, sq0, red, rs_lds, wave, lane_id());
+            if (wave == 0) gs_drain();
+            BRA_PBAR();
+        }
+    }
+#undef BRA_PBAR
+#undef BRA_PIDS
+}
+#endif  // !BRA_EMU
+
 }  // namespace bra
 
 using namespace bra;
@@ -104,5 +404,71 @@ extern "C" int bra_gridbar_probe(void* sync, void* buf, void* errs, const void* 
     BRA_LAUNCH((gridbar_probe_kernel<512>), dim3(nwg), dim3(512), 0, st, (GridSync*)sync, (unsigned*)buf, (unsigned*)errs,
                (const u32x4*)wts, (unsigned long)(wts_bytes / 16), iters, mode, wchunks, ticks);
     return BRA_LAUNCH_STATUS();
+#endif
+}
+
+extern "C" int bra_persist_layer_desc_size(void) { return (int)sizeof(PLayer); }
+
+// All decoder layers of one shared-prefix decode step in ONE launch (see decode_persist_kernel).  `layers_dev`: device array of L
+// records {Wqkv, Wo, Wgu, Wd (fragment-packed, norms folded), qn, kn, kp, vtp, kc, vct} (bra_persist_layer_desc_size() bytes
+// each); every other argument as bra_qwen_decode_step_one.  x / ss_ws hold the embedded token rows and their RMSNorm statistics
+// on entry and the last layer's output + statistics on exit (the caller runs the lm_head).  sync: bra_gridsync_bytes() bytes.
+// prefetch: 0 none, 1 weights of the following phases, 2 also the K / V^T chunk of the attention items.  stop_after > 0 (tests):
+// leave after that many phases.  BRA_ERR_UNSUPPORTED unless the shape is one of the instantiated models with <= 8 sequences and
+// the device has one CU per workgroup.
+extern "C" int bra_qwen_layers_persist(const void* layers_dev, int L, int R, int copies, int H, int Hq, int Hkv, int hd, int F, int P,
+                                       long vt_pitch, int C, long cp, float eps, float scale, const float* cosT, const float* sinT,
+                                       const int* pos, const float* rope_rows, const void* pmask, int t, const int* t_dev, void* x,
+                                       void* qkv, void* o, void* h, void* act, float* ss_ws, int nss, float* part_o, float* part_ml,
+                                       int nslot, void* sync, int prefetch, int stop_after, int timeout_us, void* stream) {
+#ifdef BRA_EMU
+    (void)layers_dev; (void)L; (void)R; (void)copies; (void)H; (void)Hq; (void)Hkv; (void)hd; (void)F; (void)P; (void)vt_pitch; (void)C; (void)cp;
+    (void)eps; (void)scale; (void)cosT; (void)sinT; (void)pos; (void)rope_rows; (void)pmask; (void)t; (void)t_dev; (void)x; (void)qkv; (void)o;
+    (void)h; (void)act; (void)ss_ws; (void)nss; (void)part_o; (void)part_ml; (void)nslot; (void)sync; (void)prefetch; (void)stop_after;
+    (void)timeout_us; (void)stream;
+    return BRA_ERR_UNSUPPORTED;       // a persistent grid needs concurrently resident workgroups
+#else
+    if (!layers_dev || L <= 0 || R <= 0 || copies <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || P <= 0 || t < 0 || t >= C) return BRA_ERR_ARG;
+    if (!cosT || !sinT || !pos || !x || !qkv || !o || !h || !act || !ss_ws || !part_o || !part_ml || !sync) return BRA_ERR_ARG;
+    const int B = R * copies, G = Hq / Hkv;
+    if (B > 8 || copies * G > 16) return BRA_ERR_UNSUPPORTED;
+    const int Nq = Hq * hd, Nkv = Hkv * hd;
+    const int npc = (P + 63) / 64, ncc = (t + 63) / 64;
+    if (vt_pitch < (long)npc * 64 || vt_pitch % 8 || cp < ((C + 63) / 64) * 64 || cp % 8) return BRA_ERR_ARG;
+    if (nslot < npc + (C + 63) / 64 + 1 || nslot > 256) return BRA_ERR_ARG;
+    if (nss != 256) return BRA_ERR_UNSUPPORTED;                      // H / 8 statistics partials per row, folded 32 per lane
+    const long kp_sr = (long)Hkv * P * hd, kp_sh = (long)P * hd, kp_ss = hd;
+    const long vt_sr = (long)Hkv * hd * vt_pitch, vt_sh = (long)hd * vt_pitch, vt_sd = vt_pitch;
+    const long lim = 1L << 30, f24 = 1L << 24;
+    const long nitems = (long)npc * Hkv * R + (long)ncc * copies * Hkv * R + (long)R * copies * Hq;
+    if (nitems >= (1 << 21) || vt_sd >= f24 || cp >= f24 || (long)(npc * 64) * kp_ss >= lim || (long)hd * vt_sd >= lim ||
+        (long)hd * cp >= lim || (long)B * Hq * nslot * hd >= lim / 4)
+        return BRA_ERR_UNSUPPORTED;
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return BRA_ERR_ARG;
+    PersistArgs a;
+    a.layers = (const PLayer*)layers_dev; a.L = L; a.M = B;
+    a.att = DecOneArgs{(const bf16_t*)qkv, (long)(Nq + 2 * Nkv), nullptr, nullptr, cosT, sinT, pos, rope_rows,
+                       nullptr, kp_sr, kp_sh, kp_ss, nullptr, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask,
+                       nullptr, nullptr, cp, part_o, part_ml, (bf16_t*)o, (long)Nq,
+                       R, copies, Hq, Hkv, P, C, t, nslot, npc, ncc, eps, scale, t_dev,
+                       1.f / (float)Hq, 1.f / (float)npc, 1.f / (float)Hkv, 1.f / (float)(ncc > 0 ? ncc : 1), 1.f / (float)copies};
+    a.x = (bf16_t*)x; a.h = (bf16_t*)h; a.act = (bf16_t*)act; a.ssx = ss_ws; a.ssh = ss_ws + 8 * (long)nss; a.nss = nss; a.eps = eps;
+    a.sync = (GridSync*)sync; a.timeout_ticks = (unsigned)(timeout_us > 0 ? timeout_us : 50000) * 100u; a.stop_after = stop_after;
+    hipStream_t st = (hipStream_t)stream;
+#define BRA_PERSIST(H_, NQ_, NKV_, F_, HD_, G_)                                                                                   \
+    if (H == H_ && Nq == NQ_ && Nkv == NKV_ && F == F_ && hd == HD_ && G == G_) {                                                 \
+        constexpr int NWG = (NQ_ + 2 * NKV_) / 16;                                                                                \
+        if (ncu < NWG) return BRA_ERR_UNSUPPORTED;                  /* every workgroup must be resident */                        \
+        hipError_t e = hipMemsetAsync(sync, 0, sizeof(GridSync), st);                                                             \
+        if (e != hipSuccess) return (int)e;                                                                                       \
+        if (prefetch <= 0) BRA_LAUNCH((decode_persist_kernel<H_, NQ_, NKV_, F_, HD_, G_, 0>), dim3(NWG), dim3(512), 0, st, a);    \
+        else if (prefetch == 1) BRA_LAUNCH((decode_persist_kernel<H_, NQ_, NKV_, F_, HD_, G_, 1>), dim3(NWG), dim3(512), 0, st, a); \
+        else BRA_LAUNCH((decode_persist_kernel<H_, NQ_, NKV_, F_, HD_, G_, 2>), dim3(NWG), dim3(512), 0, st, a);                  \
+        return BRA_LAUNCH_STATUS();                                                                                               \
+    }
+    BRA_PERSIST(2048, 2048, 1024, 6144, 128, 2)                     // Qwen3-1.7B (the reference's "Qwen3-1B", sh_reason.sh:46)
+#undef BRA_PERSIST
+    return BRA_ERR_UNSUPPORTED;
 #endif
 }

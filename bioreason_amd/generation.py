@@ -199,6 +199,10 @@ class SharedDecodeState:
     """`bra_qwen_decode_step_shared`: R prompts x `copies` sequences; prompt K / V^T are held once per prompt, each
     sequence owns only a completion cache [Hkv, C, hd]."""
 
+    def persist_timed_out(self) -> bool:
+        """(host sync) True if a barrier of the persistent step gave up (GridSync::err != 0): the rollout's tokens are invalid"""
+        return self.persist is not None and bool(self.persist["sync"].view(torch.int32)[272].item() != 0)
+
     def __init__(self, model, cache_r: KVCache, vtp, R: int, copies: int, P: int, C: int):
         eng: QwenEngine = model.engine
         dev = eng.device
@@ -248,9 +252,33 @@ class SharedDecodeState:
         self.part_o = torch.empty((B, eng.Hq, nch, eng.hd), dtype=torch.float32, device=dev)
         self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
         self.cosT, self.sinT = eng.rope(P + C + 1)
+        # persistent form of the layer loop (k_persist.hip): ONE launch for all decoder layers, bit-identical to the launched path.
+        # BRA_DEC_PERSIST: "0" launched kernels, "1" / "2" / "3" persistent with prefetch level 0 / 1 / 2; default: persistent where the
+        # kernel is instantiated for the shape (<= 8 sequences, packed + folded weights, one CU per workgroup)
+        self.persist = None
+        mode = os.environ.get("BRA_DEC_PERSIST", "2")
+        if mode != "0" and self.attn_impl == "one" and use_packed and B <= 8 and all(Rw.get("folded") for Rw in self.rw) and dev.type == "cuda":
+            tab = torch.tensor([[Rw["Wqkv_p"].data_ptr(), Rw["Wo_p"].data_ptr(), Rw["Wgu_p"].data_ptr(), Rw["Wd_p"].data_ptr(),
+                                 L.qn.data_ptr(), L.kn.data_ptr(), self.kp[i].data_ptr(), self.vtp[i].data_ptr(),
+                                 self.kc[i].data_ptr(), self.vc[i].data_ptr()] for i, (L, Rw) in enumerate(zip(eng.layers, self.rw))],
+                               dtype=torch.int64)
+            assert tab.shape[1] * 8 == get_lib()._dll.bra_persist_layer_desc_size()
+            self.persist = {"table": tab.to(dev), "sync": torch.zeros(2048, dtype=torch.uint8, device=dev),
+                            "prefetch": max(0, int(mode) - 1), "ok": None}
 
     def step(self, tok, pos, pmask, t: int, logits: torch.Tensor, t_dev=None, embed_done: bool = False):
         e = self.eng
+        if self.persist is not None and self.persist["ok"] is not False:
+            ps = self.persist
+            rc = get_lib().call_rc("bra_qwen_decode_step_persist", ctypes.addressof(self.arr), ps["table"], e.L, self.R, self.copies, e.H,
+                                   e.Hq, e.Hkv, e.hd, e.F, self.P, self.vt_pitch, self.C, self.cp, e.V, e.eps, e.scale, e.E, e.norm_w,
+                                   self.cosT, self.sinT, tok, pos, pmask, t, t_dev, int(embed_done), self.x, self.qkv, self.o, self.h,
+                                   self.act, self.ss_ws, self.nss, self.part_o, self.part_ml, self.part_o.shape[2], logits, ps["sync"],
+                                   ps["prefetch"], int(os.environ.get("BRA_DEC_PERSIST_STOP", "0")), 50000, current_stream(self.x))
+            if rc == 0:
+                ps["ok"] = True
+                return
+            ps["ok"] = False            # BRA_ERR_UNSUPPORTED (shape / CU count): launched kernels from here on
         if self.attn_impl == "one":
             get_lib().call("bra_qwen_decode_step_one", ctypes.addressof(self.arr), e.L, self.R, self.copies, e.H, e.Hq, e.Hkv,
                            e.hd, e.F, self.P, self.vt_pitch, self.C, self.cp, e.V, e.eps, e.scale, e.E, e.norm_w, self.cosT,
@@ -334,7 +362,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
              force_tokens: Optional[torch.Tensor] = None, native_step: bool = True,
              decode_impl: str = "fused", prompt_alias=None, use_graph: Optional[bool] = None,
              shared_prefix_decode: bool = True, profile: Optional[dict] = None,
-             eos_schedule: Optional[torch.Tensor] = None) -> torch.Tensor:
+             eos_schedule: Optional[torch.Tensor] = None, trace_logits: Optional[list] = None) -> torch.Tensor:
     """`force_tokens` [B, max_new_tokens] (optional): teacher forcing — the model's own choice is still recorded
     in the output, but the given token is fed back (used to compare decodes position by position).
     `use_graph`: True = sample + decode step + counter update are captured once in a hipGraph and replayed per token
@@ -343,7 +371,8 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     cannot stay ahead of the device.
     `eos_token_id` may be an int or a list of up to two ids (HF stops a row on any listed id; Qwen3's generation_config
     lists two); the first one is the pad default.  `eos_schedule` int32 [B] (benchmarks / tests with random-init weights):
-    row b is made to draw the first EOS id at step eos_schedule[b]."""
+    row b is made to draw the first EOS id at step eos_schedule[b].
+    `trace_logits` (tests): a list that receives a copy of the fp32 logits [B, V] after every decode step (eager issue only)."""
     eng = model.ensure_packed()
     B, P, H = inputs_embeds.shape
     dev = inputs_embeds.device
@@ -424,7 +453,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     ops.gemm_nt(hid, eng.E, out=logits, out_f32=True)
     len_t = torch.full((1,), P, dtype=torch.int32, device=dev)          # device-side cur_len of the fused step
     # graph_mode: True / False as requested, None = decide by measurement (see below); graph_ok: replay is possible at all
-    graph_ok = dev.type == "cuda" and fused and force_tokens is None and max_new_tokens > 2
+    graph_ok = dev.type == "cuda" and fused and force_tokens is None and max_new_tokens > 2 and trace_logits is None
     graph_mode = use_graph if use_graph is None else bool(use_graph)
     dstate = shared if shared is not None else (state if fused else None)
     # the drawing wave of the sampler also gathers x = E[token] and its RMSNorm statistic for the fused step (not under
@@ -473,6 +502,8 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
                 cur.copy_(force_tokens[:, t].to(torch.int32))
             if fused:
                 advance_(t)
+                if trace_logits is not None:
+                    trace_logits.append(logits.clone())
             else:
                 if state is not None:
                     hid = state.step(cur, next_pos, kmask, P + t, model._lora_enabled)
@@ -530,6 +561,9 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     if alive:
         sample_()
     _tick("decode_loop")
+    if shared is not None and shared.persist is not None and shared.persist["ok"] and shared.persist_timed_out():
+        raise RuntimeError("bioreason_amd: a grid barrier of the persistent decode step timed out (GridSync::err set); the rollout is "
+                           "invalid. BRA_DEC_PERSIST=0 selects the launched kernels.")
     if graph is not None:
         graph.reset()            # release the executable graph here, not whenever the cyclic GC finds the closures
         del graph

@@ -346,6 +346,30 @@ int bra_grpo_loss(const float* logp, const float* old_logp, const float* ref_log
  * `wchunks` x 16 B per thread of a read-once stream prefetched across the barrier); errs[0] = mismatching words, errs[1] =
  * barriers completed; every spin is bounded by `timeout_us` (the record's error word is set instead of hanging). */
 int bra_gridsync_bytes(void);
+/* All decoder layers of one shared-prefix decode step (bra_qwen_decode_step_one's layer loop: Qwen3DecoderLayer.forward with a
+ * KV cache, TF:qwen3:294-323) in ONE launch of one workgroup per CU: six phases per layer separated by in-launch grid barriers,
+ * the same tiles / K split / reduction order / epilogues as the launched kernels (bit-identical results), the weights of the
+ * following phases requested before the barrier that hands over their activations (prefetch 1; 2: also the K / V^T chunk of the
+ * wave's attention item).  layers_dev: device array of L records of bra_persist_layer_desc_size() bytes {Wqkv, Wo, Wgu, Wd
+ * (fragment-packed, norms folded), qn, kn, kp, vtp, kc, vct}.  x / ss_ws: embedded token rows + statistics in, last layer's
+ * output + statistics out.  sync: bra_gridsync_bytes() bytes (zeroed by the call).  Every spin is bounded by timeout_us; a
+ * timed-out launch leaves a non-zero word at sync + 1088 (GridSync::err).  BRA_ERR_UNSUPPORTED: shape not instantiated, more
+ * than 8 sequences, fewer CUs than workgroups. */
+int bra_persist_layer_desc_size(void);
+int bra_qwen_layers_persist(const void* layers_dev, int L, int R, int copies, int H, int Hq, int Hkv, int hd, int F, int P,
+                            long vt_pitch, int C, long cp, float eps, float scale, const float* cosT, const float* sinT,
+                            const int* pos, const float* rope_rows, const void* pmask, int t, const int* t_dev, void* x,
+                            void* qkv, void* o, void* h, void* act, float* ss_ws, int nss, float* part_o, float* part_ml,
+                            int nslot, void* sync, int prefetch, int stop_after, int timeout_us, void* stream);
+/* bra_qwen_decode_step_one with its layer loop replaced by bra_qwen_layers_persist: embed + statistics (unless embed_done), ONE
+ * launch for all decoder layers, lm_head.  layers_host as for bra_qwen_decode_step_one (packed + folded weights required),
+ * layers_dev / sync / prefetch / stop_after / timeout_us as for bra_qwen_layers_persist.  Bit-identical logits. */
+int bra_qwen_decode_step_persist(const void* layers_host, const void* layers_dev, int L, int R, int copies, int H, int Hq, int Hkv,
+                                 int hd, int F, int P, long vt_pitch, int C, long cp, int V, float eps, float scale, const void* E,
+                                 const void* norm_w, const float* cosT, const float* sinT, const int* tok, const int* pos,
+                                 const void* pmask, int t, const int* t_dev, int embed_done, void* x, void* qkv, void* o, void* h,
+                                 void* act, float* ss_ws, int nss, float* part_o, float* part_ml, int nslot, float* logits,
+                                 void* sync, int prefetch, int stop_after, int timeout_us, void* stream);
 int bra_gridbar_probe(void* sync, void* buf, void* errs, const void* wts, long wts_bytes, int nwg, int iters, int mode,
                       int wchunks, int timeout_us, void* stream);
 
