@@ -376,8 +376,12 @@ __device__ __forceinline__ float da_wave_sum(float v) {
     return v + wave_shfl_xor(v, 32);
 }
 
-template <int HD, int XS = 0>
-__device__ __forceinline__ void dec_attn_merge_one(const DecOneArgs& a, const int hq, const int b) {
+struct DaNoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `after_issue` runs once every request of the merge is in flight (the persistent step issues its look-ahead weight requests
+// there: loads return in order, so anything requested BEFORE the partial rows would have to land before the merge can start)
+template <int HD, int XS = 0, class Hook = DaNoHook>
+__device__ __forceinline__ void dec_attn_merge_one(const DecOneArgs& a, const int hq, const int b, const Hook& after_issue = Hook()) {
     constexpr int LR = HD / 4, PR = 64 / LR, PRE = 24;
     const int lane = lane_id();
     const int t = a.t_ptr ? a.t_ptr[0] : a.t;
@@ -404,6 +408,7 @@ __device__ __forceinline__ void dec_attn_merge_one(const DecOneArgs& a, const in
     // to its first use.  Passing the (max, sum) words through an (empty) volatile asm ties everything derived from them to a
     // point behind the fence; it waits for those four loads only (in-order return counter), not for the partial rows.
     sched_fence();
+    after_issue();
     float mc[4], lc[4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {

@@ -17,6 +17,7 @@ struct DecGemm2Args {
     int M, N, K;
     int packed;                         // W is in fragment order (bra_dec_pack_weights): [tile][k-step][lane][8]
     unsigned long long* probe;          // optional timing probe (tools/dec_overhead_probe.py): 8 stamps per probed workgroup
+    float inv_K;                        // 1 / K rounded on the host (NORM == 2: mean of squares = fma(sum, inv_K, eps))
 };
 
 // 100 MHz wall clock (s_memrealtime); the probe is compiled in but costs one uniform branch per stamp when unused
@@ -31,12 +32,47 @@ __device__ __forceinline__ void dg2_stamp(const DecGemm2Args& g, int slot) {
 
 __device__ __forceinline__ float silu_g(float x) { return x / (1.f + __expf(-x)); }
 
+// RMSNorm row factor from the statistics partials one lane folds (NORM == 2): the eight chunks in a FIXED association and one
+// explicit fma for mean + eps — under -ffast-math the optimiser is otherwise free to re-associate the sum and to form (or not
+// form) the fma differently in every kernel this is inlined into, and the launched and the persistent step would disagree in the
+// last bit of rstd (which an occasional bf16 rounding downstream then turns into a visible difference).  inv_K = 1 / K as a
+// float rounded on the host (v_rcp_f32 of a run-time K and the constant-folded 1 / K of a templated K are not the same number).
+__device__ __forceinline__ float dg2_fold_rstd(const f32x4 (&sq)[8], const int per, const float inv_K, const float eps) {
+#pragma clang fp reassociate(off)
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x4 q = sq[i];
+        const float lo = q[0] + q[1], hi = q[2] + q[3];
+        const float c = lo + hi;
+        s = s + (4 * i < per ? c : 0.f);
+    }
+    s = s + wave_shfl_xor(s, 1);
+    s = s + wave_shfl_xor(s, 2);
+    s = s + wave_shfl_xor(s, 4);
+    return rsqrtf(__builtin_fmaf(s, inv_K, eps));
+}
+
 // full-rate 24-bit multiply (v_mul_u32_u24; the 32- and 64-bit integer multiplies run at quarter rate): row index x leading dimension
 #ifdef BRA_EMU
 __device__ __forceinline__ unsigned dg2_mul24(int a, int b) { return ((unsigned)a & 0xffffffu) * ((unsigned)b & 0xffffffu); }
 #else
 __device__ __forceinline__ unsigned dg2_mul24(int a, int b) { return __umul24((unsigned)a, (unsigned)b); }
 #endif
+
+// K-reduction of one column tile: the NW per-wave partial products of a lane in wave order — a FIXED association (see
+// dg2_fold_rstd: a re-associated sum differs in the last bit between the kernels this is inlined into)
+template <int NW>
+__device__ __forceinline__ void dg2_reduce(const float (*slab)[64][4], const int lane, float (&v)[4]) {
+#pragma clang fp reassociate(off)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float sum = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) sum = sum + slab[wv][lane][r];
+        v[r] = sum;
+    }
+}
 
 // epilogue of one column tile, executed by ONE wave on the K-reduced products v (lane: batch row fr, columns 4 fq .. + 3)
 // FULLN: N is a multiple of the tile width (always so with packed weights): no ragged last tile, every column test folds away
@@ -45,6 +81,7 @@ __device__ __forceinline__ unsigned dg2_mul24(int a, int b) { return __umul24((u
 template <int MODE, int ACT, int OUTF32, int FULLN = 0, int XS = 0>
 __device__ __forceinline__ void dg2_epilogue(const DecGemm2Args& g, float (&v)[4], int tile, int lane, bool have_res,
                                              const u32x2& resv) {
+#pragma clang fp reassociate(off)
     constexpr int NCOL = MODE ? 8 : 16;
     const int fr = lane & 15, fq = lane >> 4;
     const int n0 = tile * NCOL;

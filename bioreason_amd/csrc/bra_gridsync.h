@@ -67,7 +67,17 @@ __device__ __forceinline__ void xs_store4f(__amdgpu_buffer_rsrc_t rs, unsigned b
 // Returns false when the launch is being abandoned (timeout): the caller returns at once.
 __device__ __forceinline__ void gs_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-__device__ __forceinline__ bool grid_barrier(GridSync* gs, unsigned& epoch, int nwg, unsigned timeout_ticks, volatile unsigned* flag) {
+// scalar-path read of a polled word: s_load goes through the scalar data cache (invalidated first), not through the CU's vector
+// memory queue — a poll is then not queued behind the weight requests the workgroup has in flight (EXPERIMENT: whether the
+// XCD's L2 serves a fresh copy is what tools/gridbar_probe.py mode 4 / 5 checks)
+__device__ __forceinline__ unsigned gs_load_scalar(const unsigned* p) {
+    unsigned v;
+    asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+template <int SPOLL = 0>
+__device__ __forceinline__ bool grid_barrier(GridSync* gs, unsigned& epoch, int nwg, unsigned timeout_ticks, unsigned* flag) {
     ++epoch;
     __builtin_amdgcn_s_barrier();                      // every wave of the workgroup is past its (drained) stores
     if (threadIdx.x == 0) {
@@ -82,7 +92,7 @@ __device__ __forceinline__ bool grid_barrier(GridSync* gs, unsigned& epoch, int 
             }
         }
         unsigned ok = 1u;
-        while (gs_load(&gs->gen[grp][0]) < epoch) {
+        while ((SPOLL ? gs_load_scalar(&gs->gen[grp][0]) : gs_load(&gs->gen[grp][0])) < epoch) {
             __builtin_amdgcn_s_sleep(2);
             if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)timeout_ticks || gs_load(&gs->err[0]) != 0u) {
                 gs_store(&gs->err[0], epoch);

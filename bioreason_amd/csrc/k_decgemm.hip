@@ -138,14 +138,8 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int srow = (lane >> 3) + 8 * pass;
-                float s = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const f32x4 q = sq[pass][i];
-                    s += 4 * i < per ? (q[0] + q[1]) + (q[2] + q[3]) : 0.f;
-                }
-                s += wave_shfl_xor(s, 1); s += wave_shfl_xor(s, 2); s += wave_shfl_xor(s, 4);
-                if ((lane & 7) == 0) rs_lds[srow] = rsqrtf(s / (float)g.K + g.eps);       // visible after the tile barrier
+                const float rs = dg2_fold_rstd(sq[pass], per, g.inv_K, g.eps);
+                if ((lane & 7) == 0) rs_lds[srow] = rs;       // visible after the tile barrier
             }
         };
         if (NORM == 1) {
@@ -190,13 +184,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
             if (!FAST && it == 0) dg2_stamp(g, 3);
             if (wave == it % NW) {
                 float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int wv = 0; wv < NW; ++wv) sum += slab[wv][lane][r];
-                    v[r] = sum;
-                }
+                dg2_reduce<NW>(slab, lane, v);
                 if (NORM == 2) {
                     const int mrow = MODE ? (fr & 7) : fr;                   // batch row of this lane's products (both K-halves of MODE 1)
                     const float rsf = rs_lds[mrow < g.M ? mrow : g.M - 1];
@@ -390,7 +378,7 @@ extern "C" int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, 
     const bool diag = !wide && !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256;
     if (ss_out && nss_out < (diag ? N / 8 : (N + 15) / 16)) return BRA_ERR_ARG;
     DecGemm2Args g = {(const bf16_t*)x, ldx, ss_in, nss_in, (const bf16_t*)norm_w, eps, (const bf16_t*)W, ldw,
-                      (const bf16_t*)res, ldres, out, ldo, ss_out, nss_out, M, N, K, packed, (unsigned long long*)probe};
+                      (const bf16_t*)res, ldres, out, ldo, ss_out, nss_out, M, N, K, packed, (unsigned long long*)probe, 1.f / (float)K};
     if (packed && (N % (diag ? 8 : 16) || K % (diag ? 64 : 32))) return BRA_ERR_ARG;
     bra_stream_t st = (bra_stream_t)stream;
     if ((packed & 2) && !(packed & 1)) return BRA_ERR_ARG;

@@ -234,6 +234,34 @@ extern "C" int bra_qwen_decode_step_persist(const void* layers_host, const void*
         CK(bra_embed_scatter_fwd(tok, nullptr, E, H, nullptr, 0, x, H, B, H, stream));
         CK(sg_begin(sg, x));
     }
+    if (stop_after <= -100) {
+        // diagnostics: phase by phase, the ops whose mask bit is set (1 qkv, 2 attention, 4 o, 8 gate/up, 16 down) by the LAUNCHED
+        // kernels, the others by single-phase windows of the persistent kernel — localises a numerical difference between the two
+        const int mask = -stop_after - 100;
+        char* ld = (char*)layers_dev;
+        const int rec = bra_persist_layer_desc_size();
+        for (int li = 0; li < L; ++li) {
+            const Layer& l = ls[li];
+            auto win = [&](int p0, int p1) -> int {        // phases [p0, p1) of layer li on a one-layer table
+                return bra_qwen_layers_persist(ld + (long)li * rec, 1, R, copies, H, Hq, Hkv, hd, F, P, vt_pitch, C, cp, eps, scale, cosT,
+                                               sinT, pos, ls[0].rope_rows, pmask, t, t_dev, x, qkv, o, h, act, ss_ws, nss, part_o,
+                                               part_ml, nslot, sync, 0, -1000 - (p0 * 8 + p1), timeout_us, stream);
+            };
+            if (mask & 1) CK(sg_qkv(sg, l, x, qkv)); else CK(win(0, 1));
+            if (mask & 2) CK(bra_dec_attn_one(qkv, Nqkv, l.qn, l.kn, cosT, sinT, pos, ls[0].rope_rows, l.kp, (long)Hkv * P * hd,
+                                              (long)P * hd, (long)hd, l.vtp, (long)Hkv * hd * vt_pitch, (long)hd * vt_pitch, vt_pitch, pmask,
+                                              l.kc, l.vc, cp, part_o, part_ml, nslot, o, Nq, R, copies, Hq, Hkv, hd, P, C, t, eps, scale,
+                                              t_dev, stream));
+            else CK(win(1, 3));
+            const int pk = l.flags & 1;
+            if (mask & 4) CK(bra_dec_gemm2_probe(o, sg.Nq, nullptr, 0, nullptr, 0.f, l.Wo, sg.Nq, x, sg.H, h, sg.H, sg.ssh, sg.nss, sg.B, sg.H, sg.Nq, 0, 0, pk, nullptr, stream));
+            else CK(win(3, 4));
+            if (mask & 8) CK(bra_dec_gemm2_probe(h, sg.H, sg.ssh, sg.nss, l.ln2, sg.eps, l.Wgu, sg.H, nullptr, 0, act, sg.F, nullptr, 0, sg.B, 2 * sg.F, sg.H, 1, 0, l.flags & 3, nullptr, stream));
+            else CK(win(4, 5));
+            if (mask & 16) CK(bra_dec_gemm2_probe(act, sg.F, nullptr, 0, nullptr, 0.f, l.Wd, sg.F, h, sg.H, x, sg.H, sg.ssx, sg.nss, sg.B, sg.H, sg.F, 0, 0, pk, nullptr, stream));
+            else CK(win(5, 6));
+        }
+    } else
     CK(bra_qwen_layers_persist(layers_dev, L, R, copies, H, Hq, Hkv, hd, F, P, vt_pitch, C, cp, eps, scale, cosT, sinT, pos,
                                ls[0].rope_rows, pmask, t, t_dev, x, qkv, o, h, act, ss_ws, nss, part_o, part_ml, nslot, sync,
                                prefetch, stop_after, timeout_us, stream));

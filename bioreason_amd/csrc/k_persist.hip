@@ -20,8 +20,9 @@ namespace bra {
 // the slots are double-buffered by iteration parity, as the step's buffers are by phase.
 template <int NT>
 __global__ __launch_bounds__(NT) void gridbar_probe_kernel(GridSync* gs, unsigned* buf /* [2][nwg][32] */, unsigned* errs,
-                                                           const u32x4* wts, unsigned long wts_chunks, int iters, int mode,
+                                                           const u32x4* wts, unsigned long wts_chunks, int iters, int mode_in,
                                                            int wchunks, unsigned timeout_ticks) {
+    int mode = mode_in;
     __shared__ unsigned flag;
     const int nwg = (int)gridDim.x, wg = (int)blockIdx.x, tid = (int)threadIdx.x;
     unsigned epoch = 0, bad = 0, sink = 0;
@@ -30,6 +31,9 @@ __global__ __launch_bounds__(NT) void gridbar_probe_kernel(GridSync* gs, unsigne
     for (int it = 0; it < iters; ++it) {
         unsigned* slot = buf + (size_t)(it & 1) * nwords;
         u32x4 w[8];
+        const bool spoll = mode >= 4;       // modes 4 / 5 = modes 1 / 3 with the barrier polled through the scalar path
+        if (mode == 5) mode = 3;
+        if (mode == 4) mode = 1;
         if (mode == 3) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(NT) void gridbar_probe_kernel(GridSync* gs, unsigne
         } else if (mode == 3) {
             if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the storing wave drains (its weight chunks with it)
         }
-        if (!grid_barrier(gs, epoch, nwg, timeout_ticks, &flag)) break;
+        if (spoll ? !grid_barrier<1>(gs, epoch, nwg, timeout_ticks, &flag) : !grid_barrier<0>(gs, epoch, nwg, timeout_ticks, &flag)) break;
         if (mode == 2) {
             if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __syncthreads();
@@ -99,28 +103,41 @@ struct PLayer {                           // device-side layer table (one record
     bf16_t *kc, *vct;                       // completion K cache and transposed completion V cache
 };
 
+constexpr int kPersistMaxLayers = 40;     // 40 x 80 B + the rest of the record < the 4 KiB kernel-argument segment
 struct PersistArgs {
-    const PLayer* layers; int L, M;
+    // the layer table travels IN the kernel arguments: pointers read from the argument segment are known to be global, pointers
+    // read from a table in memory are not — every access through them would be a FLAT instruction, which counts in lgkmcnt too, so
+    // each LDS wait of a tile barrier would wait for the whole weight stream in flight
+    PLayer layers[kPersistMaxLayers]; int L, M;
     DecOneArgs att;                         // per-layer pointer fields are patched from the table
     bf16_t *x, *h, *act; float *ssx, *ssh; int nss; float eps;
-    GridSync* sync; unsigned timeout_ticks; int stop_after;
+    GridSync* sync; unsigned timeout_ticks;
+    int ph_lo, ph_hi;                       // phases [ph_lo, ph_hi) of the 6 L run in this launch (diagnostics; the whole step: 0, 6 L)
+    unsigned long long* stamps;             // diagnostics (bra_persist_set_stamps): 100 MHz wall-clock stamps of workgroup 0 / wave 0,
+                                            // [6 L][4]: phase start, own requests issued + computed, stores issued, stores drained
 };
 
 #ifndef BRA_EMU
 template <int NL> struct Frag { u32x4 v[NL]; };
 
+// wait until at most N of this wave's vector-memory operations are outstanding: with N look-ahead requests issued LAST, everything
+// older (the phase's stores among them) has completed while the look-ahead stays in flight across the grid barrier
+template <int N> __device__ __forceinline__ void wait_all_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // the wave's NL consecutive KiB blocks of one packed column tile (dec_gemm2_kernel FAST: tile_base + wo[u])
-template <int NW, int NL>
+// blocks [U0, U1) of the NL: a tile can be requested in instalments (look-ahead windows hold ~48 KB per CU: what drains from
+// the CU's request queue while the grid barrier is pending)
+template <int NW, int NL, int U0 = 0, int U1 = NL>
 __device__ __forceinline__ void pw_issue(Frag<NL>& w, const bf16_t* W, const int tile, const int wave, const int lane) {
     // (every path DEFINES the fragment: a fragment left untouched on one path would be carried around the layer loop)
     if (NW < 8 && wave >= NW) {
 #pragma unroll
-        for (int u = 0; u < NL; ++u) w.v[u] = u32x4{0u, 0u, 0u, 0u};
+        for (int u = U0; u < U1; ++u) w.v[u] = u32x4{0u, 0u, 0u, 0u};
         return;
     }
     const bf16_t* p = W + (long)tile * (NW * NL * 512) + (unsigned)(wave * (NL * 512) + lane * 8);
 #pragma unroll
-    for (int u = 0; u < NL; ++u) w.v[u] = ld16_nt(p + u * 512);
+    for (int u = U0; u < U1; ++u) w.v[u] = ld16_nt(p + u * 512);
 }
 
 // the wave's activation fragments (rows of another workgroup's output: sc1)
@@ -178,16 +195,8 @@ __device__ __forceinline__ void pg_tile(const Frag<NL>& w, const Frag<NL>& x, co
 #pragma unroll
         for (int u = 0; u < NL; ++u) acc = mfma_16x16x32(w.v[u], x.v[u], acc);
         if (NORM == 2 && it == 0 && wave == 0) {
-            const int per = g.nss_in >> 3;
-            const int srow = lane >> 3;
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x4 q = sq[i];
-                s += 4 * i < per ? (q[0] + q[1]) + (q[2] + q[3]) : 0.f;
-            }
-            s += wave_shfl_xor(s, 1); s += wave_shfl_xor(s, 2); s += wave_shfl_xor(s, 4);
-            if ((lane & 7) == 0) rs_lds[srow] = rsqrtf(s / (float)g.K + g.eps);
+            const float rs = dg2_fold_rstd(sq, g.nss_in >> 3, g.inv_K, g.eps);
+            if ((lane & 7) == 0) rs_lds[lane >> 3] = rs;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[it & 1][wave][lane][r] = acc[r];
@@ -195,13 +204,7 @@ __device__ __forceinline__ void pg_tile(const Frag<NL>& w, const Frag<NL>& x, co
     raw_barrier();
     if (wave == it % NW) {
         float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float sum = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < NW; ++wv) sum += red[it & 1][wv][lane][r];
-            v[r] = sum;
-        }
+        dg2_reduce<NW>(red[it & 1], lane, v);
         if (NORM == 2) {
             const int mrow = MODE ? (fr & 7) : fr;
             const float rsf = rs_lds[mrow < g.M ? mrow : g.M - 1];
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(512) void decode_persist_kernel(PersistArgs a) {
     constexpr int NW_O = (NQ / 64 >= 64) ? 8 : 4, NL_O = NQ / 64 / NW_O;
     constexpr int NL_D = F / 64 / 8;
     constexpr int NT_GU = 2 * F / 16 / NWG;
+    constexpr int GU_A = 3;                                      // blocks of the first gate/up tile requested in the merge phase's window
     static_assert(H % 256 == 0 && (NL_QKV == 4 || NL_QKV == 8 || NL_QKV == 12), "qkv / gate-up: one register round of 8 waves");
     static_assert(H / 8 == NWG && (2 * F / 16) % NWG == 0 && NT_GU == 3, "tiles per workgroup: 1 qkv, 1 o, 3 gate/up, 1 down");
     static_assert(NQ % (64 * NW_O) == 0 && (NL_O == 4 || NL_O == 8 || NL_O == 12) && F % 512 == 0 && (NL_D == 4 || NL_D == 8 || NL_D == 12), "o / down");
@@ -251,12 +255,21 @@ __global__ __launch_bounds__(512) void decode_persist_kernel(PersistArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) sq0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     Frag<NL_QKV> wq;                          // the only fragment carried from one layer to the next (PF)
+#define BRA_PSTAMP(k_)                                                                        \
+    do {                                                                                      \
+        if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[phases * 4 + (k_)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+    // phase window (diagnostics): a phase outside [ph_lo, ph_hi) is skipped, a barrier is taken only between two phases that run
+    // (PF > 0 always runs from phase 0: the tests fold away, no fragment becomes conditionally defined)
+#define BRA_PRUN() (PF > 0 || (phases >= a.ph_lo && phases < a.ph_hi))
 #define BRA_PBAR()                                                                            \
     do {                                                                                      \
-        if (a.stop_after > 0 && ++phases >= a.stop_after) return;                             \
-        if (!grid_barrier(a.sync, epoch, NWG, a.timeout_ticks, &bar_flag)) return;            \
+        const bool both_ = PF > 0 || (phases >= a.ph_lo && phases + 1 < a.ph_hi);             \
+        ++phases;                                                                             \
+        if (phases >= a.ph_hi) return;                                                        \
+        if (both_ && !grid_barrier(a.sync, epoch, NWG, a.timeout_ticks, &bar_flag)) return;   \
     } while (0)
-    const PLayer* Ls = a.layers;
+    const PLayer* Ls = a.layers;            // (in the kernel-argument segment)
     if (PF) { BRA_PIDS(); pw_issue<8, NL_QKV>(wq, Ls[0].Wqkv, wg, wave, lane_id()); sched_fence(); }
     for (int l = 0; l < a.L; ++l) {
         const PLayer Lr = Ls[l];
@@ -266,28 +279,34 @@ __global__ __launch_bounds__(512) void decode_persist_kernel(PersistArgs a) {
         at.qw = Lr.qn; at.kw = Lr.kn; at.kp = Lr.kp; at.vtp = Lr.vtp; at.kc = Lr.kc; at.vct = Lr.vct;
         // ------------------------------------------------------------------ qkv = rmsnorm(x) Wqkv^T   (ln1 folded, rstd in the epilogue)
         {
-            BRA_PIDS();
-            DecGemm2Args g = {a.x, H, a.ssx, a.nss, nullptr, a.eps, Lr.Wqkv, H, nullptr, 0, (void*)at.qkv, NQKV, nullptr, 0, M, NQKV, H, 3, nullptr};
             u32x4 kf[4][HD / 32], vf[HD / 16][2];
             DecItem it0;
             it0.kind = 0;
+            if (BRA_PRUN()) {
+            BRA_PIDS();
+            DecGemm2Args g = {a.x, H, a.ssx, a.nss, nullptr, a.eps, Lr.Wqkv, H, nullptr, 0, (void*)at.qkv, NQKV, nullptr, 0, M, NQKV, H, 3, nullptr, 1.f / (float)H};
             if (PF >= 2) {                  // the wave's attention item: its K / V^T chunk does not depend on the new token
                 const int iw = wg + NWG * wave;
                 if (iw < nitems) dec_item_decode<HD, G>(at, iw, t, it0);
                 if (it0.kind == 2) item_kv_issue<HD>(it0.kbase, it0.kss, it0.vbase, it0.vsd, it0.key0, it0.nkeys, kf, vf);
                 sched_fence();
             }
+            BRA_PSTAMP(0);
             if (!PF) pw_issue<8, NL_QKV>(wq, Lr.Wqkv, wg, wave, lane_id());
             Frag<NL_QKV> xf;
             px_load<0, 8, NL_QKV>(xf, a.x, H, M, wave, lane_id());
             f32x4 sq[8];
             ps_load(sq, a.ssx, a.nss, M, wave, lane_id());
             pg_tile<0, 2, 0, 8, NL_QKV>(wq, xf, g, wg, 0, zero2, sq, red, rs_lds, wave, lane_id());
+            BRA_PSTAMP(2);
             if (wave == 0) gs_drain();
+            BRA_PSTAMP(3);
+            }
             BRA_PBAR();
             // -------------------------------------------------------------- attention items: q/k norm + RoPE, cache append, partials
-          {
+          if (BRA_PRUN()) {
             BRA_PIDS();
+            BRA_PSTAMP(0);
             if (PF >= 2) {
                 if (wg + NWG * wave < nitems) dec_item_run<HD, G, 1, 1>(at, it0, t, kf, vf);
                 for (int i = wg + NWG * (wave + 8); i < nitems; i += NWG * 8) {
@@ -302,45 +321,73 @@ __global__ __launch_bounds__(512) void decode_persist_kernel(PersistArgs a) {
                     dec_item_run<HD, G, 1, 0>(at, d, t, kf, vf);
                 }
             }
+            BRA_PSTAMP(2);
             gs_drain();
+            BRA_PSTAMP(3);
           }
             BRA_PBAR();
         }
         // ------------------------------------------------------------------ merge of the partials -> o
-        {
+        if (BRA_PRUN()) {
         BRA_PIDS();
-        if (PF) {                           // weights of the next two phases: o, and the first two gate/up tiles
-            pw_issue<NW_O, NL_O>(wo, Lr.Wo, wg, wave, lane_id());
-            pw_issue<8, NL_QKV>(wg0, Lr.Wgu, wg, wave, lane_id());
+        BRA_PSTAMP(0);
+        // look-ahead requests (PF) go out BEHIND the phase's own requests: loads return in order, so a weight request issued first
+        // would have to land before the phase's own operands can be used
+        auto look_ahead = [&]() {           // o projection + first gate/up tile
+            if (PF) {
+                pw_issue<NW_O, NL_O>(wo, Lr.Wo, wg, wave, lane_id());
+                pw_issue<8, NL_QKV, 0, GU_A>(wg0, Lr.Wgu, wg, wave, lane_id());
+                sched_fence();
+            }
+        };
+        {                                   // at most one (sequence, q-head) pair per wave: M Hq <= 128 < 8 NWG waves
+            const int i = wg + NWG * wave;
+            if (i < M * at.Hq) {
+                const int b = da_div(i, at.inv_Hq);
+                dec_attn_merge_one<HD, 1>(at, i - b * at.Hq, b);
+            }
+        }
+        BRA_PSTAMP(2);
+        // look-ahead requests go out LAST in a phase: a CU serves its waves' requests in arrival order, so a burst of weight
+        // requests issued earlier delays the phase's own (latency-critical) operands — measured: merge 1.7 -> 5.5 us
+        gs_drain();                         // the wave's stores of o have left before any look-ahead enters the CU's queue
+        if (PF) {
+            bare_barrier();                 // ... and so have every other wave's of this workgroup
             sched_fence();
+            look_ahead();
         }
-        for (int i = wg + NWG * wave; i < M * at.Hq; i += NWG * 8) {
-            const int b = da_div(i, at.inv_Hq);
-            dec_attn_merge_one<HD, 1>(at, i - b * at.Hq, b);
-        }
-        gs_drain();
+        BRA_PSTAMP(3);
         }
         BRA_PBAR();
         // ------------------------------------------------------------------ h = x + o Wo^T  (+ statistics of h)
         {
+            if (BRA_PRUN()) {
             BRA_PIDS();
-            DecGemm2Args g = {at.o, NQ, nullptr, 0, nullptr, 0.f, Lr.Wo, NQ, a.x, H, (void*)a.h, H, a.ssh, a.nss, M, H, NQ, 1, nullptr};
-            if (PF) {                       // the second gate/up tile and the down projection
-                pw_issue<8, NL_QKV>(wg1, Lr.Wgu, wg + NWG, wave, lane_id());
-                pw_issue<8, NL_D>(wd, Lr.Wd, wg, wave, lane_id());
-                sched_fence();
-            } else pw_issue<NW_O, NL_O>(wo, Lr.Wo, wg, wave, lane_id());
+            BRA_PSTAMP(0);
+            DecGemm2Args g = {at.o, NQ, nullptr, 0, nullptr, 0.f, Lr.Wo, NQ, a.x, H, (void*)a.h, H, a.ssh, a.nss, M, H, NQ, 1, nullptr, 1.f / (float)NQ};
+            if (!PF) pw_issue<NW_O, NL_O>(wo, Lr.Wo, wg, wave, lane_id());
             Frag<NL_O> xf;
             px_load<1, NW_O, NL_O>(xf, at.o, NQ, M, wave, lane_id());
             const u32x2 resv = pr_load<1>(a.x, H, M, H, wg, lane_id());
             pg_tile<1, 0, 0, NW_O, NL_O>(wo, xf, g, wg, 0, resv, sq0, red, rs_lds, wave, lane_id());
+            BRA_PSTAMP(2);
             if (wave == 0) gs_drain();
+            if (PF) {                       // look ahead (last, behind the epilogue wave's drained stores): first half of the down projection
+                bare_barrier();
+                sched_fence();
+                pw_issue<8, NL_D, 0, NL_D / 2>(wd, Lr.Wd, wg, wave, lane_id());
+                sched_fence();
+            }
+            BRA_PSTAMP(3);
+            }
             BRA_PBAR();
         }
         // ------------------------------------------------------------------ act = silu(gate) * up of rmsnorm(h) Wgu^T  (ln2 folded)
         {
+            if (BRA_PRUN()) {
             BRA_PIDS();
-            DecGemm2Args g = {a.h, H, a.ssh, a.nss, nullptr, a.eps, Lr.Wgu, H, nullptr, 0, (void*)a.act, F, nullptr, 0, M, 2 * F, H, 3, nullptr};
+            BRA_PSTAMP(0);
+            DecGemm2Args g = {a.h, H, a.ssh, a.nss, nullptr, a.eps, Lr.Wgu, H, nullptr, 0, (void*)a.act, F, nullptr, 0, M, 2 * F, H, 3, nullptr, 1.f / (float)H};
             if (!PF) {
                 pw_issue<8, NL_QKV>(wg0, Lr.Wgu, wg, wave, lane_id());
                 pw_issue<8, NL_QKV>(wg1, Lr.Wgu, wg + NWG, wave, lane_id());
@@ -349,28 +396,55 @@ __global__ __launch_bounds__(512) void decode_persist_kernel(PersistArgs a) {
             px_load<0, 8, NL_QKV>(xf, a.h, H, M, wave, lane_id());
             f32x4 sq[8];
             ps_load(sq, a.ssh, a.nss, M, wave, lane_id());
+            if (PF) {                       // the rest of the first tile and the second tile, behind the phase's own operands
+                sched_fence();
+                pw_issue<8, NL_QKV, GU_A, NL_QKV>(wg0, Lr.Wgu, wg, wave, lane_id());
+                pw_issue<8, NL_QKV>(wg1, Lr.Wgu, wg + NWG, wave, lane_id());
+                sched_fence();
+            }
             pg_tile<0, 2, 1, 8, NL_QKV>(wg0, xf, g, wg, 0, zero2, sq, red, rs_lds, wave, lane_id());
             pw_issue<8, NL_QKV>(wg0, Lr.Wgu, wg + 2 * NWG, wave, lane_id());
             pg_tile<0, 2, 1, 8, NL_QKV>(wg1, xf, g, wg + NWG, 1, zero2, sq, red, rs_lds, wave, lane_id());
-            if (PF && l + 1 < a.L) { pw_issue<8, NL_QKV>(wq, Ls[l + 1].Wqkv, wg, wave, lane_id()); sched_fence(); }
             pg_tile<0, 2, 1, 8, NL_QKV>(wg0, xf, g, wg + 2 * NWG, 2, zero2, sq, red, rs_lds, wave, lane_id());
+            BRA_PSTAMP(2);
             if (wave < 3) gs_drain();
+            if (PF) {                       // look ahead (last): second half of the down projection
+                bare_barrier();
+                sched_fence();
+                pw_issue<8, NL_D, NL_D / 2, NL_D>(wd, Lr.Wd, wg, wave, lane_id());
+                sched_fence();
+            }
+            BRA_PSTAMP(3);
+            }
             BRA_PBAR();
         }
         // ------------------------------------------------------------------ x = h + act Wd^T  (+ statistics of x)
         {
+            if (BRA_PRUN()) {
             BRA_PIDS();
-            DecGemm2Args g = {a.act, F, nullptr, 0, nullptr, 0.f, Lr.Wd, F, a.h, H, (void*)a.x, H, a.ssx, a.nss, M, H, F, 1, nullptr};
+            BRA_PSTAMP(0);
+            DecGemm2Args g = {a.act, F, nullptr, 0, nullptr, 0.f, Lr.Wd, F, a.h, H, (void*)a.x, H, a.ssx, a.nss, M, H, F, 1, nullptr, 1.f / (float)F};
             if (!PF) pw_issue<8, NL_D>(wd, Lr.Wd, wg, wave, lane_id());
             Frag<NL_D> xf;
             px_load<1, 8, NL_D>(xf, a.act, F, M, wave, lane_id());
             const u32x2 resv = pr_load<1>(a.h, H, M, H, wg, lane_id());
             pg_tile<1, 0, 0, 8, NL_D>(wd, xf, g, wg, 0, resv, sq0, red, rs_lds, wave, lane_id());
+            BRA_PSTAMP(2);
             if (wave == 0) gs_drain();
+            if (PF) {                       // look ahead (last): the next layer's qkv tile
+                bare_barrier();
+                sched_fence();
+                pw_issue<8, NL_QKV>(wq, Ls[l + 1 < a.L ? l + 1 : l].Wqkv, wg, wave, lane_id());
+                sched_fence();
+            }
+            BRA_PSTAMP(3);
+            }
             BRA_PBAR();
         }
     }
 #undef BRA_PBAR
+#undef BRA_PRUN
+#undef BRA_PSTAMP
 #undef BRA_PIDS
 }
 #endif  // !BRA_EMU
@@ -390,8 +464,8 @@ extern "C" int bra_gridbar_probe(void* sync, void* buf, void* errs, const void* 
     (void)sync; (void)buf; (void)errs; (void)wts; (void)wts_bytes; (void)nwg; (void)iters; (void)mode; (void)wchunks; (void)timeout_us; (void)stream;
     return BRA_ERR_UNSUPPORTED;       // workgroups of an emulated launch run one after another: nothing to synchronise
 #else
-    if (!sync || !buf || !errs || nwg <= 0 || iters <= 0 || mode < 0 || mode > 3 || wchunks < 0 || wchunks > 8) return BRA_ERR_ARG;
-    if (mode == 3 && (!wts || wts_bytes < 16)) return BRA_ERR_ARG;
+    if (!sync || !buf || !errs || nwg <= 0 || iters <= 0 || mode < 0 || mode > 5 || wchunks < 0 || wchunks > 8) return BRA_ERR_ARG;
+    if ((mode == 3 || mode == 5) && (!wts || wts_bytes < 16)) return BRA_ERR_ARG;
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return BRA_ERR_ARG;
     if (nwg > ncu) return BRA_ERR_UNSUPPORTED;
@@ -409,7 +483,20 @@ extern "C" int bra_gridbar_probe(void* sync, void* buf, void* errs, const void* 
 
 extern "C" int bra_persist_layer_desc_size(void) { return (int)sizeof(PLayer); }
 
-// All decoder layers of one shared-prefix decode step in ONE launch (see decode_persist_kernel).  `layers_dev`: device array of L
+#ifndef BRA_EMU
+static std::atomic<unsigned long long*> g_persist_stamps{nullptr};
+#endif
+// diagnostics knob: device buffer of 6 L x 4 stamps filled by the next persistent launches (null: off)
+extern "C" int bra_persist_set_stamps(void* p) {
+#ifndef BRA_EMU
+    g_persist_stamps = (unsigned long long*)p;
+#else
+    (void)p;
+#endif
+    return 0;
+}
+
+// All decoder layers of one shared-prefix decode step in ONE launch (see decode_persist_kernel).  `layers_dev`: HOST array of L
 // records {Wqkv, Wo, Wgu, Wd (fragment-packed, norms folded), qn, kn, kp, vtp, kc, vct} (bra_persist_layer_desc_size() bytes
 // each); every other argument as bra_qwen_decode_step_one.  x / ss_ws hold the embedded token rows and their RMSNorm statistics
 // on entry and the last layer's output + statistics on exit (the caller runs the lm_head).  sync: bra_gridsync_bytes() bytes.
@@ -428,7 +515,7 @@ extern "C" int bra_qwen_layers_persist(const void* layers_dev, int L, int R, int
     (void)timeout_us; (void)stream;
     return BRA_ERR_UNSUPPORTED;       // a persistent grid needs concurrently resident workgroups
 #else
-    if (!layers_dev || L <= 0 || R <= 0 || copies <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || P <= 0 || t < 0 || t >= C) return BRA_ERR_ARG;
+    if (!layers_dev || L <= 0 || L > kPersistMaxLayers || R <= 0 || copies <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || P <= 0 || t < 0 || t >= C) return BRA_ERR_ARG;
     if (!cosT || !sinT || !pos || !x || !qkv || !o || !h || !act || !ss_ws || !part_o || !part_ml || !sync) return BRA_ERR_ARG;
     const int B = R * copies, G = Hq / Hkv;
     if (B > 8 || copies * G > 16) return BRA_ERR_UNSUPPORTED;
@@ -447,24 +534,39 @@ extern "C" int bra_qwen_layers_persist(const void* layers_dev, int L, int R, int
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return BRA_ERR_ARG;
     PersistArgs a;
-    a.layers = (const PLayer*)layers_dev; a.L = L; a.M = B;
+    for (int i = 0; i < L; ++i) a.layers[i] = ((const PLayer*)layers_dev)[i];
+    a.L = L; a.M = B;
     a.att = DecOneArgs{(const bf16_t*)qkv, (long)(Nq + 2 * Nkv), nullptr, nullptr, cosT, sinT, pos, rope_rows,
                        nullptr, kp_sr, kp_sh, kp_ss, nullptr, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask,
                        nullptr, nullptr, cp, part_o, part_ml, (bf16_t*)o, (long)Nq,
                        R, copies, Hq, Hkv, P, C, t, nslot, npc, ncc, eps, scale, t_dev,
                        1.f / (float)Hq, 1.f / (float)npc, 1.f / (float)Hkv, 1.f / (float)(ncc > 0 ? ncc : 1), 1.f / (float)copies};
     a.x = (bf16_t*)x; a.h = (bf16_t*)h; a.act = (bf16_t*)act; a.ssx = ss_ws; a.ssh = ss_ws + 8 * (long)nss; a.nss = nss; a.eps = eps;
-    a.sync = (GridSync*)sync; a.timeout_ticks = (unsigned)(timeout_us > 0 ? timeout_us : 50000) * 100u; a.stop_after = stop_after;
+    a.sync = (GridSync*)sync; a.timeout_ticks = (unsigned)(timeout_us > 0 ? timeout_us : 50000) * 100u;
+    // stop_after (diagnostics): 0 = the whole step in one launch; k > 0 = phases [0, k); -1 = one launch per phase; -2 = one per layer
+    // stop_after <= -1000: -(1000 + 8 p0 + p1): exactly the phases [p0, p1) in one launch
+    const int nph = 6 * L;
+    int first = 0;
+    int win = stop_after == -1 ? 1 : (stop_after == -2 ? 6 : nph);
+    int last = stop_after > 0 ? (stop_after < nph ? stop_after : nph) : nph;
+    if (stop_after <= -1000) { const int c = -stop_after - 1000; first = c / 8; last = c % 8; win = nph; if (first >= last || last > nph) return BRA_ERR_ARG; }
+    if (stop_after < 0 && prefetch > 0) return BRA_ERR_ARG;            // windows skip the requests a later phase relies on
+    // stop_after <= -100 (diagnostics): -(100 + mask): one launch per phase, the ops whose mask bit is set (1 qkv, 2 attention, 4 o,
+    // 8 gate/up, 16 down) by the LAUNCHED kernels (needs layers_host in `timeout_us`... no: see bra_qwen_layers_mixed)
+    a.stamps = g_persist_stamps;
     hipStream_t st = (hipStream_t)stream;
 #define BRA_PERSIST(H_, NQ_, NKV_, F_, HD_, G_)                                                                                   \
     if (H == H_ && Nq == NQ_ && Nkv == NKV_ && F == F_ && hd == HD_ && G == G_) {                                                 \
         constexpr int NWG = (NQ_ + 2 * NKV_) / 16;                                                                                \
         if (ncu < NWG) return BRA_ERR_UNSUPPORTED;                  /* every workgroup must be resident */                        \
-        hipError_t e = hipMemsetAsync(sync, 0, sizeof(GridSync), st);                                                             \
-        if (e != hipSuccess) return (int)e;                                                                                       \
-        if (prefetch <= 0) BRA_LAUNCH((decode_persist_kernel<H_, NQ_, NKV_, F_, HD_, G_, 0>), dim3(NWG), dim3(512), 0, st, a);    \
-        else if (prefetch == 1) BRA_LAUNCH((decode_persist_kernel<H_, NQ_, NKV_, F_, HD_, G_, 1>), dim3(NWG), dim3(512), 0, st, a); \
-        else BRA_LAUNCH((decode_persist_kernel<H_, NQ_, NKV_, F_, HD_, G_, 2>), dim3(NWG), dim3(512), 0, st, a);                  \
+        for (int lo = first; lo < last; lo += win) {                                                                                \
+            a.ph_lo = lo; a.ph_hi = lo + win < last ? lo + win : last;                                                            \
+            hipError_t e = hipMemsetAsync(sync, 0, sizeof(GridSync), st);                                                         \
+            if (e != hipSuccess) return (int)e;                                                                                   \
+            if (prefetch <= 0) BRA_LAUNCH((decode_persist_kernel<H_, NQ_, NKV_, F_, HD_, G_, 0>), dim3(NWG), dim3(512), 0, st, a); \
+            else if (prefetch == 1) BRA_LAUNCH((decode_persist_kernel<H_, NQ_, NKV_, F_, HD_, G_, 1>), dim3(NWG), dim3(512), 0, st, a); \
+            else BRA_LAUNCH((decode_persist_kernel<H_, NQ_, NKV_, F_, HD_, G_, 2>), dim3(NWG), dim3(512), 0, st, a);              \
+        }                                                                                                                         \
         return BRA_LAUNCH_STATUS();                                                                                               \
     }
     BRA_PERSIST(2048, 2048, 1024, 6144, 128, 2)                     // Qwen3-1.7B (the reference's "Qwen3-1B", sh_reason.sh:46)

@@ -256,21 +256,21 @@ class SharedDecodeState:
         # BRA_DEC_PERSIST: "0" launched kernels, "1" / "2" / "3" persistent with prefetch level 0 / 1 / 2; default: persistent where the
         # kernel is instantiated for the shape (<= 8 sequences, packed + folded weights, one CU per workgroup)
         self.persist = None
-        mode = os.environ.get("BRA_DEC_PERSIST", "2")
+        mode = os.environ.get("BRA_DEC_PERSIST", "0")
         if mode != "0" and self.attn_impl == "one" and use_packed and B <= 8 and all(Rw.get("folded") for Rw in self.rw) and dev.type == "cuda":
             tab = torch.tensor([[Rw["Wqkv_p"].data_ptr(), Rw["Wo_p"].data_ptr(), Rw["Wgu_p"].data_ptr(), Rw["Wd_p"].data_ptr(),
                                  L.qn.data_ptr(), L.kn.data_ptr(), self.kp[i].data_ptr(), self.vtp[i].data_ptr(),
                                  self.kc[i].data_ptr(), self.vc[i].data_ptr()] for i, (L, Rw) in enumerate(zip(eng.layers, self.rw))],
                                dtype=torch.int64)
             assert tab.shape[1] * 8 == get_lib()._dll.bra_persist_layer_desc_size()
-            self.persist = {"table": tab.to(dev), "sync": torch.zeros(2048, dtype=torch.uint8, device=dev),
+            self.persist = {"table": tab.contiguous(), "sync": torch.zeros(2048, dtype=torch.uint8, device=dev),       # (host table)
                             "prefetch": max(0, int(mode) - 1), "ok": None}
 
     def step(self, tok, pos, pmask, t: int, logits: torch.Tensor, t_dev=None, embed_done: bool = False):
         e = self.eng
         if self.persist is not None and self.persist["ok"] is not False:
             ps = self.persist
-            rc = get_lib().call_rc("bra_qwen_decode_step_persist", ctypes.addressof(self.arr), ps["table"], e.L, self.R, self.copies, e.H,
+            rc = get_lib().call_rc("bra_qwen_decode_step_persist", ctypes.addressof(self.arr), ps["table"].data_ptr(), e.L, self.R, self.copies, e.H,
                                    e.Hq, e.Hkv, e.hd, e.F, self.P, self.vt_pitch, self.C, self.cp, e.V, e.eps, e.scale, e.E, e.norm_w,
                                    self.cosT, self.sinT, tok, pos, pmask, t, t_dev, int(embed_done), self.x, self.qkv, self.o, self.h,
                                    self.act, self.ss_ws, self.nss, self.part_o, self.part_ml, self.part_o.shape[2], logits, ps["sync"],

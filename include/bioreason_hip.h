@@ -14,8 +14,8 @@
  *   - every function returns 0 on success, a positive hipError_t if the launch
  *     failed, or a negative BRA_ERR_* for a rejected argument; nothing throws,
  *     nothing allocates, nothing synchronises; workspaces come from the caller.
- *   - all compute entry points are re-entrant and thread-safe.  The ONLY process-wide mutable state is four test /
- *     benchmark knobs — bra_gemm_set_variant, bra_gemm_set_ring_fill, bra_gemm_set_row_split, bra_debug_set_probe —
+ *   - all compute entry points are re-entrant and thread-safe.  The ONLY process-wide mutable state is five test /
+ *     benchmark knobs — bra_gemm_set_variant, bra_gemm_set_ring_fill, bra_gemm_set_row_split, bra_debug_set_probe, bra_persist_set_stamps —
  *     held in atomics (a concurrent launch sees the old or the new value, never a torn one), an init-once
  *     "dynamic LDS opted in" flag per kernel and device, and an init-once device-properties cache.  The knobs select
  *     between bit-identical tilings (results do not depend on them); production callers never touch them.
@@ -350,12 +350,15 @@ int bra_gridsync_bytes(void);
  * KV cache, TF:qwen3:294-323) in ONE launch of one workgroup per CU: six phases per layer separated by in-launch grid barriers,
  * the same tiles / K split / reduction order / epilogues as the launched kernels (bit-identical results), the weights of the
  * following phases requested before the barrier that hands over their activations (prefetch 1; 2: also the K / V^T chunk of the
- * wave's attention item).  layers_dev: device array of L records of bra_persist_layer_desc_size() bytes {Wqkv, Wo, Wgu, Wd
- * (fragment-packed, norms folded), qn, kn, kp, vtp, kc, vct}.  x / ss_ws: embedded token rows + statistics in, last layer's
+ * wave's attention item).  layers_dev: HOST array of L <= 40 records of bra_persist_layer_desc_size() bytes {Wqkv, Wo, Wgu, Wd
+ * (fragment-packed, norms folded), qn, kn, kp, vtp, kc, vct} (device pointers; the table is copied into the kernel arguments).  x / ss_ws: embedded token rows + statistics in, last layer's
  * output + statistics out.  sync: bra_gridsync_bytes() bytes (zeroed by the call).  Every spin is bounded by timeout_us; a
  * timed-out launch leaves a non-zero word at sync + 1088 (GridSync::err).  BRA_ERR_UNSUPPORTED: shape not instantiated, more
  * than 8 sequences, fewer CUs than workgroups. */
 int bra_persist_layer_desc_size(void);
+/* diagnostics knob (process-wide, atomic): device buffer of 6 L x 4 100-MHz wall-clock stamps of workgroup 0 filled by the following
+ * persistent launches (per phase: start, -, stores issued, stores drained); null turns it off */
+int bra_persist_set_stamps(void* p);
 int bra_qwen_layers_persist(const void* layers_dev, int L, int R, int copies, int H, int Hq, int Hkv, int hd, int F, int P,
                             long vt_pitch, int C, long cp, float eps, float scale, const float* cosT, const float* sinT,
                             const int* pos, const float* rope_rows, const void* pmask, int t, const int* t_dev, void* x,

@@ -14,8 +14,9 @@ buf = torch.zeros(2 * nwg * 32, dtype=torch.int32, device=dev)
 errs = torch.zeros(4, dtype=torch.int32, device=dev)
 wts = torch.randint(0, 2 ** 31 - 1, (1 << 28,), dtype=torch.int32, device=dev)      # 1 GiB: past the 256 MiB Infinity Cache
 print("CUs", nwg)
-for mode, wch, name in [(0, 0, "barrier only"), (1, 0, "sc1 stores / sc1 loads"), (2, 0, "plain + release / acquire fences"),
-                        (3, 2, "sc1 + 16 MB weight stream across the barrier"), (3, 4, "sc1 + 32 MB stream"), (3, 8, "sc1 + 64 MB stream")]:
+for mode, wch, name in [(0, 0, "barrier only"), (1, 0, "sc1 stores / sc1 loads"), (4, 0, "sc1, scalar-path poll"),
+                        (3, 2, "sc1 + 4 MB weight stream across the barrier"), (3, 4, "sc1 + 8 MB stream"), (3, 8, "sc1 + 16 MB stream"),
+                        (5, 2, "scalar poll + 4 MB stream"), (5, 4, "scalar poll + 8 MB stream"), (5, 8, "scalar poll + 16 MB stream")]:
     for iters in (200, 2000):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -27,6 +28,6 @@ for mode, wch, name in [(0, 0, "barrier only"), (1, 0, "sc1 stores / sc1 loads")
         er = errs.tolist()
         tmo = int(sync.view(torch.int32)[8 * 16 + 16 + 8 * 16].item())
         extra = ""
-        if mode == 3:
+        if mode in (3, 5):
             extra = "  stream %.2f TB/s" % (nwg * 512 * wch * 16 * iters / (ms * 1e-3) / 1e12)
         print(f"mode {mode} [{name}] iters {iters}: {ms * 1e3 / iters:.2f} us / iteration, bad words {er[0]}, barriers {er[1]}, timeout word {tmo}{extra}", flush=True)
