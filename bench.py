@@ -62,7 +62,7 @@ def flops_per_sample_reference():
     return 34.1e12
 
 
-def executed_flops(world_local_prompts: int, P: int, Cn: int, mode: str):
+def executed_flops(world_local_prompts: int, P: int, Cn: int, mode: str, shared_policy: bool = True):
     """FLOPs this implementation actually executes per step and GPU (shared prompts are run once): encoder once per distinct
     sequence, prefill / reference prompt once per distinct prompt, policy forward + backward for every row."""
     d_e, f_e, L_e = 1024, 4096, 29
@@ -87,8 +87,13 @@ def executed_flops(world_local_prompts: int, P: int, Cn: int, mode: str):
     prefill = lin(R * P) + attn(P, R) + 2 * d * V * R
     decode = Cn * (lin(B) + 2 * d * V * B) + B * L * 4 * q * (Cn * P + Cn * (Cn + 1) / 2)
     ref = lin(R * P + B * Cn) + attn(P, R) + B * L * 4 * q * (Cn * P + Cn * (Cn + 1) / 2) + 2 * d * V * B * Cn
-    pol_f = lin(B * S) + attn(S, B) + 2 * d * V * B * Cn
-    pol_b = lin(B * S) + 2.5 * attn(S, B) + 2 * 2 * d * V * B * Cn
+    if shared_policy:        # the prompt rows of a group once (forward AND backward), the completion rows per copy
+        att = attn(P, R) + B * L * 4 * q * (Cn * P + Cn * (Cn + 1) / 2)
+        pol_f = lin(R * P + B * Cn) + att + 2 * d * V * B * Cn
+        pol_b = lin(R * P + B * Cn) + 2.5 * att + 2 * 2 * d * V * B * Cn
+    else:
+        pol_f = lin(B * S) + attn(S, B) + 2 * d * V * B * Cn
+        pol_b = lin(B * S) + 2.5 * attn(S, B) + 2 * 2 * d * V * B * Cn
     return enc + prefill + decode + ref + pol_f + pol_b
 
 
@@ -347,7 +352,7 @@ def build_model(dims: Dims, dev, lora_dropout: float):
     return model
 
 
-def make_grpo_leg(model, dims: Dims, R: int, Cn: int, rank: int, dev, args, eos_uniform, nsteps: int):
+def make_grpo_leg(model, dims: Dims, R: int, Cn: int, rank: int, dev, args, eos_uniform, nsteps: int, share_policy=None):
     """-> (runner, step(i, timing), samples per step): cfg-3 GRPO step on R prompts x G rollouts of this rank"""
     import torch
     from bioreason_amd.rewards import text_reward_fn
@@ -356,7 +361,8 @@ def make_grpo_leg(model, dims: Dims, R: int, Cn: int, rank: int, dev, args, eos_
     B = dims.g * R
     eos_id = dims.eos if eos_uniform else None
     cfg = GRPOConfig(num_generations=dims.g, max_completion_length=Cn, eos_token_id=eos_id, pad_token_id=dims.pad if eos_id else None,
-                     seed=42, rollout_graph=False if args.no_graph else None, rollout_shared_prefix=not args.no_shared_decode)
+                     seed=42, rollout_graph=False if args.no_graph else None, rollout_shared_prefix=not args.no_shared_decode,
+                     share_policy_prompt=(not getattr(args, "no_shared_policy", False)) if share_policy is None else share_policy)
     # the reference's reward hop runs inside the timed step: ids -> host -> decode -> the five python reward functions
     # reason.py:291-296 enables by default -> device (a synthetic id -> text table stands in for the tokenizer files)
     reward_names = ["xmlcount", "soft_format", "strict_format", "less_than_4", "correctness"]
@@ -443,6 +449,8 @@ def main():
     ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="issue the rollout's decode steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-shared-decode", action="store_true", help="per-copy prompt K/V in the decode attention")
+    ap.add_argument("--no-shared-policy", action="store_true",
+                    help="policy forward / backward over every row's full prompt (independent LoRA-dropout masks per copy, as the reference draws them)")
     ap.add_argument("--completion-len", type=int, default=None)
     ap.add_argument("--lora-dropout", type=float, default=LORA_DROPOUT, help="PEFT lora_dropout of the policy pass (reference: 0.05)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the oracle timing leg and print its JSON")
@@ -528,6 +536,18 @@ def main():
                                   "workload": "the headline GRPO step with every rollout's EOS drawn at U[%d, %d] (SURVEY §8d straggler "
                                               "run; mean completion %.0f tokens; the step waits for its longest row)" % (lo_hi + (mean_len,))}
         del s_runner, s_step
+        if not args.no_shared_policy:
+            # transparency leg: the same step with the policy pass over every row's FULL prompt (what the reference executes;
+            # independent LoRA-dropout masks per copy) — the headline shares the prompt rows of a group in that pass
+            u_runner, u_step, u_B = make_grpo_leg(model, dims, R, Cn, rank, dev, args, None, S + 3, share_policy=False)
+            u_el, _ = timed_steps(u_step, S, 2, 1, dev)
+            u_ex = executed_flops(R, dims.P, Cn, "grpo", shared_policy=False)
+            secondary["unshared_policy"] = {"value": u_B * S / u_el, "unit": "samples/s", "ms_per_step": 1000.0 * u_el / S, "steps": S, "warmup": 2,
+                                            "step_tflops_executed": u_ex / 1e12 / (u_el / S),
+                                            "workload": "the headline GRPO step with the policy forward / backward over every row's full "
+                                                        "prompt (B x (P + C) rows, an independent LoRA-dropout mask per copy, as the reference "
+                                                        "draws them) instead of the shared-prompt pass"}
+            del u_runner, u_step
         f_runner, f_step, f_B = make_sft_leg(model, dims, R, rank, dev)
         f_el, _ = timed_steps(f_step, S, 2, 1, dev)
         f_ex = executed_flops(R, dims.P, 0, "sft")
@@ -542,7 +562,7 @@ def main():
         samples = world * samples_per_step * args.steps
         value = samples / elapsed
         traffic, traffic_note = pmc_traffic() if (headline_default and not dims.dry) else (None, "PMC passes exist for the headline configuration only")
-        ex = executed_flops(R, dims.P, Cn, args.mode)
+        ex = executed_flops(R, dims.P, Cn, args.mode, shared_policy=not args.no_shared_policy)
         tail = "; random-init weights" + ("; DRY RUN: toy dimensions on the CPU kernel emulator, numbers are meaningless" if dims.dry else "")
         if args.mode == "sft":
             metric = "SFT samples/sec (NT-500M+Qwen3-1.7B, DNA 2x1024, seq 2180, batch 8)"
@@ -551,11 +571,13 @@ def main():
                         "AdamW" % (args.lora_dropout, samples_per_step, dims.P, dims.label_tail)) + tail
         else:
             metric = "GRPO samples/sec (NT-500M+Qwen3-1.7B, DNA 2x1024, prompt 2180, gen 256)"
+            pol = (" (prompt rows of a group run once: shared K/V, gradients summed over the copies; one LoRA-dropout mask stream for "
+                   "the shared rows)") if not args.no_shared_policy else " (every row's full prompt)"
             workload = ("GRPO step cfg-3: NT-v2-500M encoder + Qwen3-1.7B (LoRA r=32 dropout %g all linears + dna_projection), "
                         "%d prompt x G=%d per GPU, P=%d, C=%d sampled tokens (T=0.6, top-k 20, top-p 0.95)%s, "
-                        "ref logps + policy fwd/bwd + AdamW"
+                        "ref logps + policy fwd/bwd%s + AdamW"
                         % (args.lora_dropout, R, dims.g, dims.P, Cn,
-                           (", EOS drawn at U[%d, %d] (straggler run)" % tuple(args.eos_uniform)) if args.eos_uniform else "")) + tail
+                           (", EOS drawn at U[%d, %d] (straggler run)" % tuple(args.eos_uniform)) if args.eos_uniform else "", pol)) + tail
         line = {
             "metric": metric,
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -386,6 +386,42 @@ extern "C" int bra_embed_scatter_bwd(const int* tok_src, const void* dout, long 
     return BRA_LAUNCH_STATUS();
 }
 
+// out[r, i] = (add ? add[r, i] : 0) + sum_c src[(r * copies + c) * member_stride + i],  i < n (multiple of 8), fp32 accumulation,
+// one rounding — the gradient that the `copies` sequences of a group send to the rows they SHARE (the prompt K / V of GRPO's G
+// rollouts, grpo_trainer.py:107-116: the shared prompt is run once, the upstream gradients of its rows are the sum over the copies)
+namespace bra {
+__global__ __launch_bounds__(256) void group_sum_kernel(const bf16_t* src, long member_stride, int copies, const bf16_t* add, long add_stride,
+                                                         bf16_t* out, long out_stride, int R, long n8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)R * n8) return;
+    const int r = (int)(i / n8);
+    const long c8 = i - (long)r * n8;
+    float acc[8];
+    if (add) unpack8(ld16(add + (long)r * add_stride + c8 * 8), acc);
+    else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    }
+    for (int c = 0; c < copies; ++c) {
+        float f[8];
+        unpack8(ld16(src + ((long)r * copies + c) * member_stride + c8 * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+    st16(out + (long)r * out_stride + c8 * 8, pack8(acc));
+}
+}  // namespace bra
+
+extern "C" int bra_group_sum(const void* src, long member_stride, int copies, const void* add, long add_stride, void* out,
+                             long out_stride, int R, long n, void* stream) {
+    if (R == 0 || n == 0) return 0;
+    if (!src || !out || copies <= 0 || n % 8 || member_stride % 8 || out_stride % 8 || (add && add_stride % 8)) return BRA_ERR_ARG;
+    const long items = (long)R * (n / 8);
+    BRA_LAUNCH(bra::group_sum_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, (const bra::bf16_t*)src, member_stride,
+               copies, (const bra::bf16_t*)add, add_stride, (bra::bf16_t*)out, out_stride, R, n / 8);
+    return BRA_LAUNCH_STATUS();
+}
+
 extern "C" int bra_gather_rows(const int* rows, const void* x, long ldx, void* out, long ldo, int n, int H,
                                void* stream) {
     if (n == 0) return 0;

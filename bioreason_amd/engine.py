@@ -240,7 +240,11 @@ class QwenEngine:
         saved = (x, xn, t1, qkv, q, k, v, o, lse, t2, h, hn, t3, gu, act, t4) if save else None
         return y, saved
 
-    def layer_bwd(self, li: int, dy: torch.Tensor, saved, m: SeqMeta):
+    def layer_bwd(self, li: int, dy: torch.Tensor, saved, m: SeqMeta, prefix: int = 0, extra_dkv=None):
+        """prefix > 0: the layer's queries attended to `prefix` key rows that belong to ANOTHER segment (a shared prompt) in front
+        of their own; their dK / dV rows are returned as the second value instead of entering this segment's projection backward.
+        extra_dkv = (dk_views, dv_views, copies): gradients other segments sent to THIS segment's K / V rows ([R * copies, S, Hkv, hd]
+        views), summed over the copies of each row group and added to its own."""
         L = self.layers[li]
         (x, xn, t1, qkv, q, k, v, o, lse, t2, h, hn, t3, gu, act, t4) = saved
         B, S, T = m.B, m.S, m.B * m.S
@@ -252,9 +256,17 @@ class QwenEngine:
         dh = ops.rmsnorm_bwd(dhn, h, L.ln2, self.eps, dres=dy)             # + residual branch
         do = self._lora_bwd(dh, L.WoT, L.lora["o"], on, o.view(T, self.Nq), t2, drop=self._drop(m, li, "o"))
         dq, dk, dv = ops.attn_bwd(q, k, v, o, do.view(B, S, self.Hq, self.hd), lse, m.kmask, True, self.scale)
+        pre = None
+        if prefix > 0:
+            pre = (dk[:, :prefix], dv[:, :prefix])
+            dk, dv = dk[:, prefix:], dv[:, prefix:]
+        if extra_dkv is not None:
+            dk = ops.group_sum(extra_dkv[0], extra_dkv[2], add=dk)
+            dv = ops.group_sum(extra_dkv[1], extra_dkv[2], add=dv)
         dqkv = ops.qk_norm_rope_bwd(qkv, L.qn, L.kn, cosT, sinT, m.pos, S, self.Hq, self.Hkv, self.hd, self.eps, 1.0, dq, dk, dv)
         dxn = self._lora_bwd(dqkv, L.WqkvT, L.lora["qkv"], on, xn, t1, drop=self._drop(m, li, "qkv"))
-        return ops.rmsnorm_bwd(dxn, x, L.ln1, self.eps, dres=dh)
+        dx = ops.rmsnorm_bwd(dxn, x, L.ln1, self.eps, dres=dh)
+        return (dx, pre) if prefix > 0 else dx
 
     # ------------------------------------------------------------------ stack
     def forward_hidden(self, x: torch.Tensor, m: SeqMeta, save: bool):
@@ -275,6 +287,49 @@ class QwenEngine:
             if self.layer_done_hook is not None:
                 self.layer_done_hook(li)
         return dx
+
+
+    # ------------------------------------------------------------------ stack over a shared prompt + per-copy completions
+    def forward_hidden_shared(self, xp: torch.Tensor, mp: SeqMeta, xc: torch.Tensor, mc: SeqMeta, copies: int, save: bool):
+        """GRPO's G rollouts of a prompt (grpo_trainer.py:107-116) as TWO row segments: the R distinct prompts [R * P, H] run once,
+        the B = R * copies completions [B * C, H] attend to [their prompt's K / V | their own K / V].  Rows of a batched forward are
+        independent and causal attention never lets a prompt position see a completion, so every hidden state equals the one of
+        the full [B, P + C] pass.  Returns (final-normed hidden of the LAST prompt row of every prompt [R, H], of the completion
+        rows [B * C, H], tape)."""
+        R, P, B, C = mp.B, mp.S, mc.B, mc.S
+        assert B == R * copies
+        dev = xp.device
+        tape_p, tape_c = [], []
+        for li in range(self.L):
+            kc_r = torch.empty((R, self.Hkv, P, self.hd), dtype=BF16, device=dev)
+            vc_r = torch.empty((R, self.Hkv, P, self.hd), dtype=BF16, device=dev)
+            xp, sp = self.layer_fwd(li, xp, mp, save, kv_out=(kc_r, vc_r, 0))
+            # every copy gets its prompt's K / V rows in front of its own (one broadcast copy per tensor)
+            kc = torch.empty((B, self.Hkv, P + C, self.hd), dtype=BF16, device=dev)
+            vc = torch.empty((B, self.Hkv, P + C, self.hd), dtype=BF16, device=dev)
+            kc.view(R, copies, self.Hkv, P + C, self.hd)[:, :, :, :P].copy_(kc_r[:, None])
+            vc.view(R, copies, self.Hkv, P + C, self.hd)[:, :, :, :P].copy_(vc_r[:, None])
+            xc, sc = self.layer_fwd(li, xc, mc, save, kv_out=(kc, vc, P))
+            tape_p.append(sp)
+            tape_c.append(sc)
+        last = torch.arange(R, device=dev, dtype=torch.int32) * P + (P - 1)
+        xp_last = ops.gather_rows(last, xp)
+        hid_last = ops.rmsnorm_fwd(xp_last, self.norm_w, self.eps)
+        hid_c = ops.rmsnorm_fwd(xc, self.norm_w, self.eps)
+        return hid_last, hid_c, ((tape_p, tape_c, xp_last, xc, last) if save else None)
+
+    def backward_hidden_shared(self, dhid_last: torch.Tensor, dhid_c: torch.Tensor, tape, mp: SeqMeta, mc: SeqMeta, copies: int):
+        tape_p, tape_c, xp_last, xc, last = tape
+        dxc = ops.rmsnorm_bwd(dhid_c, xc, self.norm_w, self.eps)
+        dxp = ops.scatter_rows(last, ops.rmsnorm_bwd(dhid_last, xp_last, self.norm_w, self.eps), mp.B * mp.S)
+        for li in reversed(range(self.L)):
+            dxc, pre = self.layer_bwd(li, dxc, tape_c[li], mc, prefix=mp.S)
+            tape_c[li] = None
+            dxp = self.layer_bwd(li, dxp, tape_p[li], mp, extra_dkv=(pre[0], pre[1], copies))
+            tape_p[li] = None
+            if self.layer_done_hook is not None:
+                self.layer_done_hook(li)
+        return dxp, dxc
 
 
 # =============================================================================================== NT-v2 / ESM encoder

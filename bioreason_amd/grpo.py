@@ -80,6 +80,39 @@ def repeat_sampler_indices(num_samples: int, mini_repeat_count: int, batch_size:
     return list(RepeatRandomSampler(range(num_samples), mini_repeat_count, batch_size, repeat_count, seed))
 
 
+def per_token_logps_shared_policy(model, prompt_ids: torch.Tensor, prompt_mask: torch.Tensor, completion_ids: torch.Tensor,
+                                  completion_mask_: torch.Tensor, prompt_alias: Sequence[int], **multimodal) -> Optional[torch.Tensor]:
+    """`per_token_logps` WITH gradients (the policy pass of compute_loss, grpo_trainer.py:777-779) when the rows are groups of
+    consecutive copies of a prompt (RepeatRandomSampler, :107-116): the prompt rows run once per distinct prompt — forward and
+    backward — and the completion rows attend to [their prompt's K / V | their own].  Same log-probs as the full-sequence pass
+    (rows of a batched forward are independent; a prompt position never sees a completion); the gradients that the copies send
+    into the prompt rows are summed where they enter them (the prompt's K / V rows and its last hidden state), which is what
+    the chain rule gives for the sum of the copies' losses.  ~4.6x fewer rows than B x (P + C) at cfg-3.
+    Deviation (stated in DESIGN.md): under LoRA dropout the shared prompt rows carry ONE mask stream for all copies of a prompt,
+    the reference draws an independent mask per copy — the same marginal distribution per copy, correlated across the copies.
+    Returns None when the aliases are not uniform consecutive groups (the caller then runs `per_token_logps`)."""
+    from .generation import _uniform_groups
+    grp = _uniform_groups(list(prompt_alias))
+    if grp is None or grp[1] < 2:
+        return None
+    R, copies = grp
+    tm = model.text_model
+    B, P = prompt_ids.shape
+    C = completion_ids.shape[1]
+    dev = prompt_ids.device
+    sel = torch.arange(R, device=dev) * copies
+    embeds = model._inputs_embeds(prompt_ids, multimodal.get("dna_tokenized"), multimodal.get("batch_idx_map"),
+                                  multimodal.get("dna_alias"), multimodal.get("dna_enc"))
+    hid_last, hid_c = tm.hidden_states_shared(embeds.index_select(0, sel), prompt_mask.index_select(0, sel), completion_ids,
+                                              completion_mask_, copies)
+    from .modeling import _ExpandGroupsFn, _LogProbFn
+    H = hid_c.shape[-1]
+    first = _ExpandGroupsFn.apply(hid_last, copies)                                          # [B, H]: predicts completion token 0
+    hsel = torch.cat([first[:, None, :], hid_c.view(B, C, H)[:, : C - 1, :]], dim=1).reshape(B * C, H).contiguous()
+    tgt = completion_ids.to(torch.int32).reshape(-1).contiguous()
+    return _LogProbFn.apply(hsel, tm, tgt).view(B, C)
+
+
 @torch.no_grad()
 def per_token_logps_shared_prefix(model, prompt_ids: torch.Tensor, prompt_mask: torch.Tensor, completion_ids: torch.Tensor,
                                   completion_mask_: torch.Tensor, prompt_alias: Sequence[int], **multimodal) -> torch.Tensor:

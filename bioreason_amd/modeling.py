@@ -134,6 +134,39 @@ class _StackFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class _SharedStackFn(torch.autograd.Function):
+    """The decoder stack over (distinct prompts, per-copy completions) as one autograd node (engine.forward_hidden_shared)."""
+
+    @staticmethod
+    def forward(ctx, xp, xc, anchor, model, mp, mc, copies):
+        eng = model.engine
+        need = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[2])
+        hid_last, hid_c, tape = eng.forward_hidden_shared(xp, mp, xc, mc, copies, save=need)
+        ctx.model, ctx.mp, ctx.mc, ctx.copies, ctx.tape = model, mp, mc, copies, tape
+        return hid_last, hid_c
+
+    @staticmethod
+    def backward(ctx, dlast, dc):
+        eng = ctx.model.engine
+        eng.ensure_transposed()
+        dxp, dxc = eng.backward_hidden_shared(dlast.contiguous(), dc.contiguous(), ctx.tape, ctx.mp, ctx.mc, ctx.copies)
+        ctx.tape = None
+        return dxp, None, None, None, None, None, None
+
+
+class _ExpandGroupsFn(torch.autograd.Function):
+    """row r -> `copies` consecutive copies of it; backward = sum over the copies of each group (bra_group_sum)"""
+
+    @staticmethod
+    def forward(ctx, x, copies):
+        ctx.copies = copies
+        return x.repeat_interleave(copies, dim=0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.group_sum(dy.contiguous(), ctx.copies), None
+
+
 class _LogProbFn(torch.autograd.Function):
     """log p(target | hidden row) through the tied lm_head, fused (no [rows, V] logits in HBM on the forward)."""
 
@@ -410,6 +443,41 @@ class Qwen3ForCausalLM(nn.Module):
             x = x.to(BF16)
         anchor = self.arena.anchor if self.arena is not None else x.new_zeros(1, dtype=torch.float32)
         return _StackFn.apply(x.contiguous(), anchor, self, meta)
+
+    def hidden_states_shared(self, prompt_embeds: torch.Tensor, prompt_mask: torch.Tensor, completion_ids: torch.Tensor,
+                             completion_mask: torch.Tensor, copies: int):
+        """The hidden states a [B, P + C] pass would produce at the positions GRPO keeps (grpo_trainer.py:510-520 + :779: the last
+        prompt position and the completion positions), for B = R * copies rows made of R distinct prompts whose `copies` rollouts
+        are consecutive: prompt_embeds [R, P, H] (differentiable), prompt_mask [R, P], completion_ids / completion_mask [B, C].
+        -> (hidden of the last prompt row [R, H], hidden of the completion rows [B * C, H]), both final-normed, differentiable.
+        LoRA dropout (training mode): one mask stream for the shared prompt rows, one for the completion rows."""
+        eng = self.ensure_packed()
+        if self.arena is not None:
+            self.arena.pack_if_stale()
+        R, P, H = prompt_embeds.shape
+        B, C = completion_ids.shape
+        assert B == R * copies
+        dev = prompt_embeds.device
+        S = P + C
+        kfull = torch.cat([prompt_mask.to(torch.uint8).repeat_interleave(copies, dim=0), completion_mask.to(torch.uint8)], dim=1).contiguous()
+        mp = SeqMeta(B=R, S=P, pos=torch.arange(P, dtype=torch.int32, device=dev).repeat(R), kmask=prompt_mask.to(torch.uint8).contiguous(),
+                     lora_on=self._lora_enabled, max_pos=S)
+        mc = SeqMeta(B=B, S=C, pos=(torch.arange(C, dtype=torch.int32, device=dev) + P).repeat(B), kmask=kfull,
+                     lora_on=self._lora_enabled, max_pos=S)
+        p_drop = getattr(self, "lora_dropout_p", 0.0)
+        if p_drop > 0.0 and self.training and self._lora_enabled:
+            self._dropout_calls = getattr(self, "_dropout_calls", 0) + 1
+            seed = (getattr(self, "_dropout_seed", 0x5EED) * 0x9E3779B1 + self._dropout_calls * 0x85EBCA6B) & 0xFFFFFFFF
+            mp.drop_p = mc.drop_p = p_drop
+            mp.drop_seed = seed
+            mc.drop_seed = (seed * 0x2C1B3C6D + 0x5BD1E995) & 0xFFFFFFFF      # the two segments must not share mask streams
+        xp = prompt_embeds.reshape(R * P, H)
+        if xp.dtype != BF16:
+            xp = xp.to(BF16)
+        xc = torch.empty((B * C, H), dtype=BF16, device=dev)
+        ops.embed_scatter_fwd(completion_ids.to(torch.int32).reshape(-1).contiguous(), None, eng.E, None, xc)
+        anchor = self.arena.anchor if self.arena is not None else xp.new_zeros(1, dtype=torch.float32)
+        return _SharedStackFn.apply(xp.contiguous(), xc, anchor, self, mp, mc, copies)
 
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, labels=None, position_ids=None,
                 return_logits: bool = True, **unused):

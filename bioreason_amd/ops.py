@@ -361,6 +361,22 @@ def scatter_rows(rows32, x, nrows_out):
     return out
 
 
+def group_sum(src: torch.Tensor, copies: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """src [R * copies, ...] (bf16; everything behind dim 0 contiguous, dim 0 may be strided) -> [R, ...]: sum over the members of
+    each group (+ add [R, ...]), fp32 accumulation.  The upstream gradient of rows shared by the copies of a GRPO group."""
+    n = 1
+    for d in src.shape[1:]:
+        n *= d
+    assert src.dtype == BF16 and src[0].is_contiguous() and src.shape[0] % copies == 0
+    R = src.shape[0] // copies
+    out = torch.empty((R,) + tuple(src.shape[1:]), dtype=BF16, device=src.device)
+    if add is not None:
+        assert add.shape == out.shape and add.dtype == BF16 and add[0].is_contiguous()
+    get_lib().call("bra_group_sum", src, src.stride(0), copies, add, add.stride(0) if add is not None else 0, out, out.stride(0),
+                   R, n, current_stream(src))
+    return out
+
+
 def transpose2d(x: torch.Tensor, pad_to: int = 8) -> torch.Tensor:
     """x [R, C] -> [C, Rp] view [:, :R] with row pitch Rp = R rounded up to `pad_to` (zero padded)"""
     R, C = x.shape

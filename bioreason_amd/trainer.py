@@ -61,6 +61,9 @@ class GRPOConfig:
     rollout_shared_prefix: bool = True
     grad_buckets: int = 4
     share_dna_encoding: bool = True      # frozen-encoder rows computed once per step and shared by its three passes
+    # the policy pass (forward AND backward) runs the prompt of a group of consecutive copies once (grpo.per_token_logps_shared_policy);
+    # under LoRA dropout the shared prompt rows then carry one mask stream for all copies of a prompt (deviations)
+    share_policy_prompt: bool = True
 
 
 def token_stat_rewards(completion_ids: torch.Tensor, completion_mask: torch.Tensor) -> torch.Tensor:
@@ -253,13 +256,19 @@ class GRPOStepRunner(_DataParallelStep):
         mark("rewards")
         return {"prompt_ids": prompt_ids, "prompt_mask": prompt_mask, "completion_ids": completion_ids, "completion_mask": cmask,
                 "old_per_token_logps": old_lp, "ref_per_token_logps": ref_lp, "advantages": adv, "multimodal_inputs": mm,
+                "prompt_alias": batch.get("prompt_alias"),
                 "rewards_per_func": all_rewards.mean(0), "roll_metrics": roll_metrics}
 
     # ---- compute_loss (:751-814) ----------------------------------------------------------------------------------
     def compute_loss(self, inputs: Dict):
         m, c = self.model, self.cfg
-        lp = grpo.per_token_logps(m, inputs["prompt_ids"], inputs["prompt_mask"], inputs["completion_ids"],
-                                  inputs["completion_mask"], **inputs["multimodal_inputs"])
+        lp = None
+        if c.share_policy_prompt and inputs.get("prompt_alias") is not None:
+            lp = grpo.per_token_logps_shared_policy(m, inputs["prompt_ids"], inputs["prompt_mask"], inputs["completion_ids"],
+                                                    inputs["completion_mask"], inputs["prompt_alias"], **inputs["multimodal_inputs"])
+        if lp is None:
+            lp = grpo.per_token_logps(m, inputs["prompt_ids"], inputs["prompt_mask"], inputs["completion_ids"],
+                                      inputs["completion_mask"], **inputs["multimodal_inputs"])
         eps_hi = c.epsilon_high if c.epsilon_high is not None else c.epsilon
         old = inputs["old_per_token_logps"] if c.num_iterations > 1 else None          # :786
         return grpo.grpo_loss(lp, old, inputs["ref_per_token_logps"], inputs["advantages"], inputs["completion_mask"],

@@ -338,6 +338,12 @@ int bra_group_advantage(const float* rewards, int N, int F, int G, float* adv, f
 int bra_grpo_loss(const float* logp, const float* old_logp, const float* ref_logp, const float* adv, const int* mask,
                   int B, int C, float eps_lo, float eps_hi, float beta, float* out3, float* dlogp, void* stream);
 
+/* out[r, 0..n) = (add ? add[r] : 0) + sum over the `copies` members c of group r of src[(r copies + c) member_stride + 0..n), bf16
+ * in / out, fp32 accumulation: the gradient the G rollouts of a GRPO group (grpo_trainer.py:107-116) send to the rows they share
+ * when the prompt is run once for the group (the shared prompt's K / V rows; the last prompt row's hidden state). */
+int bra_group_sum(const void* src, long member_stride, int copies, const void* add, long add_stride, void* out, long out_stride,
+                  int R, long n, void* stream);
+
 /* ---- persistent-grid building blocks (k_persist.hip, bra_gridsync.h) -------------------------------------------------
  * In-launch grid barrier + write-through hand-off used by the persistent decode step (the body of HF's `_sample` loop,
  * TF:generation/utils.py:2876-2925, kept inside one launch).  bra_gridsync_bytes: size of the synchronisation record the

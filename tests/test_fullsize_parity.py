@@ -277,6 +277,40 @@ def test_per_token_logps_fullsize(runs):
 
 
 @pytest.mark.gpu
+def test_shared_policy_pass_fullsize(runs):
+    """a9 / a11 on the path the GRPO step runs: the differentiable shared-prompt policy pass (2 prompts x 2 copies, P = 2180, one
+    left-padded prompt) — log-probs against the fp32 oracle like the full pass, and the gradient of EVERY trainable parameter
+    against the full-sequence pass on the same four rows (the sum over the copies through the shared prompt K / V rows)"""
+    from bioreason_amd import grpo
+    m, b, comp, dev = runs["m"], runs["b"], runs["comp"], runs["dev"]
+    db = _dev_batch(b, dev)
+    rows = [0, 0, 1, 1]
+    ids4, mask4 = db["input_ids"][rows], db["attention_mask"][rows]
+    dna4 = {k: torch.cat([v[0:2], v[0:2], v[2:4], v[2:4]], 0) for k, v in db["dna_tokenized"].items()}
+    mm4 = dict(dna_tokenized=dna4, batch_idx_map=[0, 0, 1, 1, 2, 2, 3, 3], dna_alias=[0, 1, 0, 1, 4, 5, 4, 5])
+    comp4 = comp.to(dev)[[0, 1, 1, 0]]
+    cm4 = torch.ones((4, C), dtype=torch.int32, device=dev)
+    w = torch.randn(4, C, generator=torch.Generator().manual_seed(9)).to(dev)
+    m.train()
+
+    def run(fn):
+        m.arena.zero_grad()
+        lp = fn()
+        (lp * w).sum().backward()
+        return lp.detach().clone(), m.arena.grads.clone()
+    lp_sh, g_sh = run(lambda: grpo.per_token_logps_shared_policy(m, ids4, mask4, comp4, cm4, [0, 0, 2, 2], **mm4))
+    lp_full, g_full = run(lambda: grpo.per_token_logps(m, ids4, mask4, comp4, cm4, **mm4))
+    m.eval()
+    _check("logps_shared_policy", torch.stack([lp_sh[0], lp_sh[2]]), runs, key="logps")
+    d = (lp_sh - lp_full).abs().max().item()
+    gr = ((g_sh - g_full).norm() / g_full.norm()).item()
+    noise = max(v.get("refbf16_vs_fp32", 0.0) for k, v in RATIOS.items() if k.startswith("grad_l")) if any(k.startswith("grad_l") for k in RATIOS) else 3e-2
+    RATIOS["shared_policy_vs_full"] = {"logps_maxabs": d, "grads_rel": gr, "grad_noise_refbf16": noise}
+    assert d <= 0.06, d
+    assert gr <= 1.5 * noise, (gr, noise)       # the two passes differ by where bf16 roundings of dK / dV fall: inside the gradients' own bf16 noise
+
+
+@pytest.mark.gpu
 def test_greedy_decode_fused_shared_prefix_fullsize(runs):
     """a8: prefill once per prompt + fused decode steps against one shared copy of the prompt K/V (the bench's rollout path),
     2 prompts x 2 copies, teacher-forced with the oracle's tokens: every choice equals the oracle's arg-max unless the
