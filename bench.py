@@ -97,6 +97,30 @@ def executed_flops(world_local_prompts: int, P: int, Cn: int, mode: str, shared_
     return enc + prefill + decode + ref + pol_f + pol_b
 
 
+DECODE_SOURCES = ("k_decgemm.hip", "bra_decgemm.h", "k_decattn.hip", "bra_decattn.h", "k_decode.hip", "k_grpo.hip", "bra_device.h")
+
+
+def decode_source_sha():
+    h = hashlib.sha256()
+    for f in DECODE_SOURCES:
+        with open(os.path.join(ROOT, "bioreason_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_decode_traffic():
+    """HBM-side bytes per token step of the token loop's kernels from the committed PMC summary, or None when it was collected from
+    different sources (same rule as pmc_traffic)"""
+    try:
+        with open(PMC_PROFILE) as fh:
+            d = json.load(fh)
+    except Exception:
+        return None
+    if d.get("decode_source_sha") != decode_source_sha() or "decode_traffic_bytes_per_token_step" not in d:
+        return None
+    return float(d["decode_traffic_bytes_per_token_step"])
+
+
 def kernel_source_sha():
     h = hashlib.sha256()
     for f in ("k_gemm.hip", "bra_device.h"):
@@ -585,7 +609,7 @@ def main():
             "dtype": "bf16", "data": "synthetic" if not dims.dry else "synthetic (dry run: toy dimensions, CPU kernel emulator, gloo)",
             "config": {"workload": workload, "global_batch": world * samples_per_step, "prompt_len": dims.P,
                        "completion_len": Cn if args.mode == "grpo" else 0, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": prof["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "roofline_mfma": {"bound": "mfma", "achieved": prof["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": prof["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "flops_per_launch": prof["flops_per_launch"], "algorithmic_bytes_per_launch": prof["bytes_per_launch"],
                          "kernel": "gemm_ring_kernel<...> (256x256 LDS-ring MFMA tiles; carries most of the family's time) + "
@@ -605,8 +629,20 @@ def main():
         }
         if dims.dry:
             line["dryrun"] = True
+        # `roofline` = the kernel family that is dominant BY TIME in the step: the rollout's token loop in a GRPO step (HBM-bound weight
+        # streaming: 60-70 % of the step), the MFMA GEMM family in an SFT step; the other family keeps its own key
+        line["roofline"] = line["roofline_mfma"]
         if args.mode == "grpo":
-            line["roofline_decode"] = decode_roofline(model, headline_rollout, Cn, R, dims.P)
+            dec = decode_roofline(model, headline_rollout, Cn, R, dims.P)
+            if dec is not None and headline_default and not dims.dry:
+                dec["traffic"] = pmc_decode_traffic()
+                dec["decode_source_sha"] = decode_source_sha()
+            line["roofline_decode"] = dec
+            step_ms = 1000.0 * elapsed / args.steps
+            gemm_ms = prof["avg_launch_ms"] * prof["launches"] / max(args.steps, 1)
+            if dec is not None and dec["share_of_step_ms"] > gemm_ms:
+                line["roofline"] = dict(dec, dominant_by_time="token loop %.0f ms of the %.0f ms step; MFMA GEMM family %.0f ms (roofline_mfma)"
+                                        % (dec["share_of_step_ms"], step_ms, gemm_ms))
             line["rollout_phases_ms"] = {k: round(v, 2) for k, v in headline_rollout.items() if isinstance(v, float)}
             line["rollout_issue"] = {"mode": "graph" if getattr(model.text_model.engine, "_rollout_use_graph", False) else "eager",
                                      "probe_host_vs_device_ms_per_token": getattr(model.text_model.engine, "_rollout_probe_ms", None)}

@@ -56,8 +56,10 @@ def test_single_process_line_carries_the_secondary_legs(emu_lib_path):
     assert d["n_gpus"] == 1 and "cpu_baseline" not in d                  # the CPU leg is skipped in a dry run
     for leg in ("sft", "straggler"):
         assert d[leg]["value"] > 0 and d[leg]["steps"] == 1 and d[leg]["unit"] == "samples/s", leg
-    assert d["roofline_decode"]["bound"] == "hbm" and d["roofline"]["bound"] == "mfma"
-    assert "gemm_ring_kernel" in d["roofline"]["kernel"]
+    assert d["roofline_decode"]["bound"] == "hbm" and d["roofline_mfma"]["bound"] == "mfma"
+    assert "gemm_ring_kernel" in d["roofline_mfma"]["kernel"]
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and "frac" in d["roofline"]       # = whichever family is dominant by time
+    assert d["unshared_policy"]["value"] > 0
 
 
 def test_world_size_mismatch_is_refused():

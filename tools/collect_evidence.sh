@@ -50,13 +50,29 @@ if tot_n:
     res["traffic_bytes_per_dispatch"] = tot_b / tot_n
     try:
         bl = json.load(open(os.path.join(out, f"{tag}_bench.json")))
-        calls_per_step = bl["roofline"]["launches"] / bl["steps"]
+        calls_per_step = bl["roofline_mfma"]["launches"] / bl["steps"]
         res["api_calls_per_step"] = calls_per_step
         res["traffic_bytes_per_call"] = tot_b / (3.0 * calls_per_step)
-        res["algorithmic_bytes_per_call"] = bl["roofline"]["algorithmic_bytes_per_launch"]
+        res["algorithmic_bytes_per_call"] = bl["roofline_mfma"]["algorithmic_bytes_per_launch"]
         res["traffic_over_algorithmic"] = res["traffic_bytes_per_call"] / max(res["algorithmic_bytes_per_call"], 1.0)
     except Exception as e:
         res["traffic_bytes_per_call_error"] = repr(e)
+# the token loop (dominant by time): HBM-side bytes per token step over its kernels (255 token steps per GRPO step, 3 steps traced)
+dh = hashlib.sha256()
+for f in ("k_decgemm.hip", "bra_decgemm.h", "k_decattn.hip", "bra_decattn.h", "k_decode.hip", "k_grpo.hip", "bra_device.h"):
+    dh.update(open(os.path.join(R, "bioreason_amd", "csrc", f), "rb").read())
+res["decode_source_sha"] = dh.hexdigest()[:16]
+dec_b, dec_k = 0.0, {}
+for key in ("dec_gemm2_kernel", "dec_attn_items_kernel", "dec_attn_merge_kernel", "topk_slices_kernel", "sample_merge_kernel", "advance_counters_kernel"):
+    fb = sum(float(r["Total"]) for r in rows("FETCH_SIZE") if r["Counter_Name"] == "FETCH_SIZE" and key in r["Kernel_Name"])
+    wb = sum(float(r["Total"]) for r in rows("WRITE_SIZE") if r["Counter_Name"] == "WRITE_SIZE" and key in r["Kernel_Name"])
+    b = (2.0 * fb + wb) * 1024.0
+    dec_k[key] = b
+    dec_b += b
+if dec_b > 0:
+    res["decode_traffic_bytes_3_steps"] = dec_b
+    res["decode_traffic_by_kernel_3_steps"] = dec_k
+    res["decode_traffic_bytes_per_token_step"] = dec_b / (3.0 * 255.0)
 sq = rows("SQ_BUSY_CYCLES")
 for key in ("gemm_ring_kernel<0", "gemm_glds_kernel<0", "attn_fwd_kernel<128", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel<128, 2", "dec_gemm2_kernel<0, 2, 1", "dec_attn_items_kernel", "dec_attn_merge_kernel"):
     busy, mfma = pick(sq, "SQ_BUSY_CYCLES", key), pick(sq, "SQ_VALU_MFMA_BUSY_CYCLES", key)
