@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def _worker(rank, world, port, emu_path, q):
+def _worker(rank, world, port, emu_path, q, grouped=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -29,6 +29,17 @@ def _worker(rank, world, port, emu_path, q):
     m = build(fix, torch.device("cpu"), True)
     b = to_dev(fix["batch"], torch.device("cpu"))
     b.pop("labels")
+    if grouped:
+        # RepeatRandomSampler's layout: consecutive copies of a prompt -> the shared-prompt rollout, reference pass and (differentiable)
+        # policy pass; rank r trains on 2 copies of prompt r of the fixture
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_shared_policy import _group_batch
+        ids, mask, mm, alias = _group_batch(fix, torch.device("cpu"), 2)
+        rows = [2 * rank, 2 * rank + 1]
+        dsel = [i for i, s_ in enumerate(mm["batch_idx_map"]) if s_ in rows]
+        b = {"input_ids": ids[rows], "attention_mask": mask[rows],
+             "dna_tokenized": {k: v[dsel] for k, v in mm["dna_tokenized"].items()},
+             "batch_idx_map": [mm["batch_idx_map"][i] - rows[0] for i in dsel], "prompt_alias": [0, 0]}
     seen = {}
 
     def reward(ids, mask):
@@ -36,15 +47,19 @@ def _worker(rank, world, port, emu_path, q):
         seen["local"] = r.clone()
         return r
 
-    G = 2 * world          # one group spans both ranks: 2 local rows per rank, G = 4 (exercises the cross-rank gather)
+    G = 2 if grouped else 2 * world          # (ungrouped) one group spans both ranks: 2 local rows per rank, G = 4 (exercises the cross-rank gather)
     runner = GRPOStepRunner(m, GRPOConfig(num_generations=G, max_completion_length=4, eos_token_id=None, seed=7, learning_rate=1e-3), reward)
     p0 = m.arena.params.clone()
     out = runner.step(b)
     gathered = [torch.empty_like(seen["local"]) for _ in range(world)]
     dist.all_gather(gathered, seen["local"])
     allr = torch.cat(gathered, 0).sum(1)
-    mean, std = allr.mean(), allr.std()
-    want_adv = ((allr - mean) / (std + 1e-4))[rank * 2:(rank + 1) * 2]
+    if grouped:
+        grp = allr.view(-1, 2)
+        want_adv = ((allr - grp.mean(1).repeat_interleave(2)) / (grp.std(1).repeat_interleave(2) + 1e-4))[rank * 2:(rank + 1) * 2]
+    else:
+        mean, std = allr.mean(), allr.std()
+        want_adv = ((allr - mean) / (std + 1e-4))[rank * 2:(rank + 1) * 2]
     params = [torch.empty_like(m.arena.params) for _ in range(world)]
     dist.all_gather(params, m.arena.params)
     grads = [torch.empty_like(m.arena.grads) for _ in range(world)]
@@ -86,6 +101,26 @@ def test_grpo_step_two_ranks(emu_lib_path):
         assert abs(mets[0] - 4.0) < 1e-6 and abs(mets[1] - want_reward) < 1e-5
         assert abs(mets[3] - want_loss) < 1e-5 * max(1.0, abs(want_loss))
         assert ncuts >= 1, "the gradient reduction was not cut into overlapped buckets"
+
+
+def test_grpo_step_two_ranks_shared_prompt_groups(emu_lib_path):
+    """the same step on the layout the bench and the trainer produce: every rank holds consecutive copies of its prompt, so the
+    rollout, the reference pass and the differentiable policy pass all run the prompt once per group — replicas identical after
+    the bucketed gradient mean, advantages = statistics of the gathered rewards per group"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib_path, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same_p, same_g, moved, loss, want_adv, got_adv, same_m, mets, want_loss, want_reward, ncuts in res:
+        assert same_p and same_g and same_m and moved > 0 and loss == loss
+        assert torch.allclose(torch.tensor(got_adv), torch.tensor(want_adv), atol=1e-5), (rank, got_adv, want_adv)
+        assert abs(mets[3] - want_loss) < 1e-5 * max(1.0, abs(want_loss)) and ncuts >= 1
 
 
 def _sft_worker(rank, world, port, emu_path, q):
