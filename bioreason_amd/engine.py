@@ -172,6 +172,18 @@ class QwenEngine:
         if self.ET is None:
             self.ET = ops.transpose2d(self.E)
 
+    # below this many rows a [rows, K] x [r_pad, K]^T product goes to the row-block kernel of k_lora.hip (32 rows per workgroup, p = 0)
+    # instead of the tiled GEMM: a 128-row tile grid over N = 64 / 128 columns is 16 workgroups at 2048 rows (measured: 182 us vs ~28 us
+    # for dy [2048, 12288] x B^T); at 19 488 rows the tiled GEMM fills the chip
+    SMALL_M = 8192
+
+    @staticmethod
+    def _down(x2d, A, scaling, n_targets):
+        """s x A^T -> [rows, r_pad] (A = the adapter image [r_pad, K], one 32-row block per target)"""
+        if x2d.shape[0] < QwenEngine.SMALL_M and A.shape[0] in (32, 64, 128):
+            return ops.lora_down_drop(x2d, A, scaling, 0.0, [0] * n_targets)
+        return ops.gemm_nt(x2d, A, alpha=scaling)
+
     @staticmethod
     def _lora_fwd(x2d, W, G: Optional[LoraGroup], on: bool, res=None, out=None, drop=None):
         """y = x W^T (+ (s dropout(x) A^T) B^T) (+res); returns (y, t).  drop = (p, seeds per target) in training mode"""
@@ -179,7 +191,7 @@ class QwenEngine:
             if drop is not None:
                 t = ops.lora_down_drop(x2d, G.A, G.scaling, drop[0], drop[1])
             else:
-                t = ops.gemm_nt(x2d, G.A, alpha=G.scaling)
+                t = QwenEngine._down(x2d, G.A, G.scaling, len(G.n_sizes))
             return ops.gemm_nt(x2d, W, a2=t, b2=G.B, res=res, out=out), t
         return ops.gemm_nt(x2d, W, res=res, out=out), None
 
@@ -187,7 +199,7 @@ class QwenEngine:
     def _lora_bwd(dy, WT, G: Optional[LoraGroup], on: bool, x2d, t, drop=None):
         """dx = dy W (+ dropout'(s (dy B) A)); accumulates dA, dB into the arena."""
         if G is not None and on:
-            dts = ops.gemm_nt(dy, G.BT, alpha=G.scaling)                 # [T, r_pad] = s * dy B
+            dts = QwenEngine._down(dy, G.BT, G.scaling, len(G.n_sizes))   # [T, r_pad] = s * dy B
             if drop is not None:
                 dxl = ops.lora_up_drop(dts, G.AT, drop[0], drop[1])      # the branch's input gradient, masked per target
                 dx = ops.gemm_nt(dy, WT, res=dxl)

@@ -75,7 +75,7 @@ def gemm_nt(
         e1.record()
         # flops and algorithmic bytes (every operand once: A, B, LoRA pair, residual, output)
         nbytes = 2.0 * (M * K + N * K + (M + N) * K2 + (M * N if res is not None else 0)) + M * N * (4.0 if out_f32 else 2.0)
-        prof.records.append((2.0 * M * N * (K + K2), e0, e1, nbytes))
+        prof.records.append((2.0 * M * N * (K + K2), e0, e1, nbytes, (M, N, K, K2, res is not None)))
     return out
 
 
@@ -109,6 +109,18 @@ class GemmProfile:
         by = sum(r[3] for r in self.records)
         return {"launches": n, "flops": fl, "ms": ms, "avg_launch_ms": ms / max(n, 1), "tflops": fl / max(ms, 1e-9) / 1e9,
                 "flops_per_launch": fl / max(n, 1), "bytes_per_launch": by / max(n, 1)}
+
+
+def gemm_profile_by_shape(prof: "GemmProfile"):
+    """(tools) per (M, N, K, K2, residual): launches, total ms, TFLOP/s — which shapes carry the GEMM time of a step"""
+    torch.cuda.synchronize()
+    agg = {}
+    for r in prof.records:
+        a = agg.setdefault(r[4], [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += r[1].elapsed_time(r[2])
+        a[2] += r[0]
+    return sorted(((k, n, ms, fl / max(ms, 1e-9) / 1e9) for k, (n, ms, fl) in agg.items()), key=lambda t: -t[2])
 
 
 GEMM_PROFILE: Optional[GemmProfile] = None
