@@ -64,6 +64,9 @@ class GRPOConfig:
     # the policy pass (forward AND backward) runs the prompt of a group of consecutive copies once (grpo.per_token_logps_shared_policy);
     # under LoRA dropout the shared prompt rows then carry one mask stream for all copies of a prompt (deviations)
     share_policy_prompt: bool = True
+    # the reference-policy pass (no grad, adapters off) on a second HIP stream, concurrent with the policy forward: at one prompt x 8
+    # rollouts both are chains of kernels that fill about half of the chip (grids of 128 - 144 workgroups on 256 CUs)
+    overlap_ref_pass: bool = True
 
 
 def token_stat_rewards(completion_ids: torch.Tensor, completion_mask: torch.Tensor) -> torch.Tensor:
@@ -199,6 +202,13 @@ class GRPOStepRunner(_DataParallelStep):
         self.lr_schedule: Optional[Callable[[int], float]] = None
         self.last_lr = cfg.learning_rate
 
+    def _side_stream(self, dev):
+        if dev.type != "cuda":
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
+
     # ---- _generate_and_score_completions (:535-749) ---------------------------------------------------------------
     def generate_and_score(self, batch: Dict, timing: bool = False, mark=lambda n: None) -> Dict:
         m, c = self.model, self.cfg
@@ -232,13 +242,23 @@ class GRPOStepRunner(_DataParallelStep):
                 old_lp = grpo.per_token_logps(m, prompt_ids, prompt_mask, completion_ids, cmask, **mm).detach()
         # reference policy = the same network with adapters disabled (:636-640)
         ref_lp = None
+        ref_join = None
         if c.beta != 0.0:
-            with torch.no_grad(), m.text_model.disable_adapter():
-                if batch.get("prompt_alias") is not None:
-                    ref_lp = grpo.per_token_logps_shared_prefix(m, prompt_ids, prompt_mask, completion_ids, cmask,
-                                                                batch["prompt_alias"], **mm)
-                else:
-                    ref_lp = grpo.per_token_logps(m, prompt_ids, prompt_mask, completion_ids, cmask, **mm)
+            def ref_pass():
+                with torch.no_grad(), m.text_model.disable_adapter():
+                    if batch.get("prompt_alias") is not None:
+                        return grpo.per_token_logps_shared_prefix(m, prompt_ids, prompt_mask, completion_ids, cmask,
+                                                                  batch["prompt_alias"], **mm)
+                    return grpo.per_token_logps(m, prompt_ids, prompt_mask, completion_ids, cmask, **mm)
+            side = self._side_stream(dev) if (c.overlap_ref_pass and not timing) else None
+            if side is not None:
+                # issued on the side stream behind everything issued so far; the caller joins (`ref_join`) before the loss reads it
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    ref_lp = ref_pass()
+                ref_join = side
+            else:
+                ref_lp = ref_pass()
         mark("ref_logps")
         # rewards (+ completion length) -> ONE all-gather -> group statistics -> local slice (:651-699, 703-716)
         rewards = self.reward_fn(completion_ids, cmask).float()
@@ -256,7 +276,7 @@ class GRPOStepRunner(_DataParallelStep):
         mark("rewards")
         return {"prompt_ids": prompt_ids, "prompt_mask": prompt_mask, "completion_ids": completion_ids, "completion_mask": cmask,
                 "old_per_token_logps": old_lp, "ref_per_token_logps": ref_lp, "advantages": adv, "multimodal_inputs": mm,
-                "prompt_alias": batch.get("prompt_alias"),
+                "prompt_alias": batch.get("prompt_alias"), "ref_join": ref_join,
                 "rewards_per_func": all_rewards.mean(0), "roll_metrics": roll_metrics}
 
     # ---- compute_loss (:751-814) ----------------------------------------------------------------------------------
@@ -271,6 +291,9 @@ class GRPOStepRunner(_DataParallelStep):
                                       inputs["completion_mask"], **inputs["multimodal_inputs"])
         eps_hi = c.epsilon_high if c.epsilon_high is not None else c.epsilon
         old = inputs["old_per_token_logps"] if c.num_iterations > 1 else None          # :786
+        if inputs.get("ref_join") is not None:                       # the reference pass ran beside the policy forward: join
+            torch.cuda.current_stream(lp.device).wait_stream(inputs["ref_join"])
+            inputs["ref_join"] = None
         return grpo.grpo_loss(lp, old, inputs["ref_per_token_logps"], inputs["advantages"], inputs["completion_mask"],
                               c.epsilon, eps_hi, c.beta)
 
