@@ -185,3 +185,33 @@ def test_shared_policy_pass_under_dropout_matches_oracle_with_injected_masks(bac
                          ("k1", l1.self_attn.k_proj, r1.self_attn.k_proj), ("o1", l1.self_attn.o_proj, r1.self_attn.o_proj)):
         assert rel(mod.lora_A["default"].weight.grad, ref.lora_A["default"].weight.grad) < 3 * tol, nm
         assert rel(mod.lora_B["default"].weight.grad, ref.lora_B["default"].weight.grad) < 3 * tol, nm
+
+
+@pytest.mark.gpu
+def test_ref_pass_on_side_stream_equals_main_stream(hip_device):
+    """GRPOConfig.overlap_ref_pass: the reference-policy pass issued on a second HIP stream (beside the policy forward) gives the
+    same bits as on the main stream, and the step that consumes it equals the step without the overlap (forward quantities are
+    deterministic: no atomics on that path)"""
+    from bioreason_amd.trainer import GRPOConfig, GRPOStepRunner
+    dev = hip_device
+    fix = torch.load(os.path.join(GOLD, "tiny_a.pt"), weights_only=False)
+    ids, mask, mm, alias = _group_batch(fix, dev, 2)
+    batch = {"input_ids": ids, "attention_mask": mask, "dna_tokenized": mm["dna_tokenized"], "batch_idx_map": mm["batch_idx_map"],
+             "prompt_alias": alias}
+    outs = []
+    for overlap in (True, False):
+        m = build(fix, dev, True)
+        runner = GRPOStepRunner(m, GRPOConfig(num_generations=2, max_completion_length=6, eos_token_id=None, seed=3, learning_rate=1e-3,
+                                              overlap_ref_pass=overlap))
+        inputs = runner.generate_and_score(batch)
+        if overlap:
+            assert inputs["ref_join"] is not None
+            torch.cuda.current_stream(dev).wait_stream(inputs["ref_join"])
+        else:
+            assert inputs["ref_join"] is None
+        torch.cuda.synchronize()
+        loss, stats = runner.compute_loss(dict(inputs, ref_join=None))
+        outs.append((inputs["completion_ids"].clone(), inputs["ref_per_token_logps"].clone(), loss.detach().clone(), stats.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]), (outs[0][1] - outs[1][1]).abs().max()
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
