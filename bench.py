@@ -387,7 +387,8 @@ def make_grpo_leg(model, dims: Dims, R: int, Cn: int, rank: int, dev, args, eos_
     cfg = GRPOConfig(num_generations=dims.g, max_completion_length=Cn, eos_token_id=eos_id, pad_token_id=dims.pad if eos_id else None,
                      seed=42, rollout_graph=False if args.no_graph else None, rollout_shared_prefix=not args.no_shared_decode,
                      share_policy_prompt=(not getattr(args, "no_shared_policy", False)) if share_policy is None else share_policy,
-                     overlap_ref_pass=not getattr(args, "no_overlap_ref", False))
+                     overlap_ref_pass=not getattr(args, "no_overlap_ref", False),
+                     overlap_policy_chains=not getattr(args, "no_overlap_chains", False))
     # the reference's reward hop runs inside the timed step: ids -> host -> decode -> the five python reward functions
     # reason.py:291-296 enables by default -> device (a synthetic id -> text table stands in for the tokenizer files)
     reward_names = ["xmlcount", "soft_format", "strict_format", "less_than_4", "correctness"]
@@ -474,6 +475,7 @@ def main():
     ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="issue the rollout's decode steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-shared-decode", action="store_true", help="per-copy prompt K/V in the decode attention")
+    ap.add_argument("--no-overlap-chains", action="store_true", help="prompt and completion chains of the shared policy pass on one stream")
     ap.add_argument("--no-overlap-ref", action="store_true", help="reference-policy pass on the main stream instead of beside the policy forward")
     ap.add_argument("--no-shared-policy", action="store_true",
                     help="policy forward / backward over every row's full prompt (independent LoRA-dropout masks per copy, as the reference draws them)")

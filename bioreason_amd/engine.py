@@ -124,6 +124,10 @@ def _mix32(a: int, b: int) -> int:
     return h
 
 
+import contextlib as _contextlib
+
+_nullctx = _contextlib.nullcontext
+
 LORA_GROUP_INDEX = {"qkv": 0, "o": 1, "gu": 2, "d": 3}
 
 
@@ -302,45 +306,81 @@ class QwenEngine:
 
 
     # ------------------------------------------------------------------ stack over a shared prompt + per-copy completions
-    def forward_hidden_shared(self, xp: torch.Tensor, mp: SeqMeta, xc: torch.Tensor, mc: SeqMeta, copies: int, save: bool):
+    def forward_hidden_shared(self, xp: torch.Tensor, mp: SeqMeta, xc: torch.Tensor, mc: SeqMeta, copies: int, save: bool, side=None):
         """GRPO's G rollouts of a prompt (grpo_trainer.py:107-116) as TWO row segments: the R distinct prompts [R * P, H] run once,
         the B = R * copies completions [B * C, H] attend to [their prompt's K / V | their own K / V].  Rows of a batched forward are
         independent and causal attention never lets a prompt position see a completion, so every hidden state equals the one of
         the full [B, P + C] pass.  Returns (final-normed hidden of the LAST prompt row of every prompt [R, H], of the completion
-        rows [B * C, H], tape)."""
+        rows [B * C, H], tape).
+        `side` (a second HIP stream): the completion chain is issued there, one event per layer behind the prompt chain's K / V —
+        at one prompt x 8 rollouts each chain alone fills about half of the chip (grids of 128 - 144 workgroups)."""
         R, P, B, C = mp.B, mp.S, mc.B, mc.S
         assert B == R * copies
         dev = xp.device
         tape_p, tape_c = [], []
+        main = torch.cuda.current_stream(dev) if side is not None else None
+        if side is not None:
+            side.wait_stream(main)
+            xc.record_stream(side)
         for li in range(self.L):
             kc_r = torch.empty((R, self.Hkv, P, self.hd), dtype=BF16, device=dev)
             vc_r = torch.empty((R, self.Hkv, P, self.hd), dtype=BF16, device=dev)
             xp, sp = self.layer_fwd(li, xp, mp, save, kv_out=(kc_r, vc_r, 0))
-            # every copy gets its prompt's K / V rows in front of its own (one broadcast copy per tensor)
-            kc = torch.empty((B, self.Hkv, P + C, self.hd), dtype=BF16, device=dev)
-            vc = torch.empty((B, self.Hkv, P + C, self.hd), dtype=BF16, device=dev)
-            kc.view(R, copies, self.Hkv, P + C, self.hd)[:, :, :, :P].copy_(kc_r[:, None])
-            vc.view(R, copies, self.Hkv, P + C, self.hd)[:, :, :, :P].copy_(vc_r[:, None])
-            xc, sc = self.layer_fwd(li, xc, mc, save, kv_out=(kc, vc, P))
             tape_p.append(sp)
-            tape_c.append(sc)
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)                              # (the whole prompt layer; its K / V rows are what the other chain needs)
+                kc_r.record_stream(side)
+                vc_r.record_stream(side)
+            with (torch.cuda.stream(side) if side is not None else _nullctx()):
+                if side is not None:
+                    side.wait_event(ev)
+                # every copy gets its prompt's K / V rows in front of its own (one broadcast copy per tensor)
+                kc = torch.empty((B, self.Hkv, P + C, self.hd), dtype=BF16, device=dev)
+                vc = torch.empty((B, self.Hkv, P + C, self.hd), dtype=BF16, device=dev)
+                kc.view(R, copies, self.Hkv, P + C, self.hd)[:, :, :, :P].copy_(kc_r[:, None])
+                vc.view(R, copies, self.Hkv, P + C, self.hd)[:, :, :, :P].copy_(vc_r[:, None])
+                xc, sc = self.layer_fwd(li, xc, mc, save, kv_out=(kc, vc, P))
+                tape_c.append(sc)
         last = torch.arange(R, device=dev, dtype=torch.int32) * P + (P - 1)
         xp_last = ops.gather_rows(last, xp)
         hid_last = ops.rmsnorm_fwd(xp_last, self.norm_w, self.eps)
-        hid_c = ops.rmsnorm_fwd(xc, self.norm_w, self.eps)
+        with (torch.cuda.stream(side) if side is not None else _nullctx()):
+            hid_c = ops.rmsnorm_fwd(xc, self.norm_w, self.eps)
+        if side is not None:
+            main.wait_stream(side)
+            for t_ in (hid_c, xc):
+                t_.record_stream(main)
         return hid_last, hid_c, ((tape_p, tape_c, xp_last, xc, last) if save else None)
 
-    def backward_hidden_shared(self, dhid_last: torch.Tensor, dhid_c: torch.Tensor, tape, mp: SeqMeta, mc: SeqMeta, copies: int):
+    def backward_hidden_shared(self, dhid_last: torch.Tensor, dhid_c: torch.Tensor, tape, mp: SeqMeta, mc: SeqMeta, copies: int, side=None):
         tape_p, tape_c, xp_last, xc, last = tape
-        dxc = ops.rmsnorm_bwd(dhid_c, xc, self.norm_w, self.eps)
+        dev = dhid_c.device
+        main = torch.cuda.current_stream(dev) if side is not None else None
+        if side is not None:
+            side.wait_stream(main)
+            dhid_c.record_stream(side)
+        with (torch.cuda.stream(side) if side is not None else _nullctx()):
+            dxc = ops.rmsnorm_bwd(dhid_c, xc, self.norm_w, self.eps)
         dxp = ops.scatter_rows(last, ops.rmsnorm_bwd(dhid_last, xp_last, self.norm_w, self.eps), mp.B * mp.S)
         for li in reversed(range(self.L)):
-            dxc, pre = self.layer_bwd(li, dxc, tape_c[li], mc, prefix=mp.S)
-            tape_c[li] = None
+            with (torch.cuda.stream(side) if side is not None else _nullctx()):
+                dxc, pre = self.layer_bwd(li, dxc, tape_c[li], mc, prefix=mp.S)
+                tape_c[li] = None
+                if side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+            if side is not None:
+                main.wait_event(ev)                          # the prompt rows' K / V gradients from the copies
+                pre[0].record_stream(main)
+                pre[1].record_stream(main)
             dxp = self.layer_bwd(li, dxp, tape_p[li], mp, extra_dkv=(pre[0], pre[1], copies))
             tape_p[li] = None
             if self.layer_done_hook is not None:
-                self.layer_done_hook(li)
+                self.layer_done_hook(li)                     # (main has waited for the completion chain's layer: its LoRA gradients are in)
+        if side is not None:
+            main.wait_stream(side)
+            dxc.record_stream(main)
         return dxp, dxc
 
 

@@ -81,7 +81,7 @@ def repeat_sampler_indices(num_samples: int, mini_repeat_count: int, batch_size:
 
 
 def per_token_logps_shared_policy(model, prompt_ids: torch.Tensor, prompt_mask: torch.Tensor, completion_ids: torch.Tensor,
-                                  completion_mask_: torch.Tensor, prompt_alias: Sequence[int], **multimodal) -> Optional[torch.Tensor]:
+                                  completion_mask_: torch.Tensor, prompt_alias: Sequence[int], side=None, **multimodal) -> Optional[torch.Tensor]:
     """`per_token_logps` WITH gradients (the policy pass of compute_loss, grpo_trainer.py:777-779) when the rows are groups of
     consecutive copies of a prompt (RepeatRandomSampler, :107-116): the prompt rows run once per distinct prompt — forward and
     backward — and the completion rows attend to [their prompt's K / V | their own].  Same log-probs as the full-sequence pass
@@ -104,7 +104,7 @@ def per_token_logps_shared_policy(model, prompt_ids: torch.Tensor, prompt_mask: 
     embeds = model._inputs_embeds(prompt_ids, multimodal.get("dna_tokenized"), multimodal.get("batch_idx_map"),
                                   multimodal.get("dna_alias"), multimodal.get("dna_enc"))
     hid_last, hid_c = tm.hidden_states_shared(embeds.index_select(0, sel), prompt_mask.index_select(0, sel), completion_ids,
-                                              completion_mask_, copies)
+                                              completion_mask_, copies, side=side)
     from .modeling import _ExpandGroupsFn, _LogProbFn
     H = hid_c.shape[-1]
     first = _ExpandGroupsFn.apply(hid_last, copies)                                          # [B, H]: predicts completion token 0

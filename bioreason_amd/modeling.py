@@ -138,20 +138,20 @@ class _SharedStackFn(torch.autograd.Function):
     """The decoder stack over (distinct prompts, per-copy completions) as one autograd node (engine.forward_hidden_shared)."""
 
     @staticmethod
-    def forward(ctx, xp, xc, anchor, model, mp, mc, copies):
+    def forward(ctx, xp, xc, anchor, model, mp, mc, copies, side):
         eng = model.engine
         need = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[2])
-        hid_last, hid_c, tape = eng.forward_hidden_shared(xp, mp, xc, mc, copies, save=need)
-        ctx.model, ctx.mp, ctx.mc, ctx.copies, ctx.tape = model, mp, mc, copies, tape
+        hid_last, hid_c, tape = eng.forward_hidden_shared(xp, mp, xc, mc, copies, save=need, side=side)
+        ctx.model, ctx.mp, ctx.mc, ctx.copies, ctx.tape, ctx.side = model, mp, mc, copies, tape, side
         return hid_last, hid_c
 
     @staticmethod
     def backward(ctx, dlast, dc):
         eng = ctx.model.engine
         eng.ensure_transposed()
-        dxp, dxc = eng.backward_hidden_shared(dlast.contiguous(), dc.contiguous(), ctx.tape, ctx.mp, ctx.mc, ctx.copies)
+        dxp, dxc = eng.backward_hidden_shared(dlast.contiguous(), dc.contiguous(), ctx.tape, ctx.mp, ctx.mc, ctx.copies, side=ctx.side)
         ctx.tape = None
-        return dxp, None, None, None, None, None, None
+        return dxp, None, None, None, None, None, None, None
 
 
 class _ExpandGroupsFn(torch.autograd.Function):
@@ -445,7 +445,7 @@ class Qwen3ForCausalLM(nn.Module):
         return _StackFn.apply(x.contiguous(), anchor, self, meta)
 
     def hidden_states_shared(self, prompt_embeds: torch.Tensor, prompt_mask: torch.Tensor, completion_ids: torch.Tensor,
-                             completion_mask: torch.Tensor, copies: int):
+                             completion_mask: torch.Tensor, copies: int, side=None):
         """The hidden states a [B, P + C] pass would produce at the positions GRPO keeps (grpo_trainer.py:510-520 + :779: the last
         prompt position and the completion positions), for B = R * copies rows made of R distinct prompts whose `copies` rollouts
         are consecutive: prompt_embeds [R, P, H] (differentiable), prompt_mask [R, P], completion_ids / completion_mask [B, C].
@@ -477,7 +477,7 @@ class Qwen3ForCausalLM(nn.Module):
         xc = torch.empty((B * C, H), dtype=BF16, device=dev)
         ops.embed_scatter_fwd(completion_ids.to(torch.int32).reshape(-1).contiguous(), None, eng.E, None, xc)
         anchor = self.arena.anchor if self.arena is not None else xp.new_zeros(1, dtype=torch.float32)
-        return _SharedStackFn.apply(xp.contiguous(), xc, anchor, self, mp, mc, copies)
+        return _SharedStackFn.apply(xp.contiguous(), xc, anchor, self, mp, mc, copies, side)
 
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, labels=None, position_ids=None,
                 return_logits: bool = True, **unused):

@@ -67,6 +67,8 @@ class GRPOConfig:
     # the reference-policy pass (no grad, adapters off) on a second HIP stream, concurrent with the policy forward: at one prompt x 8
     # rollouts both are chains of kernels that fill about half of the chip (grids of 128 - 144 workgroups on 256 CUs)
     overlap_ref_pass: bool = True
+    # the two row segments of the shared-prompt policy pass (prompt chain, completion chain) on two HIP streams, one event per layer
+    overlap_policy_chains: bool = True
 
 
 def token_stat_rewards(completion_ids: torch.Tensor, completion_mask: torch.Tensor) -> torch.Tensor:
@@ -202,12 +204,14 @@ class GRPOStepRunner(_DataParallelStep):
         self.lr_schedule: Optional[Callable[[int], float]] = None
         self.last_lr = cfg.learning_rate
 
-    def _side_stream(self, dev):
+    def _side_stream(self, dev, which: int = 0):
         if dev.type != "cuda":
             return None
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=dev)
-        return self._side
+            self._side = {}
+        if which not in self._side:
+            self._side[which] = torch.cuda.Stream(device=dev)
+        return self._side[which]
 
     # ---- _generate_and_score_completions (:535-749) ---------------------------------------------------------------
     def generate_and_score(self, batch: Dict, timing: bool = False, mark=lambda n: None) -> Dict:
@@ -284,8 +288,10 @@ class GRPOStepRunner(_DataParallelStep):
         m, c = self.model, self.cfg
         lp = None
         if c.share_policy_prompt and inputs.get("prompt_alias") is not None:
+            side2 = self._side_stream(inputs["prompt_ids"].device, 1) if c.overlap_policy_chains else None
             lp = grpo.per_token_logps_shared_policy(m, inputs["prompt_ids"], inputs["prompt_mask"], inputs["completion_ids"],
-                                                    inputs["completion_mask"], inputs["prompt_alias"], **inputs["multimodal_inputs"])
+                                                    inputs["completion_mask"], inputs["prompt_alias"], side=side2,
+                                                    **inputs["multimodal_inputs"])
         if lp is None:
             lp = grpo.per_token_logps(m, inputs["prompt_ids"], inputs["prompt_mask"], inputs["completion_ids"],
                                       inputs["completion_mask"], **inputs["multimodal_inputs"])
