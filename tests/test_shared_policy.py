@@ -215,3 +215,33 @@ def test_ref_pass_on_side_stream_equals_main_stream(hip_device):
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1]), (outs[0][1] - outs[1][1]).abs().max()
     assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,copies", [("tiny_a", 2), ("tiny_b", 3)])
+def test_two_stream_chains_equal_one_stream(hip_device, name, copies):
+    """the prompt chain and the completion chain of the shared policy pass on two HIP streams (engine.forward_hidden_shared
+    `side`): log-probs bit-identical to the one-stream pass, gradients equal up to the order of the fp32 atomics of the LoRA
+    weight gradients (both chains add into the same arena)"""
+    from bioreason_amd import grpo
+    dev = hip_device
+    fix = torch.load(os.path.join(GOLD, f"{name}.pt"), weights_only=False)
+    m = build(fix, dev, True)
+    m.train()
+    ids, mask, mm, alias = _group_batch(fix, dev, copies)
+    B, C = ids.shape[0], 9
+    g = torch.Generator().manual_seed(2)
+    comp = torch.randint(3, fix["config"]["text"]["vocab_size"] - 8, (B, C), generator=g).to(dev)
+    cmask = torch.ones((B, C), dtype=torch.int32, device=dev)
+    w = torch.randn(B, C, generator=g).to(dev)
+    side = torch.cuda.Stream(device=dev)
+    res = []
+    for s_ in (None, side, side, None):
+        m.arena.zero_grad()
+        lp = grpo.per_token_logps_shared_policy(m, ids, mask, comp, cmask, alias, side=s_, **mm)
+        (lp * w).sum().backward()
+        torch.cuda.synchronize()
+        res.append((lp.detach().clone(), m.arena.grads.clone()))
+    for lp, gr in res[1:]:
+        assert torch.equal(lp, res[0][0])
+        assert rel(gr, res[0][1]) < 1e-4, rel(gr, res[0][1])

@@ -36,3 +36,17 @@ for it in range(4):
     torch.cuda.synchronize()
     print("iter", it, "ref side == quiet:", bool(torch.equal(ref_side, ref_quiet)), float((ref_side - ref_quiet).abs().max()),
           "| policy beside ref vs quiet (dropout masks differ per call, so only finite check):", bool(torch.isfinite(lp).all()), flush=True)
+
+# the two-stream chains of the policy pass at full size: log-probs bit-identical, gradients equal up to atomics order (dropout off)
+model.text_model.lora_dropout_p = 0.0
+side = torch.cuda.Stream(device=dev)
+res = []
+for s_ in (None, side, side):
+    model.arena.zero_grad()
+    lp = grpo.per_token_logps_shared_policy(model, inputs["prompt_ids"], inputs["prompt_mask"], inputs["completion_ids"],
+                                            inputs["completion_mask"], inputs["prompt_alias"], side=s_, **inputs["multimodal_inputs"])
+    lp.sum().backward()
+    torch.cuda.synchronize()
+    res.append((lp.detach().clone(), model.arena.grads.clone()))
+for lp, gr in res[1:]:
+    print("two-stream chains: logps equal", bool(torch.equal(lp, res[0][0])), "grads rel", float((gr - res[0][1]).norm() / res[0][1].norm()), flush=True)
