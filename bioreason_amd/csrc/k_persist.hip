@@ -83,6 +83,65 @@ __global__ __launch_bounds__(NT) void gridbar_probe_kernel(GridSync* gs, unsigne
 #endif
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Chained launches (probe): kernel k of a dependent chain is launched on stream k % 2, requests its read-once "weights" at once,
+// THEN waits on a device-side counter for kernel k - 1 (all of its workgroups have published), reads the predecessor's slots
+// (sc1), publishes its own and bumps its counter.  Two kernels are resident at a time (the in-stream order keeps k + 2 behind k), so
+// the weight stream of k + 1 overlaps the latency chain of k — what a launch boundary forbids and a grid barrier paid for with
+// queueing (NOTES.md).  mode 0: the same kernels without the wait, on ONE stream (ordinary dependent launches).
+#ifndef BRA_EMU
+template <int NT, int WCH>
+__global__ __launch_bounds__(NT, 2) void chain_probe_kernel(unsigned* done /* [n] counters, 64-byte apart */, unsigned* buf /* [2][nwg][32] */,
+                                                            unsigned* errs, const u32x4* wts, unsigned long wts_chunks, int k, int chained,
+                                                            unsigned timeout_ticks) {
+    __shared__ unsigned ok_flag;
+    const int nwg = (int)gridDim.x, wg = (int)blockIdx.x, tid = (int)threadIdx.x;
+    u32x4 w[WCH];
+#pragma unroll
+    for (int u = 0; u < WCH; ++u) {
+        const unsigned long c = ((unsigned long)k * nwg + wg) * (unsigned long)(NT * WCH) + (unsigned long)u * NT + tid;
+        w[u] = ld16_nt(wts + c % wts_chunks);
+    }
+    sched_fence();
+    if (chained && k > 0) {
+        if (tid == 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned ok = 1u;
+            while (gs_load(done + 16 * (k - 1)) < (unsigned)nwg) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)timeout_ticks) { ok = 0u; gs_store(errs + 3, (unsigned)k); break; }
+            }
+            ok_flag = ok;
+        }
+        __syncthreads();
+        if (!ok_flag) return;
+    }
+    const __amdgpu_buffer_rsrc_t rs = xs_rsrc(buf);
+    const unsigned nwords = (unsigned)nwg * 32u;
+    unsigned bad = 0, sink = 0;
+    if (k > 0) {
+        for (unsigned c = tid; c < nwords / 4; c += NT) {
+            const u32x4 v = xs_load16(rs, (unsigned)((((k - 1) & 1) * nwords + 4 * c) * 4));
+            const unsigned src = (4 * c) >> 5, j = (4 * c) & 31u;
+            const unsigned want = (unsigned)(k - 1) * 1000003u + src * 64u + j;
+            bad += (v.x != want) + (v.y != want + 1u) + (v.z != want + 2u) + (v.w != want + 3u);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < WCH; ++u) sink ^= w[u].x ^ w[u].y ^ w[u].z ^ w[u].w;
+    if (tid < 16) {
+        u32x2 v;
+        v.x = (unsigned)k * 1000003u + (unsigned)wg * 64u + 2u * tid + (sink == 0x12345678u ? 1u : 0u);
+        v.y = v.x + 1u;
+        xs_store8(rs, (unsigned)(((k & 1) * nwords + wg * 32 + 2 * tid) * 4), v);
+        gs_drain();
+    }
+    if (bad) atomicAdd(errs, bad);
+    __syncthreads();
+    if (tid == 0) gs_add(done + 16 * k, 1u);
+}
+#endif
+
 // =====================================================================================================================
 // The decode step of the shared-prefix rollout as ONE launch: all decoder layers of Qwen3DecoderLayer.forward with a KV cache
 // (TF:qwen3:294-323) for the new token of every sequence — what bra_qwen_decode_step_one issues as six launches per layer.
@@ -572,5 +631,27 @@ extern "C" int bra_qwen_layers_persist(const void* layers_dev, int L, int R, int
     BRA_PERSIST(2048, 2048, 1024, 6144, 128, 2)                     // Qwen3-1.7B (the reference's "Qwen3-1B", sh_reason.sh:46)
 #undef BRA_PERSIST
     return BRA_ERR_UNSUPPORTED;
+#endif
+}
+
+// n dependent probe kernels (see chain_probe_kernel): chained = 1 alternates stream_a / stream_b with device-side waits, 0 issues
+// them all on stream_a.  done: n x 16 words (zeroed here on stream_a BEFORE the first launch; the caller orders stream_b behind it),
+// buf: 2 x nwg x 32 words, errs: 4 words ([0] mismatching words, [3] kernel index of a timed-out wait).
+extern "C" int bra_chain_probe(void* done, void* buf, void* errs, const void* wts, long wts_bytes, int nwg, int n, int chained, int wchunks,
+                               int timeout_us, void* stream_a, void* stream_b) {
+#ifdef BRA_EMU
+    (void)done; (void)buf; (void)errs; (void)wts; (void)wts_bytes; (void)nwg; (void)n; (void)chained; (void)wchunks; (void)timeout_us; (void)stream_a; (void)stream_b;
+    return BRA_ERR_UNSUPPORTED;
+#else
+    if (!done || !buf || !errs || !wts || wts_bytes < 16 || nwg <= 0 || n <= 0 || (wchunks != 4 && wchunks != 8 && wchunks != 12)) return BRA_ERR_ARG;
+    hipStream_t sa = (hipStream_t)stream_a, sb = (hipStream_t)stream_b;
+    const unsigned ticks = (unsigned)(timeout_us > 0 ? timeout_us : 20000) * 100u;
+    for (int k = 0; k < n; ++k) {
+        hipStream_t st = (chained && (k & 1)) ? sb : sa;
+        if (wchunks == 4) BRA_LAUNCH((chain_probe_kernel<512, 4>), dim3(nwg), dim3(512), 0, st, (unsigned*)done, (unsigned*)buf, (unsigned*)errs, (const u32x4*)wts, (unsigned long)(wts_bytes / 16), k, chained, ticks);
+        else if (wchunks == 8) BRA_LAUNCH((chain_probe_kernel<512, 8>), dim3(nwg), dim3(512), 0, st, (unsigned*)done, (unsigned*)buf, (unsigned*)errs, (const u32x4*)wts, (unsigned long)(wts_bytes / 16), k, chained, ticks);
+        else BRA_LAUNCH((chain_probe_kernel<512, 12>), dim3(nwg), dim3(512), 0, st, (unsigned*)done, (unsigned*)buf, (unsigned*)errs, (const u32x4*)wts, (unsigned long)(wts_bytes / 16), k, chained, ticks);
+    }
+    return BRA_LAUNCH_STATUS();
 #endif
 }

@@ -379,6 +379,10 @@ int bra_qwen_decode_step_persist(const void* layers_host, const void* layers_dev
                                  const void* pmask, int t, const int* t_dev, int embed_done, void* x, void* qkv, void* o, void* h,
                                  void* act, float* ss_ws, int nss, float* part_o, float* part_ml, int nslot, float* logits,
                                  void* sync, int prefetch, int stop_after, int timeout_us, void* stream);
+/* probe: n dependent kernels that each stream `wchunks` x 16 B per thread of read-once data, as ordinary launches on one stream
+ * (chained 0) or alternating two streams with device-side waits on per-kernel completion counters (chained 1): see k_persist.hip */
+int bra_chain_probe(void* done, void* buf, void* errs, const void* wts, long wts_bytes, int nwg, int n, int chained, int wchunks,
+                    int timeout_us, void* stream_a, void* stream_b);
 int bra_gridbar_probe(void* sync, void* buf, void* errs, const void* wts, long wts_bytes, int nwg, int iters, int mode,
                       int wchunks, int timeout_us, void* stream);
 
