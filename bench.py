@@ -437,6 +437,8 @@ def timed_steps(step, steps: int, warmup: int, world: int, dev, first_index: int
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks"""
     import torch
     import torch.distributed as dist
+    if dist.is_initialized() and world == 1:
+        world = 2            # BRA_DP_SINGLE_RANK rehearsal: take the collective branches below in the one-rank group
     sync = (lambda: torch.cuda.synchronize()) if dev.type == "cuda" else (lambda: None)
     for i in range(warmup):
         step(first_index + i)
@@ -516,7 +518,8 @@ def main():
             raise SystemExit(f"rank {rank}: needs GPU {local}, {torch.cuda.device_count()} visible")
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-        if world > 1:
+        if world > 1 or (os.environ.get("BRA_DP_SINGLE_RANK") == "1" and "RANK" in os.environ):
+            # (the second form: one-rank RCCL group on a 1-GPU box, every collective of the step issued — tools/rccl_single_rank.sh)
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group(backend="nccl", device_id=dev)
 
@@ -666,7 +669,7 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"not measured: {type(e).__name__}"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -22,6 +22,7 @@ No model sharding: NT-500M + Qwen3-1.7B + KV cache + activations use < 60 GB of 
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional
 
@@ -109,12 +110,15 @@ class _DataParallelStep:
         self.model = model
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # `dp`: the collectives of the step are issued.  BRA_DP_SINGLE_RANK=1 issues them in a ONE-rank group too (each is then the
+        # identity): the hardware rehearsal of the RCCL path on a 1-GPU box (tools/rccl_single_rank.sh), never set in production
+        self.dp = dist.is_initialized() and (self.world > 1 or os.environ.get("BRA_DP_SINGLE_RANK") == "1")
         self.timers: Dict[str, float] = {}
         self._handles: List = []
         self._cuts: Dict[int, tuple] = {}
         self._n_buckets = max(1, int(n_buckets))
         arena = model.arena
-        if self.world > 1 and METRIC_SLOT not in arena._shapes:
+        if self.dp and METRIC_SLOT not in arena._shapes:
             arena.add(METRIC_SLOT, 1, 64)            # mask stays 0: excluded from the norm and from the update
             arena.commit()
             arena.pack()
@@ -131,7 +135,7 @@ class _DataParallelStep:
             offs = [a._offsets[k] for k in a._offsets if k.startswith(f"text.layers.{li}.")]
             starts.append(min(offs) if offs else None)
         self._cuts = {}
-        if self.world == 1 or any(s is None for s in starts) or sorted(starts) != starts:
+        if not self.dp or any(s is None for s in starts) or sorted(starts) != starts:
             return
         nb = min(self._n_buckets, L)
         hi = a.numel
@@ -153,11 +157,11 @@ class _DataParallelStep:
     def begin_backward(self):
         self._handles = []
         eng = self.model.text_model.engine
-        eng.layer_done_hook = self._layer_done if (self.world > 1 and self._cuts) else None
+        eng.layer_done_hook = self._layer_done if (self.dp and self._cuts) else None
 
     def reduce_gradients(self) -> float:
         """finish the data-parallel sum; returns the factor that turns the sum into DDP's mean"""
-        if self.world == 1:
+        if not self.dp:
             return 1.0
         eng = self.model.text_model.engine
         eng.layer_done_hook = None
@@ -267,7 +271,7 @@ class GRPOStepRunner(_DataParallelStep):
         # rewards (+ completion length) -> ONE all-gather -> group statistics -> local slice (:651-699, 703-716)
         rewards = self.reward_fn(completion_ids, cmask).float()
         packed = torch.cat([rewards, cmask.sum(1, keepdim=True).float()], dim=1).contiguous()
-        if self.world > 1:
+        if self.dp:
             gathered = [torch.empty_like(packed) for _ in range(self.world)]
             dist.all_gather(gathered, packed)
             packed_all = torch.cat(gathered, dim=0)
@@ -327,14 +331,14 @@ class GRPOStepRunner(_DataParallelStep):
             self.begin_backward()
         loss, stats = self.compute_loss(inputs)
         mark("policy_fwd")
-        if self.world > 1:                  # loss / KL / clip ratio of this rank ride in the gradient bucket's spare slot
+        if self.dp:                         # loss / KL / clip ratio of this rank ride in the gradient bucket's spare slot
             m.arena.grad(METRIC_SLOT).view(-1)[:3].add_(stats / ga)
         (loss / ga if ga > 1 else loss).backward()
         mark("policy_bwd")
         out = {"loss_t": loss.detach(), "stats_t": stats, "reward_mean_t": inputs["roll_metrics"][1]}
         if slot == ga - 1:
             scale = self.reduce_gradients()
-            if self.world > 1:
+            if self.dp:
                 local3 = m.arena.grad(METRIC_SLOT).view(-1)[:3] * scale
             else:
                 local3 = stats
