@@ -422,6 +422,32 @@ extern "C" int bra_group_sum(const void* src, long member_stride, int copies, co
     return BRA_LAUNCH_STATUS();
 }
 
+// out block ((r copies + c) inner + h) = src block (r inner + h) for every copy c: the K / V rows of a shared prompt placed in front
+// of each rollout's own rows (one 16-byte load, `copies` 16-byte stores per thread)
+namespace bra {
+__global__ __launch_bounds__(256) void group_broadcast_kernel(const bf16_t* src, long src_blk_stride, bf16_t* out, long out_blk_stride,
+                                                               int copies, int inner, long nblk, long n8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nblk * n8) return;
+    const long blk = i / n8;
+    const long c8 = i - blk * n8;
+    const long r = blk / inner;
+    const long h = blk - r * inner;
+    const u32x4 v = ld16(src + blk * src_blk_stride + c8 * 8);
+    for (int c = 0; c < copies; ++c) st16(out + ((r * copies + c) * inner + h) * out_blk_stride + c8 * 8, v);
+}
+}  // namespace bra
+
+extern "C" int bra_group_broadcast(const void* src, long src_blk_stride, void* out, long out_blk_stride, int R, int copies, int inner,
+                                   long n, void* stream) {
+    if (R == 0 || n == 0 || inner == 0) return 0;
+    if (!src || !out || copies <= 0 || inner < 0 || n % 8 || src_blk_stride % 8 || out_blk_stride % 8) return BRA_ERR_ARG;
+    const long nblk = (long)R * inner, items = nblk * (n / 8);
+    BRA_LAUNCH(bra::group_broadcast_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, (const bra::bf16_t*)src,
+               src_blk_stride, (bra::bf16_t*)out, out_blk_stride, copies, inner, nblk, n / 8);
+    return BRA_LAUNCH_STATUS();
+}
+
 extern "C" int bra_gather_rows(const int* rows, const void* x, long ldx, void* out, long ldo, int n, int H,
                                void* stream) {
     if (n == 0) return 0;

@@ -338,8 +338,8 @@ class QwenEngine:
                 # every copy gets its prompt's K / V rows in front of its own (one broadcast copy per tensor)
                 kc = torch.empty((B, self.Hkv, P + C, self.hd), dtype=BF16, device=dev)
                 vc = torch.empty((B, self.Hkv, P + C, self.hd), dtype=BF16, device=dev)
-                kc.view(R, copies, self.Hkv, P + C, self.hd)[:, :, :, :P].copy_(kc_r[:, None])
-                vc.view(R, copies, self.Hkv, P + C, self.hd)[:, :, :, :P].copy_(vc_r[:, None])
+                ops.group_broadcast(kc_r, kc, copies)
+                ops.group_broadcast(vc_r, vc, copies)
                 xc, sc = self.layer_fwd(li, xc, mc, save, kv_out=(kc, vc, P))
                 tape_c.append(sc)
         last = torch.arange(R, device=dev, dtype=torch.int32) * P + (P - 1)

@@ -115,7 +115,7 @@ def per_token_logps_shared_policy(model, prompt_ids: torch.Tensor, prompt_mask: 
 
 @torch.no_grad()
 def per_token_logps_shared_prefix(model, prompt_ids: torch.Tensor, prompt_mask: torch.Tensor, completion_ids: torch.Tensor,
-                                  completion_mask_: torch.Tensor, prompt_alias: Sequence[int], **multimodal) -> torch.Tensor:
+                                  completion_mask_: torch.Tensor, prompt_alias: Sequence[int], side=None, **multimodal) -> torch.Tensor:
     """`per_token_logps` for a no-grad pass (the reference policy, grpo_trainer.py:628-640) when several rows share a
     prompt (GRPO's G copies): the prompt is run ONCE per distinct prompt with its K/V kept, then only the C completion
     tokens of every row are run against [shared prompt K/V | own completion K/V].  Rows of a batched forward are
@@ -131,6 +131,28 @@ def per_token_logps_shared_prefix(model, prompt_ids: torch.Tensor, prompt_mask: 
     C = completion_ids.shape[1]
     S = P + C
     dev = prompt_ids.device
+    from .generation import _uniform_groups
+    grp = _uniform_groups(list(prompt_alias))
+    if grp is not None and grp[1] >= 2:
+        # consecutive groups of equal size (RepeatRandomSampler's order): the two-segment forward of the policy pass, nothing kept
+        R, copies = grp
+        sel = torch.arange(R, device=dev) * copies
+        embeds = model._inputs_embeds(prompt_ids, multimodal.get("dna_tokenized"), multimodal.get("batch_idx_map"), multimodal.get("dna_alias"),
+                                      multimodal.get("dna_enc"))
+        mp = SeqMeta(B=R, S=P, pos=torch.arange(P, dtype=torch.int32, device=dev).repeat(R),
+                     kmask=prompt_mask.index_select(0, sel).to(torch.uint8).contiguous(), lora_on=tm._lora_enabled, max_pos=S)
+        kfull = torch.cat([prompt_mask, completion_mask_.to(prompt_mask.dtype)], dim=1).to(torch.uint8).contiguous()
+        mc = SeqMeta(B=B, S=C, pos=(torch.arange(C, dtype=torch.int32, device=dev) + P).repeat(B), kmask=kfull,
+                     lora_on=tm._lora_enabled, max_pos=S)
+        ids32 = completion_ids.to(torch.int32).reshape(-1).contiguous()
+        xc = torch.empty((B * C, eng.H), dtype=BF16, device=dev)
+        ops.embed_scatter_fwd(ids32, None, eng.E, None, xc)
+        xp = embeds.index_select(0, sel).reshape(R * P, -1).to(BF16).contiguous()
+        hid_last, hid_c, _ = eng.forward_hidden_shared(xp, mp, xc, mc, copies, save=False, side=side)
+        first = hid_last.repeat_interleave(copies, dim=0)
+        hsel = torch.cat([first[:, None, :], hid_c.view(B, C, -1)[:, : C - 1, :]], dim=1).reshape(B * C, -1).contiguous()
+        logp, _ = ops.lmhead_logprob(hsel, eng.E, ids32)
+        return logp.view(B, C)
     reps = sorted(set(prompt_alias))
     where = {r: i for i, r in enumerate(reps)}
     sel = torch.tensor(reps, device=dev)

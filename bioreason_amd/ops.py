@@ -389,6 +389,17 @@ def group_sum(src: torch.Tensor, copies: int, add: Optional[torch.Tensor] = None
     return out
 
 
+def group_broadcast(src: torch.Tensor, out: torch.Tensor, copies: int) -> torch.Tensor:
+    """src [R, I, n...] (contiguous) -> out[(r copies + c), i, :n...] for every copy c; out is [R * copies, I, N...] with the same
+    trailing dims except dim 2 (N >= n rows; the first n are written): a shared prompt's K / V in front of each rollout's own."""
+    R, I = src.shape[0], src.shape[1]
+    assert src.dtype == BF16 and out.dtype == BF16 and src.is_contiguous() and out.is_contiguous()
+    assert out.shape[0] == R * copies and out.shape[1] == I and out.shape[3:] == src.shape[3:] and out.shape[2] >= src.shape[2]
+    n = src[0, 0].numel()
+    get_lib().call("bra_group_broadcast", src, src.stride(1), out, out.stride(1), R, copies, I, n, current_stream(src))
+    return out
+
+
 def transpose2d(x: torch.Tensor, pad_to: int = 8) -> torch.Tensor:
     """x [R, C] -> [C, Rp] view [:, :R] with row pitch Rp = R rounded up to `pad_to` (zero padded)"""
     R, C = x.shape

@@ -344,6 +344,13 @@ int bra_grpo_loss(const float* logp, const float* old_logp, const float* ref_log
 int bra_group_sum(const void* src, long member_stride, int copies, const void* add, long add_stride, void* out, long out_stride,
                   int R, long n, void* stream);
 
+/* The inverse placement: block (r inner + h) of src (n contiguous bf16 elements, blocks src_blk_stride apart) is written to blocks
+ * ((r copies + c) inner + h) of out (out_blk_stride apart) for c in [0, copies): a shared prompt's K / V rows [R, Hkv, P, hd] put in
+ * front of every rollout's own rows in a [R copies, Hkv, P + C, hd] cache (the completion rows of the shared-prompt passes attend to
+ * [prompt | own]; replaces `expand` + copy of the reference's batched layout, grpo_trainer.py:107-116 / TF:qwen3:185-207). */
+int bra_group_broadcast(const void* src, long src_blk_stride, void* out, long out_blk_stride, int R, int copies, int inner, long n,
+                        void* stream);
+
 /* ---- persistent-grid building blocks (k_persist.hip, bra_gridsync.h) -------------------------------------------------
  * In-launch grid barrier + write-through hand-off used by the persistent decode step (the body of HF's `_sample` loop,
  * TF:generation/utils.py:2876-2925, kept inside one launch).  bra_gridsync_bytes: size of the synchronisation record the

@@ -83,6 +83,17 @@ def test_group_sum_kernel(backend):
     assert torch.equal(ops.group_sum(src, 3).cpu(), src.float().view(2, 3, 7, 4, 8).sum(1).to(torch.bfloat16).cpu())
 
 
+def test_group_broadcast_kernel(backend):
+    from bioreason_amd import ops
+    g = torch.Generator().manual_seed(1)
+    src = torch.randn(2, 3, 5, 8, generator=g).to(torch.bfloat16).to(backend)
+    out = torch.full((6, 3, 9, 8), 7.0, dtype=torch.bfloat16, device=backend)
+    ops.group_broadcast(src, out, 3)
+    want = torch.full((6, 3, 9, 8), 7.0, dtype=torch.bfloat16)
+    want.view(2, 3, 3, 9, 8)[:, :, :, :5] = src.cpu()[:, None]
+    assert torch.equal(out.cpu(), want)
+
+
 def test_runner_uses_the_shared_policy_pass(backend):
     """GRPOStepRunner.compute_loss takes the shared pass for grouped batches (cfg.share_policy_prompt) and the step still trains"""
     from bioreason_amd.trainer import GRPOConfig, GRPOStepRunner
