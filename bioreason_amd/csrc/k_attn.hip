@@ -853,6 +853,12 @@ static int launch_dkv(const AttnArgs& a, bra_stream_t st) {
         int rc = launch_dkv_v<HD, 1, 4>(a, st);
         return rc ? rc : launch_dkv_v<HD, 2, 4>(a, st);
     }
+    // short query loops (the completion segment of a shared-prompt pass: Sq = C) or grids that cannot fill the chip twice over
+    // (one prompt: 72 workgroups of 256 keys): ONE launch that keeps dK and dV (4 waves, one per SIMD, the whole register file; S and
+    // P computed once) instead of two that each recompute S — same arithmetic, bit-identical.  Long loops at full grids stay on the
+    // two 8-wave kernels: there the second wave per SIMD is worth more than the third S (B = 8, S = 2436: 1.83 vs 2.16 ms).
+    const long grid8 = (long)((a.Sk + 255) / 256) * a.Hkv * a.B;
+    if (a.Sq <= 512 || grid8 < 256) return launch_dkv_v<HD, 0, 4>(a, st);
     int rc = launch_dkv_v<HD, 1, NW>(a, st);
     return rc ? rc : launch_dkv_v<HD, 2, NW>(a, st);
 }

@@ -21,6 +21,8 @@ struct LoraDownArgs {
     float alpha;
     DropCfg d;
     int nb_live;                    // rank blocks that belong to a target module; the padding blocks behind them produce zeros
+    int steps_per;                  // K steps (of 128) per workgroup along gridDim.y (split-K form), nstep when gridDim.y == 1
+    float* part;                    // split-K form: fp32 partial tiles [gridDim.y][M][R] (unscaled) instead of t
 };
 
 // workgroup = 32 rows of x against all R = 32 RB adapter rows; K in steps of 128 through LDS, the four waves take two of the
@@ -75,14 +77,18 @@ __global__ __launch_bounds__(256) void lora_down_drop_kernel(LoraDownArgs g) {
     for (int rb = 0; rb < NL; ++rb)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[rb][q] = 0.f;
-    issue(0); commit(0, 0);
+    // split-K form (small M: M / 32 workgroups cannot fill the chip, and each would read all of A): gridDim.y workgroups per row
+    // block take `steps_per` K steps each and leave fp32 partial tiles that lora_partial_reduce_kernel sums in a fixed order
+    const int s_lo = (int)blockIdx.y * g.steps_per;
+    const int s_hi = s_lo + g.steps_per < nstep ? s_lo + g.steps_per : nstep;
+    issue(s_lo); commit(s_lo & 1, s_lo);
     __syncthreads();
     const int mrow = m0 + (lane & 31);                           // this lane's row of x (A-operand row)
-    for (int s = 0; s < nstep; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
         const int buf = s & 1;
         // requests without a branch around them (the last step re-requests its own tile and drops it); the fragment reads are
         // tied behind the fence through `lrow` so that the requests are not sunk to the commit behind the MFMAs
-        issue(s + 1 < nstep ? s + 1 : s);
+        issue(s + 1 < s_hi ? s + 1 : s);
         sched_fence();
         const int lrow = opaque_i(lane & 31);
 #pragma unroll
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256) void lora_down_drop_kernel(LoraDownArgs g) {
                 acc[rb] = mfma_32x32x16(af, bf, acc[rb]);
             }
         }
-        if (s + 1 < nstep) commit(buf ^ 1, s + 1);
+        if (s + 1 < s_hi) commit(buf ^ 1, s + 1);
         __syncthreads();
     }
     if (wave != 0) {
@@ -120,9 +126,27 @@ __global__ __launch_bounds__(256) void lora_down_drop_kernel(LoraDownArgs g) {
 #pragma unroll
                 for (int w = 0; w < 3; ++w) v += red[((w * NL + (rb < NL ? rb : 0)) * 64 + lane) * 16 + q];
             }
-            if (m < g.M && r < g.R) g.t[(long)m * g.ldt + r] = f2bf(g.alpha * v);
+            if (m < g.M && r < g.R) {
+                if (g.part) g.part[((long)blockIdx.y * g.M + m) * g.R + r] = v;
+                else g.t[(long)m * g.ldt + r] = f2bf(g.alpha * v);
+            }
         }
     }
+}
+
+// t[m, r] = bf16(alpha * (part[0][m][r] + part[1][m][r] + ...)): the fixed-order sum of the split-K partial tiles; 4 columns per thread
+__global__ __launch_bounds__(256) void lora_partial_reduce_kernel(const float* part, int ks, long MR, int R, float alpha, bf16_t* t, long ldt) {
+    const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= MR) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int k = 0; k < ks; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(part + (long)k * MR + i4);
+        a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+    }
+    const long m = i4 / R;
+    const int r = (int)(i4 - m * R);
+    bf16_t* o = t + m * ldt + r;
+    o[0] = f2bf(alpha * a0); o[1] = f2bf(alpha * a1); o[2] = f2bf(alpha * a2); o[3] = f2bf(alpha * a3);
 }
 
 struct LoraUpArgs {
@@ -218,20 +242,56 @@ static DropCfg make_cfg(float p, unsigned s0, unsigned s1, unsigned s2, unsigned
     return d;
 }
 
+static int lora_down_launch(const void* x, long ldx, const void* A, long lda, void* t, long ldt, int M, int K, int R, float alpha, float p,
+                            unsigned s0, unsigned s1, unsigned s2, unsigned s3, int nb_live, float* part, int ksplit, void* stream);
+
 extern "C" int bra_lora_down_drop(const void* x, long ldx, const void* A, long lda, void* t, long ldt, int M, int K, int R,
                                   float alpha, float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, int nb_live, void* stream) {
+    return lora_down_launch(x, ldx, A, lda, t, ldt, M, K, R, alpha, p, s0, s1, s2, s3, nb_live, nullptr, 1, stream);
+}
+
+extern "C" int bra_lora_down_splitk_plan(int M, int K) {
+    // workgroups per row block so that the grid reaches ~2 per CU while every workgroup keeps >= 3 K steps (its prologue is one step)
+    const int gx = (M + 31) / 32, nstep = (K + 127) / 128;
+    if (gx <= 0 || gx >= 192 || nstep < 6) return 1;
+    int want = 512 / gx, cap = nstep / 3;
+    int ks = want < cap ? want : cap;
+    if (ks < 2) return 1;
+    const int per = (nstep + ks - 1) / ks;
+    return (nstep + per - 1) / per;
+}
+
+extern "C" int bra_lora_down_drop_splitk(const void* x, long ldx, const void* A, long lda, void* t, long ldt, int M, int K, int R,
+                                         float alpha, float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, int nb_live,
+                                         float* part, int ksplit, void* stream) {
+    if (ksplit <= 1) return lora_down_launch(x, ldx, A, lda, t, ldt, M, K, R, alpha, p, s0, s1, s2, s3, nb_live, nullptr, 1, stream);
+    if (!part || ksplit > (K + 127) / 128 || ldt % 4) return BRA_ERR_ARG;
+    return lora_down_launch(x, ldx, A, lda, t, ldt, M, K, R, alpha, p, s0, s1, s2, s3, nb_live, part, ksplit, stream);
+}
+
+static int lora_down_launch(const void* x, long ldx, const void* A, long lda, void* t, long ldt, int M, int K, int R, float alpha, float p,
+                            unsigned s0, unsigned s1, unsigned s2, unsigned s3, int nb_live, float* part, int ksplit, void* stream) {
     if (M == 0) return 0;
     if (!x || !A || !t || M < 0 || K <= 0 || K % 8 || ldx % 8 || lda % 8 || (R != 32 && R != 64 && R != 128)) return BRA_ERR_ARG;
     if (!(p >= 0.f && p < 1.f) || (long)M * K >= (1l << 32)) return BRA_ERR_ARG;
     if (nb_live <= 0 || nb_live > R / 32) nb_live = R / 32;
-    LoraDownArgs g = {(const bf16_t*)x, ldx, (const bf16_t*)A, lda, (bf16_t*)t, ldt, M, K, R, alpha, make_cfg(p, s0, s1, s2, s3), nb_live};
-    const dim3 grid((M + 31) / 32);
+    const int nstep = (K + 127) / 128;
+    const int per = part ? (nstep + ksplit - 1) / ksplit : nstep;
+    const int ny = part ? (nstep + per - 1) / per : 1;                 // no empty workgroup
+    LoraDownArgs g = {(const bf16_t*)x, ldx, (const bf16_t*)A, lda, (bf16_t*)t, ldt, M, K, R, alpha, make_cfg(p, s0, s1, s2, s3), nb_live,
+                      per, part};
+    const dim3 grid((M + 31) / 32, ny);
     bra_stream_t st = (bra_stream_t)stream;
 #define BRA_LD(RB_, NL_) BRA_LAUNCH((lora_down_drop_kernel<RB_, NL_>), grid, dim3(256), 0, st, g)
     if (R == 32) BRA_LD(1, 1);
     else if (R == 64) { if (nb_live == 1) BRA_LD(2, 1); else BRA_LD(2, 2); }
     else { if (nb_live == 3) BRA_LD(4, 3); else if (nb_live == 4) BRA_LD(4, 4); else { g.nb_live = 4; BRA_LD(4, 4); } }
 #undef BRA_LD
+    if (part) {
+        const long MR = (long)M * R;
+        BRA_LAUNCH(lora_partial_reduce_kernel, dim3((unsigned)((MR / 4 + 255) / 256)), dim3(256), 0, st, (const float*)part, ny, MR, R, alpha,
+                   (bf16_t*)t, ldt);
+    }
     return BRA_LAUNCH_STATUS();
 }
 

@@ -6,6 +6,7 @@ kernel from ``libbioreason_hip.so``.  No function here falls back to torch math.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -166,13 +167,23 @@ def dropout_mask(M: int, K: int, p: float, seed: int, device) -> torch.Tensor:
     return out
 
 
+LORA_DOWN_SPLITK = os.environ.get("BRA_LORA_SPLITK", "1") != "0"
+
+
 def lora_down_drop(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, seeds) -> torch.Tensor:
     """t [M, R] = alpha * dropout_j(x) A^T with one mask stream per 32 rows of A (PEFT: per target module)"""
     M, K = x.shape
     R = A.shape[0]
     t = torch.empty((M, R), dtype=BF16, device=x.device)
-    get_lib().call("bra_lora_down_drop", x, _ld(x), A, _ld(A), t, _ld(t), M, K, R, alpha, p, *_seeds4(seeds), min(len(seeds), 4),
-                   current_stream(x))
+    lib = get_lib()
+    ks = int(lib._dll.bra_lora_down_splitk_plan(int(M), int(K))) if LORA_DOWN_SPLITK else 1
+    if ks > 1:
+        part = torch.empty((ks, M, R), dtype=torch.float32, device=x.device)
+        lib.call("bra_lora_down_drop_splitk", x, _ld(x), A, _ld(A), t, _ld(t), M, K, R, alpha, p, *_seeds4(seeds), min(len(seeds), 4),
+                 part, ks, current_stream(x))
+        return t
+    lib.call("bra_lora_down_drop", x, _ld(x), A, _ld(A), t, _ld(t), M, K, R, alpha, p, *_seeds4(seeds), min(len(seeds), 4),
+             current_stream(x))
     return t
 
 

@@ -81,6 +81,14 @@ int bra_wgrad_tn(const void* Y, long ldy, const void* T, long ldt, float* C, lon
  * columns, and the padding blocks (zero rows of A, zero columns of dts) are skipped instead of masked. */
 int bra_lora_down_drop(const void* x, long ldx, const void* A, long lda, void* t, long ldt, int M, int K, int R, float alpha,
                        float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, int nb_live, void* stream);
+/* Split-K form of bra_lora_down_drop for small M (M / 32 row-block workgroups cannot fill 256 CUs and each would read all of A):
+ * `ksplit` workgroups per row block take K / ksplit each, fp32 partial tiles go to `part` ([ksplit, M, R] floats, caller-provided)
+ * and a second launch sums them in a FIXED order (deterministic) and scales / rounds once.  bra_lora_down_splitk_plan(M, K) returns
+ * the split the host layer uses (1 = use the plain form). */
+int bra_lora_down_splitk_plan(int M, int K);
+int bra_lora_down_drop_splitk(const void* x, long ldx, const void* A, long lda, void* t, long ldt, int M, int K, int R, float alpha,
+                              float p, unsigned s0, unsigned s1, unsigned s2, unsigned s3, int nb_live, float* part, int ksplit,
+                              void* stream);
 int bra_lora_up_drop(const void* dts, long ldd, const void* AT, long ldat, void* out, long ldo, int M, int K, int R, float p,
                      unsigned s0, unsigned s1, unsigned s2, unsigned s3, int nb_live, void* stream);
 int bra_wgrad_tn_drop(const void* Y, long ldy, const void* T, long ldt, float* C, long c_sn, long c_sr, int M, int N, int R,

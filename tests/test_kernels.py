@@ -752,6 +752,34 @@ def test_lora_dropout_kernels(backend, M, K, R):
     assert rel(t0, (0.5 * x.float() @ A.float().T).to(BF)) < 4e-3
 
 
+@pytest.mark.parametrize("M,K,R,nlive", [(100, 768, 64, 2), (70, 1024, 128, 3), (33, 896, 32, 1), (40, 6144, 64, 1)])
+def test_lora_down_drop_split_k(backend, M, K, R, nlive):
+    """small M: `ksplit` workgroups per 32-row block take K / ksplit each, a second launch sums the fp32 partial tiles in a fixed order
+    (bra_lora_down_drop_splitk) — same masks (the hash is of the element index), same result up to the fp32 summation order,
+    deterministic from call to call"""
+    from bioreason_amd._lib import get_lib
+    p, seeds = 0.25, [11, 22, 33, 44][:nlive]
+    assert get_lib()._dll.bra_lora_down_splitk_plan(M, K) >= 2 and get_lib()._dll.bra_lora_down_splitk_plan(19488, K) == 1
+    x, A = rnd(M, K, dev=backend), rnd(R, K, dev=backend, scale=K ** -0.5)
+    A[32 * nlive:] = 0
+    masks = [ops.dropout_mask(M, K, p, seeds[j], backend).float().cpu() for j in range(nlive)]
+    xd = [(x.float().cpu() * mk / (1 - p)).to(BF).float() for mk in masks]
+    want = torch.zeros(M, R)
+    for j in range(nlive):
+        want[:, 32 * j:32 * j + 32] = 0.5 * xd[j] @ A.float().cpu()[32 * j:32 * j + 32].T
+    old = ops.LORA_DOWN_SPLITK
+    try:
+        ops.LORA_DOWN_SPLITK = True
+        t1 = ops.lora_down_drop(x, A, 0.5, p, seeds)
+        t2 = ops.lora_down_drop(x, A, 0.5, p, seeds)
+        ops.LORA_DOWN_SPLITK = False
+        t0 = ops.lora_down_drop(x, A, 0.5, p, seeds)
+    finally:
+        ops.LORA_DOWN_SPLITK = old
+    assert torch.equal(t1.cpu(), t2.cpu())
+    assert rel(t1, want.to(BF)) < 4e-3 and rel(t1, t0) < 4e-3 and (t1[:, 32 * nlive:] == 0).all()
+
+
 # ----------------------------------------------------------------------------- one-launch shared-prefix decode attention
 def _rope_rows_ref(x, cos, sin):
     """rotate-half RoPE (TF:qwen3:109-133) of x [..., hd] with cos / sin [..., hd/2] rows"""
@@ -980,3 +1008,21 @@ def test_lora_dropout_kernels_at_bench_shapes(hip_device, K, R, nlive, what):
     for j in range(nlive):
         want_dA[32 * j:32 * j + 32] = dts.float()[:, 32 * j:32 * j + 32].T @ xd[j]
     assert rel(dA, want_dA) < 2e-4 and (dA[32 * nlive:] == 0).all(), what       # fp32 atomics over 19 488 rows: summation order
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,R,nlive", [(2180, 2048, 128, 3), (2048, 6144, 64, 1), (2180, 2048, 64, 2)])
+def test_lora_down_drop_split_k_at_bench_shapes(hip_device, M, K, R, nlive):
+    """the split-K form at the shapes of the shared-prompt passes (one prompt = 2180 rows, eight completions = 2048 rows)"""
+    dev, p = hip_device, 0.05
+    seeds = [101, 202, 303][:nlive]
+    x, A = rnd(M, K, dev=dev, seed=1), rnd(R, K, dev=dev, scale=K ** -0.5, seed=2)
+    A[32 * nlive:] = 0
+    want = torch.zeros(M, R, device=dev)
+    for j in range(nlive):
+        mk = ops.dropout_mask(M, K, p, seeds[j], dev).float()
+        want[:, 32 * j:32 * j + 32] = 2.0 * (x.float() * mk / (1 - p)).to(BF).float() @ A.float()[32 * j:32 * j + 32].T
+    assert ops.LORA_DOWN_SPLITK
+    t = ops.lora_down_drop(x, A, 2.0, p, seeds)
+    assert rel(t, want.to(BF)) < 4e-3 and (t[:, 32 * nlive:] == 0).all()
+    assert torch.equal(t, ops.lora_down_drop(x, A, 2.0, p, seeds))

@@ -26,3 +26,5 @@ ms = timeit(lambda: ops.attn_fwd(q, k, vt, kmask, True, scale))
 print("fwd ms %.3f  TFLOP/s %.1f" % (ms, fl_fwd / ms / 1e9), flush=True)
 ms = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, kmask, True, scale))
 print("bwd (delta + 3 transposes + dq + dkv) ms %.3f  TFLOP/s (2.5x fwd flops) %.1f" % (ms, 2.5 * fl_fwd / ms / 1e9), flush=True)
+dq, dk, dv = ops.attn_bwd(q, k, v, o, do, lse, kmask, True, scale)
+print("checksums dq %.6e dk %.6e dv %.6e" % (dq.float().abs().sum().item(), dk.float().abs().sum().item(), dv.float().abs().sum().item()))
