@@ -527,7 +527,7 @@ def main():
     model = build_model(dims, dev, args.lora_dropout)
     R = args.prompts_per_gpu
     Cn = args.completion_len if args.completion_len is not None else dims.c
-    nsteps = args.warmup + args.steps + 1
+    nsteps = args.warmup + args.steps + 2
     if args.mode == "sft":
         runner, step, samples_per_step = make_sft_leg(model, dims, R, rank, dev)
     else:
@@ -548,6 +548,21 @@ def main():
     ops.GEMM_PROFILE = None
     # phase breakdown (one extra, untimed, instrumented step)
     step(args.warmup + args.steps, timing=True)
+    # the same GEMM family with the chains of the step issued on ONE stream (one more untimed step): in the timed steps the reference
+    # pass and the two chains of the policy pass run concurrently, so a HIP-event pair around a launch also spans time in which the
+    # kernel shares the chip (or waits for a CU) — this figure is the per-kernel one that a rocprof trace of a serial run would give
+    prof_serial = None
+    cfg_ = getattr(runner, "cfg", None)
+    if dev.type == "cuda" and args.mode == "grpo" and cfg_ is not None and hasattr(cfg_, "overlap_policy_chains"):
+        keep = (cfg_.overlap_policy_chains, cfg_.overlap_ref_pass)
+        cfg_.overlap_policy_chains = cfg_.overlap_ref_pass = False
+        try:
+            ops.GEMM_PROFILE = ops.GemmProfile(dominant_only=True)
+            step(args.warmup + args.steps + 1)
+            prof_serial = ops.GEMM_PROFILE.summary()
+        finally:
+            ops.GEMM_PROFILE = None
+            cfg_.overlap_policy_chains, cfg_.overlap_ref_pass = keep
     loss = float(out["loss_t"].item())
     headline_timers = dict(runner.timers)
     headline_rollout = dict(getattr(runner, "rollout_profile", {}))
@@ -634,6 +649,12 @@ def main():
                                 "(tests/test_fullsize_parity.py, tests/test_model_parity.py); north_star's 1e-3 rel is below one bf16 "
                                 "rounding (4e-3) and is met only by the log-probs",
         }
+        if prof_serial is not None and prof_serial["launches"]:
+            line["roofline_mfma"]["one_stream"] = {
+                "achieved": prof_serial["tflops"], "frac": prof_serial["tflops"] / PEAK_BF16_TFLOPS, "launches": prof_serial["launches"],
+                "avg_launch_ms": prof_serial["avg_launch_ms"],
+                "note": "the same launches in one extra untimed step with every chain on one stream (no concurrent kernels inside the "
+                        "event pairs); `achieved` above is measured inside the timed steps, where three chains share the chip"}
         if dims.dry:
             line["dryrun"] = True
         # `roofline` = the kernel family that is dominant BY TIME in the step: the rollout's token loop in a GRPO step (HBM-bound weight
