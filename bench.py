@@ -469,6 +469,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", choices=["grpo", "sft"], default="grpo")
+    ap.add_argument("--no-one-stream-profile", action="store_true", help="skip the extra untimed step that profiles the GEMM family with every chain on one stream")
     ap.add_argument("--prompts-per-gpu", type=int, default=1, help="distinct prompts per GPU (x G=8 rollouts each); headline = 1")
     ap.add_argument("--eos-uniform", type=int, nargs=2, metavar=("LO", "HI"), default=None,
                     help="straggler run (SURVEY §8d): every rollout ends at a length drawn from U[LO, HI]")
@@ -553,7 +554,7 @@ def main():
     # kernel shares the chip (or waits for a CU) — this figure is the per-kernel one that a rocprof trace of a serial run would give
     prof_serial = None
     cfg_ = getattr(runner, "cfg", None)
-    if dev.type == "cuda" and args.mode == "grpo" and cfg_ is not None and hasattr(cfg_, "overlap_policy_chains"):
+    if dev.type == "cuda" and args.mode == "grpo" and cfg_ is not None and hasattr(cfg_, "overlap_policy_chains") and not args.no_one_stream_profile:
         keep = (cfg_.overlap_policy_chains, cfg_.overlap_ref_pass)
         cfg_.overlap_policy_chains = cfg_.overlap_ref_pass = False
         try:
