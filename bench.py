@@ -158,10 +158,11 @@ def cpu_model_name():
 
 
 def cpu_baseline(mode: str = "grpo"):
-    """The oracle on the host cores, bounded: ONE sample of the workload at full model size, bf16, sdpa, all cores
-    (<= 64 threads), 1 warm-up pass + 3 timed passes of every leg, medians reported.
-    GRPO: encoder fwd (2 x 1024) + prefill P=2180 + decode steps (median per-step time of 16 steps, x255) +
-    reference log-probs forward + policy forward/backward over P+C.  SFT: forward + backward of one sample."""
+    """The oracle on the host cores, bounded: ONE sample of the workload at full model size, all cores (<= 64 threads), sdpa.
+    GRPO, bf16 (the reference's dtype): encoder fwd (2 x 1024) + prefill P=2180 [1 warm-up + 1 timed pass] + decode steps (median
+    per-step time of 12 steps timed inside one generate call, x255) + reference log-probs forward [1 pass] + policy forward/backward
+    over P+C [1 pass]; then the same sample in fp32, one pass per leg (SURVEY §8d asks for both).  About 80 s of host time per dtype:
+    the token loop is extrapolated from its per-step median, never run in full.  SFT: forward + backward of one sample."""
     import torch
     from oracle import dna_llm_oracle as O
     from oracle import grpo_math as GM
@@ -234,9 +235,10 @@ def cpu_baseline(mode: str = "grpo"):
     def roll(n):
         return lambda: model.generate(input_ids=b["input_ids"], attention_mask=b["attention_mask"], **mm, max_new_tokens=n, **gen_kw)
 
-    def measure(timer, NS):
+    def measure(timer, NS, timer_rest=None):
         """one sample of the cfg-3 workload, leg by leg; `timer(fn, n)` -> (seconds, passes)"""
-        t_r1, n1 = timer(roll(1), 3)               # encoder + prefill + first draw
+        timer_rest = timer_rest or timer
+        t_r1, n1 = timer(roll(1), 1)               # encoder + prefill + first draw
         # decode steps: timed INSIDE one generate call (every call of the text model after the prefill is one token step) — the
         # difference of two whole-rollout timings is the difference of two noisy 10-second numbers and came out anywhere between
         # 0 and 1.3 s per step on a shared host
@@ -250,15 +252,18 @@ def cpu_baseline(mode: str = "grpo"):
         per_step = gaps[len(gaps) // 2] if gaps else 0.0
         t_rollout = t_r1 + per_step * (C - 1)
 
+        kept = {}
+
         def ref_pass():
             O.set_adapters(text, False)
             with torch.no_grad():
                 out = GM.per_token_logps(model, ids, mask, **mm)[:, -C:]
             O.set_adapters(text, True)
+            kept["ref"] = out
             return out
 
-        t_ref, n_ref = timer(ref_pass, 2)
-        ref_lp = ref_pass()
+        t_ref, n_ref = timer_rest(ref_pass, 1)
+        ref_lp = kept["ref"]
 
         def pol_pass():
             for p in model.parameters():
@@ -267,16 +272,23 @@ def cpu_baseline(mode: str = "grpo"):
             loss, _, _ = GM.grpo_loss(lp.float(), None, ref_lp.float(), torch.ones(1), torch.ones(1, C), 0.2, 0.2, 0.04)
             loss.backward()
 
-        t_pol, n_pol = timer(pol_pass, 2)
+        t_pol, n_pol = timer_rest(pol_pass, 1)
         total = t_rollout + t_ref + t_pol
         return total, (f"rollout {t_rollout:.1f}s (encoder + prefill {t_r1:.1f}s [{n1} runs] + {per_step * 1e3:.0f} ms/decode step, "
                        f"median of {len(gaps)} steps timed inside one generate call, x {C - 1}), ref logps {t_ref:.1f}s [{n_ref}], "
                        f"policy fwd+bwd {t_pol:.1f}s [{n_pol}]")
 
-    total, desc = measure(med, 16)
+    def once(fn, n):
+        t0 = time.time()
+        fn()
+        return time.time() - t0, 1
+
+    t16 = time.time()
+    total, desc = measure(med, 12, once)
     res = dict(common, value=1.0 / total, dtype="bf16",
                sample=f"1 sample of the cfg-3 workload at full model size (bf16 — the reference's dtype, grpo_trainer.py:221 — sdpa), "
-                      f"medians after 1 warm-up: {desc}; model build {build_s:.0f}s not counted")
+                      f"prefill after 1 warm-up pass, the other legs one pass each: {desc} (measured in {time.time() - t16:.0f}s); "
+                      f"model build {build_s:.0f}s not counted")
     # fp32 leg (SURVEY §8d asks for both): the same sample with the modules in fp32, ONE cold pass per leg (no warm-up, no median:
     # the leg is bounded to about a minute of host time), skipped when the bf16 leg already used up the budget
     fp32_budget = float(os.environ.get("BENCH_CPU_FP32_BUDGET", "150"))
@@ -284,11 +296,6 @@ def cpu_baseline(mode: str = "grpo"):
         try:
             model.float()
             t32 = time.time()
-
-            def once(fn, n):
-                t0 = time.time()
-                fn()
-                return time.time() - t0, 1
 
             total32, desc32 = measure(once, 4)
             res["fp32"] = {"value": 1.0 / total32, "unit": "samples/s", "cores": ncores,
