@@ -308,23 +308,29 @@ def cpu_baseline(mode: str = "grpo"):
 
 
 # ---------------------------------------------------------------------------------------------- GPU legs
-def decode_roofline(model, rollout_profile, Cn, n_prompts, P):
+def decode_roofline(model, rollout_profile, Cn, n_prompts, P, loop_ev=None):
     """HBM roofline of the rollout's token loop (the largest phase of the step by time; every kernel in it is a weight / KV
     stream): algorithmic bytes of one decode step = merged bf16 projection weights + tied lm_head + the K/V rows the
     step attends to (prompt rows once per prompt, completion rows per sequence, averaged over the C steps), divided by
-    the measured time per step (host-synchronised wall time of the token loop in the instrumented step)."""
+    the measured time per token step: HIP events on the launch stream around the token loop of every rollout of the TIMED steps
+    (`loop_ev`); the host-synchronised wall time of the loop in the instrumented step is kept beside it as a cross-check."""
     e = model.text_model.engine
     w_bytes = 2 * (e.L * ((e.Nq + 2 * e.Nkv) * e.H + e.H * e.Nq + 3 * e.F * e.H) + e.V * e.H)
     kv_bytes = e.L * 2 * e.Nkv * 2 * (n_prompts * P + n_prompts * G * (Cn / 2.0))
     ms = rollout_profile.get("decode_loop")
     steps = rollout_profile.get("decode_steps", Cn - 1)
+    ms_instr = (ms / steps) if (ms and steps >= 2) else None
+    timing = "host-synchronised wall time of the token loop in the instrumented step"
+    if loop_ev is not None:
+        ms, steps = loop_ev["ms"], loop_ev["steps"]
+        timing = "HIP events on the launch stream around the token loop, mean over the %d rollouts of the timed steps" % loop_ev["rollouts"]
     if not ms or steps < 2:
         return None
     per_step_ms = ms / steps
     ach = (w_bytes + kv_bytes) / (per_step_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
             "traffic": None, "bytes_per_step": w_bytes + kv_bytes, "ms_per_token_step": per_step_ms,
-            "share_of_step_ms": ms,
+            "share_of_step_ms": ms, "timing": timing, "ms_per_token_step_instrumented": ms_instr,
             "kernel": "token loop of the rollout: dec_gemm2_kernel (qkv / o / gate-up+SwiGLU / down / lm_head, weight streaming at "
                       "M = 8) + dec_attn_items / dec_attn_merge + sampler; per-kernel durations: profiles/*_bench_kernel_stats.csv"}
 
@@ -549,11 +555,22 @@ def main():
         gc.freeze()
         if dev.type == "cuda":
             ops.GEMM_PROFILE = ops.GemmProfile(dominant_only=True)
+            if hasattr(runner, "loop_events"):
+                runner.loop_events = []          # generate() appends a HIP-event pair around its token loop: the timed steps only
 
     elapsed, out = timed_steps(step, args.steps, args.warmup, world, dev, before_timed=before_timed)
     prof = ops.GEMM_PROFILE.summary() if ops.GEMM_PROFILE is not None else {
         "tflops": 0.0, "flops_per_launch": 0.0, "bytes_per_launch": 0.0, "launches": 0, "avg_launch_ms": 0.0}
     ops.GEMM_PROFILE = None
+    loop_ev = None
+    if getattr(runner, "loop_events", None):
+        torch.cuda.synchronize()
+        ms_l = [a.elapsed_time(b) for a, b, _ in runner.loop_events]
+        st_l = [n for _, _, n in runner.loop_events]
+        if ms_l and min(st_l) >= 2:
+            loop_ev = {"ms": sum(ms_l) / len(ms_l), "steps": sum(st_l) / len(st_l), "rollouts": len(ms_l)}
+    if hasattr(runner, "loop_events"):
+        runner.loop_events = None
     # phase breakdown (one extra, untimed, instrumented step)
     step(args.warmup + args.steps, timing=True)
     # the same GEMM family with the chains of the step issued on ONE stream (one more untimed step): in the timed steps the reference
@@ -669,7 +686,7 @@ def main():
         # streaming: 60-70 % of the step), the MFMA GEMM family in an SFT step; the other family keeps its own key
         line["roofline"] = line["roofline_mfma"]
         if args.mode == "grpo":
-            dec = decode_roofline(model, headline_rollout, Cn, R, dims.P)
+            dec = decode_roofline(model, headline_rollout, Cn, R, dims.P, loop_ev)
             if dec is not None and headline_default and not dims.dry:
                 dec["traffic"] = pmc_decode_traffic()
                 dec["decode_source_sha"] = decode_source_sha()

@@ -361,7 +361,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
              check_every: int = 16, return_full_length: bool = False,
              force_tokens: Optional[torch.Tensor] = None, native_step: bool = True,
              decode_impl: str = "fused", prompt_alias=None, use_graph: Optional[bool] = None,
-             shared_prefix_decode: bool = True, profile: Optional[dict] = None,
+             shared_prefix_decode: bool = True, profile: Optional[dict] = None, loop_events: Optional[list] = None,
              eos_schedule: Optional[torch.Tensor] = None, trace_logits: Optional[list] = None) -> torch.Tensor:
     """`force_tokens` [B, max_new_tokens] (optional): teacher forcing — the model's own choice is still recorded
     in the output, but the given token is fed back (used to compare decodes position by position).
@@ -481,6 +481,12 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         rope_args = (shared.cosT, shared.sinT, eng.hd, shared.rope_rows)
         ops.rope_rows(shared.cosT, shared.sinT, next_pos, eng.hd, shared.rope_rows)
     _tick("decode_setup")
+    # `loop_events` (measurement): a HIP-event pair on the launch stream around the token loop of THIS call is appended — bench.py
+    # times the loop inside its timed steps with it (no host synchronisation, unlike `profile`)
+    ev_loop = None
+    if loop_events is not None and dev.type == "cuda":
+        ev_loop = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev_loop[0].record()
     last = max_new_tokens - 1                 # index of the final draw (no decode step follows it)
     t = 0
     alive = True                              # False once every row has emitted EOS
@@ -560,6 +566,9 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         alive = eager_steps(last - t)
     if alive:
         sample_()
+    if ev_loop is not None:
+        ev_loop[1].record()
+        loop_events.append((ev_loop[0], ev_loop[1], (max_new_tokens if alive else n_done) - 1))
     _tick("decode_loop")
     if shared is not None and shared.persist is not None and shared.persist["ok"] and shared.persist_timed_out():
         raise RuntimeError("bioreason_amd: a grid barrier of the persistent decode step timed out (GridSync::err set); the rollout is "

@@ -204,6 +204,7 @@ class GRPOStepRunner(_DataParallelStep):
         if hasattr(model.text_model, "set_dropout_seed"):          # every rank draws its own LoRA dropout masks, as separate
             model.text_model.set_dropout_seed(cfg.seed * 1000003 + self.rank)   # processes with their own RNG streams do
         self.rollout_profile: Dict[str, float] = {}      # filled by step(timing=True): phases inside generate(), ms
+        self.loop_events: Optional[list] = None          # a list: generate() appends (start, end, token steps) HIP events of its token loop
         # optimiser step index -> learning rate (HF Trainer.create_scheduler, set by DNALLMGRPOTrainer); None = constant cfg.learning_rate
         self.lr_schedule: Optional[Callable[[int], float]] = None
         self.last_lr = cfg.learning_rate
@@ -237,7 +238,7 @@ class GRPOStepRunner(_DataParallelStep):
                                     seed=c.seed + 1000003 * self.step_idx + self.rank, return_full_length=sched is None,
                                     prompt_alias=batch.get("prompt_alias"), use_graph=c.rollout_graph,
                                     shared_prefix_decode=c.rollout_shared_prefix, eos_schedule=sched,
-                                    profile=self.rollout_profile if timing else None)
+                                    profile=self.rollout_profile if timing else None, loop_events=self.loop_events)
         self.step_idx += 1
         mark("rollout")
         if c.eos_token_id is not None:
