@@ -25,8 +25,15 @@ __global__ __launch_bounds__(64) void dec_attn_items_kernel(DecOneArgs a) {
     dec_attn_item<HD, G, 0>(a, (int)blockIdx.x);           // dispatch order = workgroup id
 }
 
+// the merge reads nine fields of the record: all of them lead the argument list (14 dwords, delivered in SGPRs with the wave:
+// kernel-argument preload, -mllvm -amdgpu-kernarg-preload-count) — nothing is fetched from the argument segment, which the host
+// has just written, before the requests go out (-0.4 us per launch).  The items kernel needs nine pointers before its first
+// request: they do not fit, it keeps the record.
 template <int HD>
-__global__ __launch_bounds__(64) void dec_attn_merge_kernel(DecOneArgs a) {
+__global__ __launch_bounds__(64) void dec_attn_merge_kernel(float* m_part_ml, float* m_part_o, bf16_t* m_o, int m_ldo, int m_Hq, int m_nslot,
+                                                            int m_npc, int m_t, const int* m_t_ptr, DecOneArgs a0) {
+    DecOneArgs a = a0;
+    a.part_ml = m_part_ml; a.part_o = m_part_o; a.o = m_o; a.ldo = m_ldo; a.Hq = m_Hq; a.nslot = m_nslot; a.npc = m_npc; a.t = m_t; a.t_ptr = m_t_ptr;
     dec_attn_merge_one<HD, 0>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -63,7 +70,8 @@ extern "C" int bra_dec_attn_one(const void* qkv, long ldqkv, const void* qw, con
 #define BRA_DO(HD_, G_)                                                                                   \
     if (hd == HD_ && G == G_) {                                                                           \
         BRA_LAUNCH((dec_attn_items_kernel<HD_, G_>), dim3(nitems), dim3(64), 0, st, a);                   \
-        BRA_LAUNCH((dec_attn_merge_kernel<HD_>), dim3(Hq, R * copies), dim3(64), 0, st, a);               \
+        BRA_LAUNCH((dec_attn_merge_kernel<HD_>), dim3(Hq, R * copies), dim3(64), 0, st, a.part_ml, a.part_o, a.o, (int)a.ldo, a.Hq,   \
+                   a.nslot, a.npc, a.t, a.t_ptr, a);                                                      \
         return BRA_LAUNCH_STATUS();                                                                       \
     }
     BRA_DO(128, 1) BRA_DO(128, 2) BRA_DO(128, 4) BRA_DO(64, 1) BRA_DO(64, 2) BRA_DO(64, 4)

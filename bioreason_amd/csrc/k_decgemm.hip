@@ -29,8 +29,17 @@ namespace bra {
 // zeroed), every offset fits 32 bits (host-checked), no probe stamps.  With two waves per SIMD each prologue instruction costs
 // ~8 cycles of the launch's critical path, so the path to the first request is kept to: kernel arguments, one 24-bit multiply
 // per base, scalar base + 32-bit lane offset + immediate per request.
+#define BRA_DG2_HEAD_PARAMS const bf16_t* h_x, const bf16_t* h_W, const bf16_t* h_res, const float* h_ss_in, int h_ldx, int h_ldres, int h_M, int h_N, \
+                            int h_K, int h_nss_in
+#define BRA_DG2_HEAD_ARGS(g) (g).x, (g).W, (g).res, (g).ss_in, (int)(g).ldx, (int)(g).ldres, (g).M, (g).N, (g).K, (g).nss_in
 template <int MODE, int NORM, int ACT, int OUTF32, int NW, int NL, int WIDE = 0, int PK = 0, int FAST = 0>
-__global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(DecGemm2Args g) {
+__global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(BRA_DG2_HEAD_PARAMS, DecGemm2Args g0) {
+    // everything between kernel entry and the first weight / activation request arrives in SGPRs with the wave (kernel-argument
+    // preload, -mllvm -amdgpu-kernarg-preload-count: the leading 14 dwords); the rest of the record is fetched from the argument
+    // segment while the requests are in flight (a scalar load of the arguments is one memory round trip that every wave of a
+    // 5 - 10 us launch otherwise waits for before it can form its first address)
+    DecGemm2Args g = g0;
+    g.x = h_x; g.W = h_W; g.res = h_res; g.ss_in = h_ss_in; g.ldx = h_ldx; g.ldres = h_ldres; g.M = h_M; g.N = h_N; g.K = h_K; g.nss_in = h_nss_in;
     static_assert(!WIDE || (MODE == 0 && NORM != 1), "wide rows: 16-column tiles, statistics applied in the epilogue");
     static_assert(!FAST || (PK && NORM != 1), "fast form: packed weights, folded norm or none");
     __shared__ float red[2][NW][64][4];
@@ -335,12 +344,12 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     do {                                                                                                                       \
         if constexpr (NORM != 1) {                                                                                             \
             if (fast) {                                                                                                        \
-                BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 1, 1>), grid, dim3(NW_ * 64), 0, st, g); \
+                BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 1, 1>), grid, dim3(NW_ * 64), 0, st, BRA_DG2_HEAD_ARGS(g), g); \
                 break;                                                                                                         \
             }                                                                                                                  \
         }                                                                                                                      \
-        if (g.packed & 1) BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 1>), grid, dim3(NW_ * 64), 0, st, g); \
-        else BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 0>), grid, dim3(NW_ * 64), 0, st, g);      \
+        if (g.packed & 1) BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 1>), grid, dim3(NW_ * 64), 0, st, BRA_DG2_HEAD_ARGS(g), g); \
+        else BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 0>), grid, dim3(NW_ * 64), 0, st, BRA_DG2_HEAD_ARGS(g), g);      \
     } while (0)
     if (nw == 16) {
         if constexpr (WIDE != 0) { if (nl == 12) BRA_DG2(16, 12); else if (nl == 8) BRA_DG2(16, 8); else BRA_DG2(16, 4); }

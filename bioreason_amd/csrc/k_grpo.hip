@@ -305,8 +305,9 @@ __global__ __launch_bounds__(64) void force_token_kernel(float* logits, long ldl
 // (one workgroup of up to 1024 threads: with 64 threads the n * hd row elements were 16 dependent position -> table round trips
 //  in series, 6.5 us per token for 4 KB)
 __global__ __launch_bounds__(1024) void advance_counters_kernel(int* pos, int n, int* a, int* b, const float* cosT, const float* sinT,
-                                                                int hd, float* rows) {
-    const int i = (int)threadIdx.x, nt = (int)blockDim.x;
+                                                                int hd, float* rows, int nt) {
+    const int i = (int)threadIdx.x;                // (nt = blockDim.x as an argument: blockDim lives in the implicit arguments, which are
+                                                   //  not among the preloaded dwords — reading it is a memory round trip at entry)
     if (rows) {                                   // one pass: every lane reads the positions it needs before anyone bumps them
         const int half = hd / 2;
         for (int e = i; e < n * hd; e += nt) {
@@ -473,7 +474,7 @@ extern "C" int bra_advance_counters(int* pos, int n, int* a, int* b, const float
     if (rope_rows && (!cosT || !sinT || hd <= 0 || hd % 2)) return BRA_ERR_ARG;
     const long ne = rope_rows ? (long)n * hd : 0;
     const int nt = ne <= 64 ? 64 : (ne >= 1024 ? 1024 : (int)((ne + 63) / 64 * 64));
-    BRA_LAUNCH(advance_counters_kernel, dim3(1), dim3(nt), 0, stream, pos, n, a, b, cosT, sinT, hd, rope_rows);
+    BRA_LAUNCH(advance_counters_kernel, dim3(1), dim3(nt), 0, stream, pos, n, a, b, cosT, sinT, hd, rope_rows, nt);
     return BRA_LAUNCH_STATUS();
 }
 

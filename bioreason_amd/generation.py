@@ -468,10 +468,12 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
                    cur, None, eos_id=eos, eos_id2=eos2, tokens_out=tokens, ws=sample_ws,
                    embed=(eng.E, dstate.x, dstate.ss_ws[0]) if fuse_embed else None)
 
-    def advance_(t_grid: int):
-        """one fused decode step; the kernels take the step index from step_t / len_t, `t_grid` only sizes grids"""
+    def advance_(t_grid: int, exact_t: bool = False):
+        """one fused decode step.  Under graph replay the kernels take the step index from step_t / len_t and `t_grid` only sizes
+        grids; issued launch by launch (`exact_t`: t_grid IS the step index) the shared-prefix step gets it as a launch argument —
+        the attention kernels then start without the dependent scalar load of the device-side counter"""
         if shared is not None:
-            shared.step(cur, next_pos, pmask, t_grid, logits, t_dev=step_t, embed_done=fuse_embed)
+            shared.step(cur, next_pos, pmask, t_grid, logits, t_dev=None if exact_t else step_t, embed_done=fuse_embed)
         else:
             state.step(cur, next_pos, kmask, P + t_grid, logits, len_dev=len_t, embed_done=fuse_embed)
         ops.advance_counters(next_pos, step_t, len_t, rope=rope_args)
@@ -507,7 +509,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             if force_tokens is not None:
                 cur.copy_(force_tokens[:, t].to(torch.int32))
             if fused:
-                advance_(t)
+                advance_(t, exact_t=True)
                 if trace_logits is not None:
                     trace_logits.append(logits.clone())
             else:
@@ -539,8 +541,17 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             host_s = _time.perf_counter() - h0
             e1.record()
             e1.synchronize()
-            want_graph = host_s > 0.8 * e0.elapsed_time(e1) * 1e-3
-            eng._rollout_use_graph = want_graph
+            vote = host_s > 0.8 * e0.elapsed_time(e1) * 1e-3
+            # one slow probe must not lock a whole run into replay (a capture per rollout costs ~90 ms at Qwen3-1.7B; a transient
+            # on the host — first-use set-up, a page-cache miss — was seen to inflate a single probe 4x): eager is settled by one
+            # vote, replay needs two consecutive ones; an undecided rollout continues launch by launch
+            if not vote:
+                eng._rollout_use_graph = False
+            else:
+                eng._rollout_graph_votes = getattr(eng, "_rollout_graph_votes", 0) + 1
+                if eng._rollout_graph_votes >= 2:
+                    eng._rollout_use_graph = True
+            want_graph = bool(getattr(eng, "_rollout_use_graph", False))
             eng._rollout_probe_ms = (host_s * 1e3 / 8, e0.elapsed_time(e1) / 8)      # host issue vs device time per step
             if profile is not None:
                 profile["auto_host_ms_per_step"] = host_s * 1e3 / 8
