@@ -70,6 +70,7 @@ class GRPOConfig:
     overlap_ref_pass: bool = True
     # the two row segments of the shared-prompt policy pass (prompt chain, completion chain) on two HIP streams, one event per layer
     overlap_policy_chains: bool = True
+    overlap_rollout_weights: bool = True     # merge + pack the rollout's weight set on a side stream beside the frozen DNA encoder
 
 
 def token_stat_rewards(completion_ids: torch.Tensor, completion_mask: torch.Tensor) -> torch.Tensor:
@@ -223,6 +224,17 @@ class GRPOStepRunner(_DataParallelStep):
         m, c = self.model, self.cfg
         dev = batch["input_ids"].device
         mm = {"dna_tokenized": batch["dna_tokenized"], "batch_idx_map": batch["batch_idx_map"], "dna_alias": batch.get("dna_alias")}
+        wside = None
+        if (c.overlap_rollout_weights and dev.type == "cuda" and not timing and c.rollout_shared_prefix
+                and batch.get("prompt_alias") is not None):
+            # the rollout's weight set (LoRA merged into the base weights, gate / up interleaved, fragment-packed: ~17 GB of HBM
+            # traffic, ~4 ms) depends on the parameters only: built on a side stream while the main stream runs the frozen encoder
+            # (an under-filled GEMM chain); generation.rollout_weights caches it by parameter version, so generate() finds it
+            from . import generation as _gen
+            wside = self._side_stream(dev, 2)
+            wside.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(wside):
+                _gen.rollout_weights(m.text_model, rows=int(batch["input_ids"].shape[0]))
         if c.share_dna_encoding and batch["dna_tokenized"] is not None and batch["batch_idx_map"]:
             # the frozen encoder (no_grad, dna_llm.py:121) once per distinct sequence and STEP: its rows feed the rollout, the
             # reference pass and the policy pass alike (the reference evaluates it three times to the same values); the
@@ -230,6 +242,8 @@ class GRPOStepRunner(_DataParallelStep):
             mm["dna_enc"] = m.encode_dna(batch["dna_tokenized"], batch.get("dna_alias"))
         prompt_ids, prompt_mask = batch["input_ids"], batch["attention_mask"]
         B = prompt_ids.shape[0]
+        if wside is not None:
+            torch.cuda.current_stream(dev).wait_stream(wside)
         sched = batch.get("eos_schedule")
         # rollout (unwrapped_model.generate, :579-596): only completion ids come back
         completion_ids = m.generate(input_ids=prompt_ids, attention_mask=prompt_mask, **mm,
