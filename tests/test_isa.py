@@ -1,0 +1,72 @@
+"""ISA-level regression guards for the token loop (no GPU: hipcc cross-compiles gfx950).  The kernels of the decode step are 5 - 10 us
+long; what sits between kernel entry and the first memory request is on their critical path (NOTES.md).  These tests read the
+cross-compiled assembly: the arguments the first requests need must arrive preloaded in SGPRs, and the fast projection kernels must
+issue their weight requests before they wait for anything fetched from the argument segment."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "bioreason_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _makefile_flags():
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    line = next(l for l in mk.splitlines() if l.startswith("HIPFLAGS :="))
+    flags = line.split(":=", 1)[1].replace("$(ARCH)", "gfx950").replace("$(EXTRA_HIPFLAGS)", "").split()
+    return [f for f in flags if f != "-I."]
+
+
+def _asm(src, tmp_path):
+    out = os.path.join(str(tmp_path), src + ".s")
+    subprocess.run([HIPCC, *_makefile_flags(), "-I", CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out], check=True,
+                   stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _kernels(asm):
+    """name -> (instruction lines after the compatibility header, preload length)"""
+    res = {}
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", asm, re.S | re.M):
+        body = [l.strip() for l in m.group(2).split("\n")]
+        body = [l for l in body if l and not l.startswith((";", ".", "_Z"))]
+        res[m.group(1)] = (body, int(m.group(3)))
+    return res
+
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) or shutil.which("c++filt") is None, reason="needs hipcc")
+
+
+def test_makefile_asks_for_kernarg_preload():
+    assert "-amdgpu-kernarg-preload-count=16" in " ".join(_makefile_flags())
+
+
+def test_decode_attention_merge_takes_its_arguments_preloaded(tmp_path):
+    ks = _kernels(_asm("k_decattn.hip", tmp_path))
+    merge = {n: v for n, v in ks.items() if "dec_attn_merge_kernel" in n}
+    assert merge
+    for n, (body, pre) in merge.items():
+        assert pre >= 13, (n, pre)
+        # behind the compatibility header (s_load ... s_branch) the kernel reads the argument segment at most for the optional
+        # device-side step counter: no s_load from s[0:1] (the segment pointer) before the first global load
+        start = next(i for i, l in enumerate(body) if l.startswith("s_branch")) + 1
+        first_ld = next(i for i, l in enumerate(body) if l.startswith("global_load"))
+        assert not [l for l in body[start:first_ld] if l.startswith("s_load") and "s[0:1]" in l], n
+
+
+def test_fast_decode_projections_request_weights_before_any_argument_fetch(tmp_path):
+    ks = _kernels(_asm("k_decgemm.hip", tmp_path))
+    # the FAST instantiations of the decode step: <MODE, NORM, ACT, OUTF32, NW, NL, WIDE = 0, PK = 1, FAST = 1>
+    fast = {n: v for n, v in ks.items() if re.search(r"dec_gemm2_kernelILi\dELi\dELi\dELi\dELi\d+ELi\d+ELi0ELi1ELi1E", n)}
+    assert len(fast) >= 8
+    for n, (body, pre) in fast.items():
+        assert pre >= 14, (n, pre)
+        start = next(i for i, l in enumerate(body) if l.startswith("s_branch")) + 1
+        first_ld = next(i for i, l in enumerate(body) if l.startswith("global_load"))
+        seg_loads = [i for i, l in enumerate(body[start:], start) if l.startswith("s_load") and "s[0:1]" in l]
+        assert first_ld - start <= 40, (n, first_ld - start)                 # first request within 40 instructions of entry
+        assert not seg_loads or seg_loads[0] > first_ld, n                   # ... and before anything is fetched from the segment
