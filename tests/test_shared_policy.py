@@ -229,6 +229,34 @@ def test_ref_pass_on_side_stream_equals_main_stream(hip_device):
 
 
 @pytest.mark.gpu
+def test_rollout_weights_on_side_stream_give_the_same_rollout(hip_device):
+    """GRPOConfig.overlap_rollout_weights: the merged / packed weight set of the rollout built on a side stream beside the DNA
+    encoder (twice in a row: the second build replaces the first set) — same sampled tokens, same reference log-probs as with the
+    set built on the main stream inside generate()"""
+    from bioreason_amd.trainer import GRPOConfig, GRPOStepRunner
+    dev = hip_device
+    fix = torch.load(os.path.join(GOLD, "tiny_a.pt"), weights_only=False)
+    ids, mask, mm, alias = _group_batch(fix, dev, 2)
+    batch = {"input_ids": ids, "attention_mask": mask, "dna_tokenized": mm["dna_tokenized"], "batch_idx_map": mm["batch_idx_map"],
+             "prompt_alias": alias}
+    outs = []
+    for overlap in (True, False):
+        m = build(fix, dev, True)
+        runner = GRPOStepRunner(m, GRPOConfig(num_generations=2, max_completion_length=6, eos_token_id=None, seed=3, learning_rate=1e-3,
+                                              overlap_rollout_weights=overlap, overlap_ref_pass=False))
+        got = []
+        for _ in range(2):                       # the second step rebuilds the set from the updated adapters
+            out = runner.step(batch)
+            inputs = runner._buffered_inputs[0]
+            got.append((inputs["completion_ids"].clone(), inputs["ref_per_token_logps"].clone(), out["loss_t"].clone()))
+        torch.cuda.synchronize()
+        outs.append(got)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(outs[0][0][2], outs[1][0][2])          # first step's loss: identical inputs, no atomics on the forward path
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,copies", [("tiny_a", 2), ("tiny_b", 3)])
 def test_two_stream_chains_equal_one_stream(hip_device, name, copies):
     """the prompt chain and the completion chain of the shared policy pass on two HIP streams (engine.forward_hidden_shared
