@@ -402,7 +402,8 @@ def make_grpo_leg(model, dims: Dims, R: int, Cn: int, rank: int, dev, args, eos_
                      share_policy_prompt=(not getattr(args, "no_shared_policy", False)) if share_policy is None else share_policy,
                      overlap_ref_pass=not getattr(args, "no_overlap_ref", False),
                      overlap_policy_chains=not getattr(args, "no_overlap_chains", False),
-                     overlap_rollout_weights=not getattr(args, "no_overlap_weights", False))
+                     overlap_rollout_weights=not getattr(args, "no_overlap_weights", False),
+                     overlap_ref_chains=bool(getattr(args, "overlap_ref_chains", False)))
     # the reference's reward hop runs inside the timed step: ids -> host -> decode -> the five python reward functions
     # reason.py:291-296 enables by default -> device (a synthetic id -> text table stands in for the tokenizer files)
     reward_names = ["xmlcount", "soft_format", "strict_format", "less_than_4", "correctness"]
@@ -492,6 +493,7 @@ def main():
     ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="issue the rollout's decode steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-shared-decode", action="store_true", help="per-copy prompt K/V in the decode attention")
+    ap.add_argument("--overlap-ref-chains", action="store_true", help="(experiment) the two chains of the reference pass on two streams as well")
     ap.add_argument("--no-overlap-weights", action="store_true", help="build the rollout's merged / packed weight set on the main stream (no overlap with the DNA encoder)")
     ap.add_argument("--no-overlap-chains", action="store_true", help="prompt and completion chains of the shared policy pass on one stream")
     ap.add_argument("--no-overlap-ref", action="store_true", help="reference-policy pass on the main stream instead of beside the policy forward")

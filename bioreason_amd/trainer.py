@@ -70,6 +70,7 @@ class GRPOConfig:
     overlap_ref_pass: bool = True
     # the two row segments of the shared-prompt policy pass (prompt chain, completion chain) on two HIP streams, one event per layer
     overlap_policy_chains: bool = True
+    overlap_ref_chains: bool = False         # prompt / completion chains of the reference pass on two streams as well (measured: see NOTES)
     overlap_rollout_weights: bool = True     # merge + pack the rollout's weight set on a side stream beside the frozen DNA encoder
 
 
@@ -271,9 +272,10 @@ class GRPOStepRunner(_DataParallelStep):
                 with torch.no_grad(), m.text_model.disable_adapter():
                     if batch.get("prompt_alias") is not None:
                         return grpo.per_token_logps_shared_prefix(m, prompt_ids, prompt_mask, completion_ids, cmask,
-                                                                  batch["prompt_alias"], **mm)
+                                                                  batch["prompt_alias"], side=ref_side2, **mm)
                     return grpo.per_token_logps(m, prompt_ids, prompt_mask, completion_ids, cmask, **mm)
             side = self._side_stream(dev) if (c.overlap_ref_pass and not timing) else None
+            ref_side2 = self._side_stream(dev, 3) if (side is not None and c.overlap_ref_chains) else None
             if side is not None:
                 # issued on the side stream behind everything issued so far; the caller joins (`ref_join`) before the loss reads it
                 side.wait_stream(torch.cuda.current_stream(dev))
