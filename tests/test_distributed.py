@@ -123,6 +123,52 @@ def test_grpo_step_two_ranks_shared_prompt_groups(emu_lib_path):
         assert abs(mets[3] - want_loss) < 1e-5 * max(1.0, abs(want_loss)) and ncuts >= 1
 
 
+def _single_rank_worker(port, emu_path, q, dp):
+    """one process; dp: a ONE-rank gloo group with BRA_DP_SINGLE_RANK=1 (every collective of the step issued, each the identity) — or no
+    process group at all"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BRA_EMU_THREADS="2")
+    torch.set_num_threads(1)
+    if dp:
+        os.environ["BRA_DP_SINGLE_RANK"] = "1"
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    from bioreason_amd import _lib
+    _lib.use_library_for_tests(emu_path)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_model_parity import build, to_dev
+    from bioreason_amd.trainer import GRPOConfig, GRPOStepRunner
+    fix = torch.load(os.path.join(GOLD, "tiny_a.pt"), weights_only=False)
+    m = build(fix, torch.device("cpu"), True)
+    b = to_dev(fix["batch"], torch.device("cpu"))
+    b.pop("labels")
+    runner = GRPOStepRunner(m, GRPOConfig(num_generations=2, max_completion_length=4, eos_token_id=None, seed=7, learning_rate=1e-3),
+                            lambda ids, mask: torch.stack([(ids[:, 0] % 5).float(), (ids[:, 1] % 3).float()], dim=1))
+    out = runner.step(b)
+    q.put((dp, bool(runner.dp), len(runner._cuts), m.arena.params.tolist(), out["metrics_t"].tolist()))
+    if dp:
+        dist.destroy_process_group()
+
+
+def test_single_rank_group_issues_the_collectives_and_changes_nothing(emu_lib_path):
+    """BRA_DP_SINGLE_RANK (the hardware rehearsal of the RCCL path on a 1-GPU box, tools/rccl_single_rank.sh): the data-parallel code
+    path — bucketed all-reduce from inside the backward, packed all-gather, metric slot — in a one-rank group gives the parameters
+    and the metric record of the plain single-process step (the SGD-free part is deterministic on the emulator)"""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for dp in (True, False):
+        q = ctx.Queue()
+        p = ctx.Process(target=_single_rank_worker, args=(35500 + (os.getpid() % 2000), emu_lib_path, q, dp))
+        p.start()
+        r = q.get(timeout=900)
+        p.join(timeout=60)
+        assert p.exitcode == 0
+        res[dp] = r
+    assert res[True][1] and res[True][2] >= 1 and not res[False][1]
+    plain = torch.tensor(res[False][3])
+    assert torch.allclose(torch.tensor(res[True][3])[: plain.numel()], plain, rtol=0, atol=1e-6)       # (the DP arena carries a 64-float metric slot at its end)
+    assert torch.allclose(torch.tensor(res[True][4]), torch.tensor(res[False][4]), atol=1e-5)
+
+
 def _sft_worker(rank, world, port, emu_path, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
