@@ -115,6 +115,16 @@ __device__ __forceinline__ void dg2_epilogue(const DecGemm2Args& g, float (&v)[4
             if (n + 3 < N && (g.ldo & 3) == 0) { f32x4 o = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(cp) = o; }
             else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = v[r];
         }
+        if (g.ss_out) {
+            // fp32 logits: `ss_out` [M][nss_out] receives the MAXIMUM of every 16-column tile instead of statistics — the sampler
+            // (k_grpo.hip: sample_tiles_kernel) finds the top-k tiles among V / 16 maxima and only then touches their logits
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = (live && n + r < N) ? fmaxf(mx, v[r]) : mx;
+            mx = fmaxf(mx, wave_shfl_xor(mx, 16));
+            mx = fmaxf(mx, wave_shfl_xor(mx, 32));
+            if (fq == 0 && m < g.M) g.ss_out[(long)m * g.nss_out + tile] = mx;
+        }
         return;
     }
     float ss = 0.f;

@@ -380,7 +380,7 @@ extern "C" int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, 
                                    int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* probe, void* stream) {
     if (M <= 0 || M > 16 || N <= 0 || K <= 0 || K % 32 || ldx % 8 || ldw % 8 || !x || !W || !out) return BRA_ERR_ARG;
     if (act && (N % 16 || out_f32 || res || ss_out)) return BRA_ERR_ARG;
-    if (out_f32 && (res || ss_out)) return BRA_ERR_ARG;
+    if (out_f32 && res) return BRA_ERR_ARG;            // (out_f32 with ss_out: per-tile maxima of the logits, 16-column tiles)
     if (norm_w && (!ss_in || nss_in < 32 || nss_in % 32 || nss_in > 256)) return BRA_ERR_ARG;
     if (res && ldres % 4) return BRA_ERR_ARG;
     const bool wide = M > 8;                     // 9 .. 16 rows: 16-column tiles everywhere (a diagonal tile holds 8 rows)

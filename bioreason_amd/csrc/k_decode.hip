@@ -20,6 +20,7 @@ struct Layer {
     int pad_;
     const void* head_packed;                                           // record 0 only: fragment-packed lm_head matrix, or null
     const float* rope_rows;                                            // record 0 only: [B, hd] cos | sin rows of the current positions, or null
+    float* head_tmax;                                                  // record 0 only: [B, ceil(V / 16)] maxima of the logits' 16-column tiles (sampler), or null
 };
 
 }  // namespace
@@ -106,11 +107,17 @@ static int sg_tail(const StepGemms& s, const Layer& l, const void* o, void* x, v
     if ((rc = bra_dec_gemm(h, s.H, l.ln2, s.eps, l.Wgu, s.H, nullptr, 0, act, s.F, s.B, 2 * s.F, s.H, 1, 0, s.stream))) return rc;
     return bra_dec_gemm(act, s.F, nullptr, 0.f, l.Wd, s.F, h, s.H, x, s.H, s.B, s.H, s.F, 0, 0, s.stream);
 }
-static int sg_head(const StepGemms& s, const void* x, const void* norm_w, const void* E, const void* Epacked, int folded, float* logits) {
+// `tmax` (optional, [B, ceil(V / 16)]): the projection's epilogue also leaves the maximum of every 16-column tile of the logits
+// (bra_sample_tiles); the first-generation kernel has no such epilogue — bra_tile_max then computes them in a launch of its own
+static int sg_head(const StepGemms& s, const void* x, const void* norm_w, const void* E, const void* Epacked, int folded, float* logits,
+                   float* tmax) {
+    const int nt = (s.V + 15) / 16;
     if (s.v2 && Epacked)
-        return bra_dec_gemm2_probe(x, s.H, s.ssx, s.nss, norm_w, s.eps, Epacked, s.H, nullptr, 0, logits, s.V, nullptr, 0, s.B, s.V, s.H, 0, 1, folded ? 3 : 1, nullptr, s.stream);
-    if (s.v2) return bra_dec_gemm2(x, s.H, s.ssx, s.nss, norm_w, s.eps, E, s.H, nullptr, 0, logits, s.V, nullptr, 0, s.B, s.V, s.H, 0, 1, s.stream);
-    return bra_dec_gemm(x, s.H, norm_w, s.eps, E, s.H, nullptr, 0, logits, s.V, s.B, s.V, s.H, 0, 1, s.stream);
+        return bra_dec_gemm2_probe(x, s.H, s.ssx, s.nss, norm_w, s.eps, Epacked, s.H, nullptr, 0, logits, s.V, tmax, tmax ? nt : 0, s.B, s.V, s.H, 0, 1, folded ? 3 : 1, nullptr, s.stream);
+    if (s.v2) return bra_dec_gemm2(x, s.H, s.ssx, s.nss, norm_w, s.eps, E, s.H, nullptr, 0, logits, s.V, tmax, tmax ? nt : 0, s.B, s.V, s.H, 0, 1, s.stream);
+    int rc = bra_dec_gemm(x, s.H, norm_w, s.eps, E, s.H, nullptr, 0, logits, s.V, s.B, s.V, s.H, 0, 1, s.stream);
+    if (rc || !tmax) return rc;
+    return bra_tile_max(logits, s.V, s.B, s.V, tmax, nt, s.stream);
 }
 
 // Fused variant (k_decfused.hip): 6 launches per layer.  The layer records carry ROLLOUT weights in
@@ -140,7 +147,7 @@ extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B,
         CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, nchunk, len_dev, 0, stream));
         CK(sg_tail(sg, l, o, x, h, act));
     }
-    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits));
+    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits, L > 0 ? ls[0].head_tmax : nullptr));
 #undef CK
     return 0;
 }
@@ -176,7 +183,7 @@ extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R
         CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, ntot, t_dev, npc, stream));
         CK(sg_tail(sg, l, o, x, h, act));
     }
-    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits));
+    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits, L > 0 ? ls[0].head_tmax : nullptr));
 #undef CK
     return 0;
 }
@@ -207,7 +214,7 @@ extern "C" int bra_qwen_decode_step_one(const void* layers_host, int L, int R, i
                             part_o, part_ml, nslot, o, Nq, R, copies, Hq, Hkv, hd, P, C, t, eps, scale, t_dev, stream));
         CK(sg_tail(sg, l, o, x, h, act));
     }
-    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits));
+    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits, L > 0 ? ls[0].head_tmax : nullptr));
 #undef CK
     return 0;
 }
@@ -265,7 +272,7 @@ extern "C" int bra_qwen_decode_step_persist(const void* layers_host, const void*
     CK(bra_qwen_layers_persist(layers_dev, L, R, copies, H, Hq, Hkv, hd, F, P, vt_pitch, C, cp, eps, scale, cosT, sinT, pos,
                                ls[0].rope_rows, pmask, t, t_dev, x, qkv, o, h, act, ss_ws, nss, part_o, part_ml, nslot, sync,
                                prefetch, stop_after, timeout_us, stream));
-    if (logits) CK(sg_head(sg, x, norm_w, E, ls[0].head_packed, ls[0].flags & 4, logits));
+    if (logits) CK(sg_head(sg, x, norm_w, E, ls[0].head_packed, ls[0].flags & 4, logits, ls[0].head_tmax));
 #undef CK
     return 0;
 }

@@ -49,11 +49,13 @@ __device__ __forceinline__ uint64_t cand_key(float v, int idx) { return ((uint64
 
 // EPT = candidates per thread: a slice holds at most 256 * EPT elements (10 covers Qwen3's 151 936-entry vocabulary; every
 // round of the extraction rescans a winner lane's EPT registers, so the count is kept as small as the vocabulary allows)
+// (nsl = gridDim.x slices per row: 64 over the logits themselves, 8 over the V / 16 tile maxima of bra_sample_tiles)
 template <int EPT>
 __global__ __launch_bounds__(256) void topk_slices_kernel(const float* logits, long ldl, int V, int k, float* cand_v,
                                                           int* cand_i) {
     __shared__ uint64_t lists[16][64];            // [lane-row of the workgroup][rank]
     const int row = (int)blockIdx.y, sl = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63;
+    const int kSlices = (int)gridDim.x;
     const int per = (V + kSlices - 1) / kSlices;
     const int lo = sl * per, hi = (lo + per) < V ? (lo + per) : V;
     const float* lr = logits + (long)row * ldl;
@@ -293,12 +295,196 @@ __global__ __launch_bounds__(64) void sample_merge_kernel(const float* cand_v, c
     if (ss) for (int c = lane; c < nss; c += 64) ss[(long)row * nss + c] = c == 0 ? acc : 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Sampler over TILE MAXIMA (round 4).  The lm_head projection's epilogue (bra_decgemm.h) leaves, next to the fp32 logits, the
+// maximum of every 16-column tile: tmax [B, ceil(V / 16)].  Under the order (value desc, index asc) every one of the k best
+// logits of a row lies in one of the k best TILES under (tile maximum desc, tile index asc): a tile T that holds one of them and
+// is not among those would have k tiles in front of it, each with an element that precedes T's best element (a larger value, or
+// the same value at a smaller index — tiles are contiguous index ranges), hence k elements in front of one of the k best.  So
+//   stage 1  topk_slices_kernel over the 9 496 maxima of a row (8 slices) instead of 151 936 logits (64 slices),
+//   stage 2  ONE wave per row: merges the 8 slice lists into the k best tiles, gathers their 16 k logits, extracts the k best
+//            (the same list the 64-slice path produces: same order, same ties), draws, gathers the embedding row of the token
+//            and — the launch that used to follow every decode step — moves the row's rotary position on: pos_out = pos0 + step
+//            and the (cos | sin) row of that position for the decode attention of the step that follows.
+constexpr int kTileSlices = 8;
+
+__global__ __launch_bounds__(256) void tile_max_kernel(const float* logits, long ldl, int V, float* tmax, long ldm) {
+    const int row = (int)blockIdx.y, tile = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int ntiles = (V + 15) / 16;
+    if (tile >= ntiles) return;
+    const float* lr = logits + (long)row * ldl;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const int c = tile * 16 + j; v[j] = lr[c < V ? c : V - 1]; }
+    float m = v[0];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
+    tmax[(long)row * ldm + tile] = m;
+}
+
+// NL = list entries per lane in stage 2a (nsl * k <= 64 * NL), NU = gathered logits per lane (16 k <= 64 * NU)
+template <int NL, int NU>
+__global__ __launch_bounds__(64) void sample_tiles_kernel(const float* logits, long ldl, int V, const float* cand_v, const int* cand_i,
+                                                          int nsl, int k, float temperature, float top_p, int do_sample, uint32_t seed,
+                                                          const int* step_ptr, int step_arg, uint8_t* finished, int pad_id, int eos_id,
+                                                          int eos_id2, int* out_ids, float* out_logp, int* tokens_out, long ldt,
+                                                          const bf16_t* E, long lde, int H, bf16_t* x, long ldx, float* ss, int nss,
+                                                          const int* pos0, int* pos_out, const float* cosT, const float* sinT, int hd,
+                                                          float* rope_rows) {
+    __shared__ float sv[kTileSlices * 64];
+    __shared__ int si[kTileSlices * 64];
+    __shared__ int tsel[64];
+    __shared__ float top_v[64];
+    __shared__ int top_i[64];
+    __shared__ int s_choice;
+    __shared__ float pick_ws[64];
+    const int row = (int)blockIdx.x, lane = lane_id();
+    const long base = (long)row * nsl * k;
+    const int nlist = nsl * k;
+    // every first-round request up front, from clamped addresses (no branch around a load)
+    uint32_t step_w = *reinterpret_cast<const uint32_t*>(step_ptr ? (const void*)step_ptr : (const void*)cand_i);
+    uint32_t fin_w = *(finished ? finished + row : reinterpret_cast<const uint8_t*>(cand_i));
+    uint32_t pos_w = *reinterpret_cast<const uint32_t*>(pos0 ? (const void*)(pos0 + row) : (const void*)cand_i);
+    float lv[NL];
+    int li[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int j = lane + 64 * u;
+        const int jj = j < nlist ? j : nlist - 1;
+        lv[u] = cand_v[base + jj];
+        li[u] = cand_i[base + jj];
+    }
+    pin_u32(step_w); pin_u32(fin_w); pin_u32(pos_w);
+    const int step_v = step_ptr ? (int)step_w : step_arg, fin_v = finished ? (int)(fin_w & 0xffu) : 0;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int j = lane + 64 * u;
+        if (j < nlist) { sv[j] = lv[u]; si[j] = li[u]; }
+    }
+    // the rotary row of the position this token is fed at: requested now, stored at the end (hd <= 128: two floats per lane)
+    const int p_new = (int)pos_w + step_v;
+    const int half = hd >> 1;
+    float rr[2] = {0.f, 0.f};
+    if (rope_rows) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int d = lane + 64 * u;
+            const int dc = d < hd ? d : 0;
+            const float* tp = dc < half ? cosT + ((long)p_new * half + dc) : sinT + ((long)p_new * half + dc - half);
+            rr[u] = *tp;
+        }
+    }
+    __syncthreads();
+    // ---- stage 2a: lane = slice list (sorted value desc / tile index asc); k rounds over the heads -> the k best tiles
+    {
+        int ptr = 0;
+        const bool mine = lane < nsl;
+        const int l0 = mine ? lane * k : 0;
+        uint64_t head = (mine && si[l0] != 0x7fffffff) ? cand_key(sv[l0], si[l0]) : 0ull;
+        for (int round = 0; round < k; ++round) {
+            const uint64_t w = row_max_u64(head);                 // nsl <= 16: the lists sit in the first lane-row
+            if (lane == 0) tsel[round] = w ? 0x7fffffff - (int)(uint32_t)w : -1;
+            if (head == w && w != 0ull) {
+                ++ptr;
+                head = (ptr < k && si[l0 + ptr] != 0x7fffffff) ? cand_key(sv[l0 + ptr], si[l0 + ptr]) : 0ull;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- stage 2b: the logits of those tiles (16 k <= 64 NU values), all requested before the first is used
+    const float* lr = logits + (long)row * ldl;
+    float gv[NU];
+    int gi[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int j = lane + 64 * u;
+        const int tq = j >> 4;
+        const int t = tsel[tq < k ? tq : k - 1];
+        const int idx = t * 16 + (j & 15);
+        const bool ok = tq < k && t >= 0 && idx < V;
+        gi[u] = ok ? idx : -1;
+        gv[u] = lr[ok ? idx : 0];
+    }
+    uint64_t key[NU];
+    uint64_t best = 0ull;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        key[u] = gi[u] >= 0 ? cand_key(gv[u], gi[u]) : 0ull;
+        best = key[u] > best ? key[u] : best;
+    }
+    for (int round = 0; round < k; ++round) {
+        const uint64_t w = wave_max_u64(best);
+        if (lane == 0) {
+            top_v[round] = w ? unord_f32((uint32_t)(w >> 32)) : -3.0e38f;
+            top_i[round] = w ? 0x7fffffff - (int)(uint32_t)w : 0x7fffffff;
+        }
+        if (best == w && w != 0ull) {
+            best = 0ull;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                key[u] = key[u] == w ? 0ull : key[u];
+                best = key[u] > best ? key[u] : best;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0)
+        s_choice = sample_pick(pick_ws, top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_v, fin_v, finished, pad_id,
+                               eos_id, eos_id2, out_ids, out_logp, tokens_out, ldt);
+    __syncthreads();
+    if (rope_rows) {
+        if (hd <= 128) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int d = lane + 64 * u; if (d < hd) rope_rows[(long)row * hd + d] = rr[u]; }
+        } else {
+            for (int d = lane; d < hd; d += 64)
+                rope_rows[(long)row * hd + d] = d < half ? cosT[(long)p_new * half + d] : sinT[(long)p_new * half + d - half];
+        }
+    }
+    if (pos_out && lane == 0) pos_out[row] = p_new;
+    if (!E) return;
+    const int tok = s_choice;
+    float acc = 0.f;
+    const int nch = H / 8;
+    const bf16_t* er = E + (long)tok * lde;
+    u32x4 ev[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int j = lane + 64 * u; ev[u] = ld16(er + (j < nch ? j : 0) * 8); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pin_u32x4(ev[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = lane + 64 * u;
+        if (j < nch) {
+            st16(x + (long)row * ldx + j * 8, ev[u]);
+            float f[8];
+            unpack8(ev[u], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += f[i] * f[i];
+        }
+    }
+    for (int j = lane + 256; j < nch; j += 64) {
+        const u32x4 v = ld16(er + j * 8);
+        st16(x + (long)row * ldx + j * 8, v);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += f[i] * f[i];
+    }
+    acc = wave_sum<64>(acc);
+    if (ss) for (int c = lane; c < nss; c += 64) ss[(long)row * nss + c] = c == 0 ? acc : 0.f;
+}
+
 // synthetic EOS schedule (bench / tests: random-init weights never emit EOS on their own): row b's logit of `token` is
 // raised above everything else at the step its schedule names, so the sampler — greedy or warped — draws it there.
-__global__ __launch_bounds__(64) void force_token_kernel(float* logits, long ldl, int B, int token, const int* step_ptr,
-                                                         const int* at) {
+__global__ __launch_bounds__(64) void force_token_kernel(float* logits, long ldl, int B, int token, const int* step_ptr, int step_arg,
+                                                         const int* at, float* tmax, long ldm) {
     const int b = (int)threadIdx.x;
-    if (b < B && at[b] == step_ptr[0]) logits[(long)b * ldl + token] = 1.0e30f;
+    const int step = step_ptr ? step_ptr[0] : step_arg;
+    if (b < B && at[b] == step) {
+        logits[(long)b * ldl + token] = 1.0e30f;
+        if (tmax) tmax[(long)b * ldm + (token >> 4)] = 1.0e30f;       // (the maximum of the token's 16-column tile)
+    }
 }
 
 // counters of the replayed token loop: pos[0 .. n) += 1 (rotary positions), a[0] += 1, b[0] += 1 (step index, cache length)
@@ -464,7 +650,65 @@ extern "C" int bra_force_token(float* logits, long ldl, int B, int V, int token,
                                void* stream) {
     if (B == 0) return 0;
     if (!logits || !step_ptr || !at || token < 0 || token >= V || B > 64) return BRA_ERR_ARG;
-    BRA_LAUNCH(force_token_kernel, dim3(1), dim3(64), 0, stream, logits, ldl, B, token, step_ptr, at);
+    BRA_LAUNCH(force_token_kernel, dim3(1), dim3(64), 0, stream, logits, ldl, B, token, step_ptr, 0, at, (float*)nullptr, 0L);
+    return BRA_LAUNCH_STATUS();
+}
+
+// bra_force_token for the tile-maxima sampler: also raises the maximum of the token's tile; `step_ptr` null -> the step index
+// is the launch argument `step` (token loop issued launch by launch: no device-side counter)
+extern "C" int bra_force_token_tiles(float* logits, long ldl, int B, int V, int token, const int* step_ptr, int step, const int* at,
+                                     float* tmax, long ldm, void* stream) {
+    if (B == 0) return 0;
+    if (!logits || !at || token < 0 || token >= V || B > 64 || (tmax && ldm < (V + 15) / 16)) return BRA_ERR_ARG;
+    BRA_LAUNCH(force_token_kernel, dim3(1), dim3(64), 0, stream, logits, ldl, B, token, step_ptr, step, at, tmax, ldm);
+    return BRA_LAUNCH_STATUS();
+}
+
+extern "C" int bra_tile_max(const float* logits, long ldl, int B, int V, float* tmax, long ldm, void* stream) {
+    if (B == 0) return 0;
+    if (!logits || !tmax || V <= 0 || ldm < (V + 15) / 16) return BRA_ERR_ARG;
+    const int ntiles = (V + 15) / 16;
+    BRA_LAUNCH(tile_max_kernel, dim3((ntiles + 255) / 256, B), dim3(256), 0, stream, logits, ldl, V, tmax, ldm);
+    return BRA_LAUNCH_STATUS();
+}
+
+// The sampler over tile maxima (see sample_tiles_kernel): logits fp32 [B, V] with tmax [B, ceil(V / 16)] = the maximum of every
+// 16-column tile (lm_head epilogue of the decode step, or bra_tile_max).  Same tokens as bra_sample / bra_sample_embed for the
+// same inputs.  ws: bra_sample_ws_floats words.  `step_ptr` null: the step index is `step`.  E / x / ss as bra_sample_embed.
+// pos0 / pos_out / cosT / sinT / hd / rope_rows (optional): pos_out[b] = pos0[b] + step and rope_rows[b] = (cos | sin) row of that
+// position — what bra_advance_counters would leave for the decode step that follows this draw.
+// BRA_ERR_UNSUPPORTED: fewer than 4096 tiles' worth of vocabulary is fine, but V / 16 > 8 * 4096, top_k outside 1..64.
+extern "C" int bra_sample_tiles(const float* logits, long ldl, const float* tmax, long ldm, int B, int V, float temperature, int top_k,
+                                float top_p, int do_sample, unsigned seed, const int* step_ptr, int step, void* finished, int pad_id,
+                                int eos_id, int eos_id2, int* out_ids, float* out_logp, int* tokens_out, long ldt, void* ws,
+                                const void* E, long lde, int H, void* x, long ldx, float* ss, int nss, const int* pos0, int* pos_out,
+                                const float* cosT, const float* sinT, int hd, float* rope_rows, void* stream) {
+    if (B == 0) return 0;
+    if (!logits || !tmax || !out_ids || !ws || V <= 0 || (do_sample && temperature <= 0.f)) return BRA_ERR_ARG;
+    if (do_sample && (top_k <= 0 || top_k > 64)) return BRA_ERR_UNSUPPORTED;
+    if (E && (!x || H % 8 || lde % 8 || ldx % 8)) return BRA_ERR_ARG;
+    if (rope_rows && (!pos0 || !cosT || !sinT || hd <= 0 || hd % 2)) return BRA_ERR_ARG;
+    if (pos_out && !pos0) return BRA_ERR_ARG;
+    const int ntiles = (V + 15) / 16;
+    if (ldm < ntiles) return BRA_ERR_ARG;
+    if ((ntiles + kTileSlices - 1) / kTileSlices > 4096) return BRA_ERR_UNSUPPORTED;
+    const int k = do_sample ? top_k : 1;
+    float* cv = (float*)ws;
+    int* ci = (int*)ws + (long)B * kTileSlices * k;
+    const int per = (ntiles + kTileSlices - 1) / kTileSlices;
+    if (per <= 1280) BRA_LAUNCH(topk_slices_kernel<5>, dim3(kTileSlices, B), dim3(256), 0, stream, tmax, ldm, ntiles, k, cv, ci);
+    else if (per <= 2560) BRA_LAUNCH(topk_slices_kernel<10>, dim3(kTileSlices, B), dim3(256), 0, stream, tmax, ldm, ntiles, k, cv, ci);
+    else BRA_LAUNCH(topk_slices_kernel<16>, dim3(kTileSlices, B), dim3(256), 0, stream, tmax, ldm, ntiles, k, cv, ci);
+    int r = BRA_LAUNCH_STATUS();
+    if (r) return r;
+#define BRA_ST(NL_, NU_)                                                                                                        \
+    BRA_LAUNCH((sample_tiles_kernel<NL_, NU_>), dim3(B), dim3(64), 0, stream, logits, ldl, V, (const float*)cv, (const int*)ci,  \
+               kTileSlices, k, temperature, top_p, do_sample, (uint32_t)seed, step_ptr, step, (uint8_t*)finished, pad_id, eos_id, \
+               eos_id2, out_ids, out_logp, tokens_out, ldt, (const bf16_t*)E, lde, H, (bf16_t*)x, ldx, ss, nss, pos0, pos_out,    \
+               cosT, sinT, hd, rope_rows)
+    if (k <= 20) BRA_ST(3, 5);
+    else BRA_ST(8, 16);
+#undef BRA_ST
     return BRA_LAUNCH_STATUS();
 }
 

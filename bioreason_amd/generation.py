@@ -54,7 +54,8 @@ class _LayerDesc(ctypes.Structure):
                 + [(n, ctypes.c_int) for n in ("r_qkv", "r_o", "r_gu", "r_d")]
                 + [(n, ctypes.c_float) for n in ("s_qkv", "s_o", "s_gu", "s_d")]
                 + [("kc", ctypes.c_void_p), ("vc", ctypes.c_void_p), ("kp", ctypes.c_void_p), ("vtp", ctypes.c_void_p)]
-                + [("flags", ctypes.c_int), ("pad_", ctypes.c_int), ("head_packed", ctypes.c_void_p), ("rope_rows", ctypes.c_void_p)])
+                + [("flags", ctypes.c_int), ("pad_", ctypes.c_int), ("head_packed", ctypes.c_void_p), ("rope_rows", ctypes.c_void_p),
+                   ("head_tmax", ctypes.c_void_p)])
 
 
 class DecodeState:
@@ -458,15 +459,47 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     dstate = shared if shared is not None else (state if fused else None)
     # the drawing wave of the sampler also gathers x = E[token] and its RMSNorm statistic for the fused step (not under
     # teacher forcing, where the token fed back is not the sampled one)
+    # sampler over tile maxima (ops.sample_tiles): the lm_head epilogue of the fused step leaves the maximum of every 16-column
+    # tile of the logits in `tmax`; the top-k stage then scans V / 16 maxima + 16 k logits instead of V logits (same tokens)
+    ntile = (eng.V + 15) // 16
+    use_tiles = (dstate is not None and os.environ.get("BRA_SAMPLE_TILES", "1") == "1" and B <= 64 and ntile <= 8 * 4096
+                 and (not do_sample or 1 <= top_k <= 64))
+    tmax = None
+    if use_tiles:
+        tmax = torch.empty((B, ntile), dtype=torch.float32, device=dev)
+        dstate.arr[0].head_tmax = tmax.data_ptr()
+        ops.tile_max(logits, tmax)
+        sample_ws = torch.empty((2 * B * 8 * kk,), dtype=torch.float32, device=dev)
     fuse_embed = (dstate is not None and dstate.ss_ws is not None and force_tokens is None and sample_ws is not None
                   and B <= 16)
+    rope_args = None
+    if shared is not None and getattr(shared, "rope_rows", None) is not None:
+        rope_args = (shared.cosT, shared.sinT, eng.hd, shared.rope_rows)
+        ops.rope_rows(shared.cosT, shared.sinT, next_pos, eng.hd, shared.rope_rows)
+    # issued launch by launch, the shared-prefix loop needs no device-side counters at all: the step index is a launch argument of
+    # the sampler too, and its drawing wave leaves the (cos | sin) rows of the positions the step that follows rotates with —
+    # the bra_advance_counters launch per token is gone (a replayed graph keeps the counters: its launch arguments are frozen)
+    fuse_adv = use_tiles and rope_args is not None
+    pos0 = next_pos.clone() if fuse_adv else None
+    counters_at = [0]                       # the step index the device-side counters (step_t, len_t, next_pos) hold
 
-    def sample_():
+    def sample_(t_host: Optional[int] = None):
+        """the draw of step t.  `t_host` given: launch-by-launch issue (the index travels as an argument where the kernels take it)"""
+        host_step = t_host is not None and fuse_adv
+        fin = finished if eos >= 0 else None
+        emb = (eng.E, dstate.x, dstate.ss_ws[0]) if fuse_embed else None
+        if use_tiles:
+            st = t_host if host_step else step_t
+            if eos_schedule is not None:
+                ops.force_token_tiles(logits, eos, st, eos_schedule, tmax)
+            ops.sample_tiles(logits, tmax, temperature, top_k, top_p, do_sample, seed, st, fin, pad, cur, None, eos_id=eos,
+                             eos_id2=eos2, tokens_out=tokens, ws=sample_ws, embed=emb,
+                             advance=(pos0, next_pos, rope_args[0], rope_args[1], rope_args[2], rope_args[3]) if host_step else None)
+            return
         if eos_schedule is not None:
             ops.force_token(logits, eos, step_t, eos_schedule)
-        ops.sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished if eos >= 0 else None, pad,
-                   cur, None, eos_id=eos, eos_id2=eos2, tokens_out=tokens, ws=sample_ws,
-                   embed=(eng.E, dstate.x, dstate.ss_ws[0]) if fuse_embed else None)
+        ops.sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, fin, pad,
+                   cur, None, eos_id=eos, eos_id2=eos2, tokens_out=tokens, ws=sample_ws, embed=emb)
 
     def advance_(t_grid: int, exact_t: bool = False):
         """one fused decode step.  Under graph replay the kernels take the step index from step_t / len_t and `t_grid` only sizes
@@ -476,12 +509,19 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             shared.step(cur, next_pos, pmask, t_grid, logits, t_dev=None if exact_t else step_t, embed_done=fuse_embed)
         else:
             state.step(cur, next_pos, kmask, P + t_grid, logits, len_dev=len_t, embed_done=fuse_embed)
+        if exact_t and fuse_adv:
+            return                          # (the next draw moves the positions on)
         ops.advance_counters(next_pos, step_t, len_t, rope=rope_args)
+        counters_at[0] += 1
 
-    rope_args = None
-    if shared is not None and getattr(shared, "rope_rows", None) is not None:
-        rope_args = (shared.cosT, shared.sinT, eng.hd, shared.rope_rows)
-        ops.rope_rows(shared.cosT, shared.sinT, next_pos, eng.hd, shared.rope_rows)
+    def sync_counters(tt: int):
+        """device-side counters <- step tt (before a graph capture that follows launch-by-launch steps)"""
+        if fuse_adv and counters_at[0] != tt:
+            step_t.fill_(tt)
+            len_t.fill_(P + tt)
+            next_pos.copy_(pos0 + tt)
+            ops.rope_rows(rope_args[0], rope_args[1], next_pos, eng.hd, rope_args[3])
+            counters_at[0] = tt
     _tick("decode_setup")
     # `loop_events` (measurement): a HIP-event pair on the launch stream around the token loop of THIS call is appended — bench.py
     # times the loop inside its timed steps with it (no host synchronisation, unlike `profile`)
@@ -502,7 +542,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         for _ in range(n):
             if t >= last:
                 return True
-            sample_()
+            sample_(t)
             if eos_stop(t):
                 n_done = t + 1
                 return False
@@ -560,6 +600,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         if t == 0:
             alive = eager_steps(1)                       # eager first step: one-time kernel attribute set-up happens here
         if alive and t < last:
+            sync_counters(t)
             graph = torch.cuda.CUDAGraph()
             # thread_local: other threads of the process (the RCCL watchdog of a data-parallel run) keep making HIP calls
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
@@ -576,7 +617,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     elif alive:
         alive = eager_steps(last - t)
     if alive:
-        sample_()
+        sample_(t if graph is None else None)
     if ev_loop is not None:
         ev_loop[1].record()
         loop_events.append((ev_loop[0], ev_loop[1], (max_new_tokens if alive else n_done) - 1))

@@ -449,6 +449,45 @@ def sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished,
     return out_ids
 
 
+def tile_max(logits: torch.Tensor, tmax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """maxima of the 16-column tiles of fp32 logits [B, V] -> [B, ceil(V / 16)] (the second input of `sample_tiles`)"""
+    B, V = logits.shape
+    if tmax is None:
+        tmax = torch.empty((B, (V + 15) // 16), dtype=torch.float32, device=logits.device)
+    get_lib().call("bra_tile_max", logits, _ld(logits), B, V, tmax, _ld(tmax), current_stream(logits))
+    return tmax
+
+
+def sample_tiles(logits, tmax, temperature, top_k, top_p, do_sample, seed, step, finished, pad_id, out_ids, out_logp=None, eos_id=-1,
+                 tokens_out=None, ws=None, embed=None, eos_id2=-1, advance=None):
+    """`sample` over (logits, tile maxima): same tokens, two light launches.  `step`: a device int32 [1] (replayed loops) or a
+    python int (the loop issued launch by launch).  `advance` = (pos0 int32 [B], pos_out int32 [B] or None, cosT, sinT, hd,
+    rope_rows fp32 [B, hd]): the drawing wave also leaves pos0 + step and the (cos | sin) row of that position."""
+    B, V = logits.shape
+    if do_sample and not (1 <= top_k <= 64):
+        raise NotImplementedError("sampling needs 1 <= top_k <= 64 on the HIP path (see ops.sample)")
+    k = top_k if do_sample else 1
+    if ws is None:
+        ws = torch.empty((2 * B * 8 * k,), dtype=torch.float32, device=logits.device)
+    ldt = tokens_out.stride(0) if tokens_out is not None else 0
+    E, x, ss = embed if embed is not None else (None, None, None)
+    pos0, pos_out, cosT, sinT, hd, rows = advance if advance is not None else (None, None, None, None, 0, None)
+    step_ptr, step_i = (step, 0) if isinstance(step, torch.Tensor) else (None, int(step))
+    get_lib().call("bra_sample_tiles", logits, _ld(logits), tmax, _ld(tmax), B, V, temperature, top_k, top_p, int(do_sample),
+                   seed & 0xFFFFFFFF, step_ptr, step_i, finished, pad_id, eos_id, eos_id2, out_ids, out_logp, tokens_out, ldt, ws,
+                   E, _ld(E) if E is not None else 0, E.shape[1] if E is not None else 0, x, _ld(x) if x is not None else 0, ss,
+                   ss.shape[-1] if ss is not None else 0, pos0, pos_out, cosT, sinT, hd, rows, current_stream(logits))
+    return out_ids
+
+
+def force_token_tiles(logits: torch.Tensor, token: int, step, at: torch.Tensor, tmax: Optional[torch.Tensor]):
+    """`force_token` that keeps the tile maxima consistent; `step`: device int32 [1] or python int"""
+    B, V = logits.shape
+    step_ptr, step_i = (step, 0) if isinstance(step, torch.Tensor) else (None, int(step))
+    get_lib().call("bra_force_token_tiles", logits, _ld(logits), B, V, int(token), step_ptr, step_i, at, tmax,
+                   _ld(tmax) if tmax is not None else 0, current_stream(logits))
+
+
 def force_token(logits: torch.Tensor, token: int, step_t: torch.Tensor, at: torch.Tensor):
     """logits[b, token] = +big where at[b] == step_t[0] (synthetic EOS schedule of the straggler bench / tests)"""
     B, V = logits.shape
@@ -472,18 +511,23 @@ def row_sumsq(x: torch.Tensor, nss: int = 32) -> torch.Tensor:
     return ss
 
 
-def dec_gemm2(x, W, ss_in=None, norm_w=None, eps=1e-6, res=None, act=False, out_f32=False, want_ss=False, packed=False):
+def dec_gemm2(x, W, ss_in=None, norm_w=None, eps=1e-6, res=None, act=False, out_f32=False, want_ss=False, packed=False,
+              tile_max=None):
     """decode-time projection (bra_dec_gemm2): y = rmsnorm(x) W^T (+res | SwiGLU | fp32); returns (y, ss_out or None).
-    packed: W is the fragment-ordered copy made by dec_pack_weights (same logical shape); 3 = with the norm weight folded"""
+    packed: W is the fragment-ordered copy made by dec_pack_weights (same logical shape); 3 = with the norm weight folded.
+    tile_max (out_f32 only): fp32 [M, >= ceil(N / 16)] that receives the maximum of every 16-column tile of the logits"""
     M, K = x.shape
     N = W.shape[0]
     out = torch.empty((M, N // 2 if act else N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     nss_out = (N // 8 + 32) // 32 * 32
     ss_out = torch.zeros((16 if M > 8 else 8, nss_out), dtype=torch.float32, device=x.device) if want_ss else None
+    if tile_max is not None:
+        assert out_f32 and not want_ss
+        ss_out, nss_out, want_ss = tile_max, _ld(tile_max), True
     get_lib().call("bra_dec_gemm2_probe", x, _ld(x), ss_in, ss_in.shape[1] if ss_in is not None else 0, norm_w, eps, W, _ld(W),
                    res, _ld(res) if res is not None else 0, out, _ld(out), ss_out, nss_out if want_ss else 0, M, N, K,
                    int(act), int(out_f32), int(packed), None, current_stream(x))
-    return out, ss_out
+    return out, (None if tile_max is not None else ss_out)
 
 
 def dec_pack_weights(W: torch.Tensor, act: bool = False, out_f32: bool = False, norm_w: Optional[torch.Tensor] = None,

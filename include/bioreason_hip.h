@@ -165,7 +165,9 @@ int bra_attn_decode(const void* q, const void* kc, const void* vc, const void* k
  * TF:generation/utils.py:2876-2925 -> TF:qwen3:367-427 with a KV cache), enqueued by native code so the
  * ~400 launches of a step are not paced by the Python interpreter.  `layers_host` is a HOST array of L
  * records {ln1, ln2, qn, kn, Wqkv, Wo, Wgu, Wd, A_qkv, B_qkv, A_o, B_o, A_gu, B_gu, A_d, B_d (device ptrs, LoRA
- * ones may be null); int r_qkv, r_o, r_gu, r_d; float s_qkv, s_o, s_gu, s_d; kc, vc}; the rest are device
+ * ones may be null); int r_qkv, r_o, r_gu, r_d; float s_qkv, s_o, s_gu, s_d; kc, vc; kp, vtp; int flags, pad; record 0:
+ * head_packed, rope_rows, head_tmax (float [B, ceil(V / 16)] or null: the step functions that write logits also leave the
+ * maximum of every 16-column tile there for bra_sample_tiles)}, bra_qwen_layer_desc_size() bytes each; the rest are device
  * pointers to caller-owned workspaces.  Writes the final-normed hidden rows [B, H] to `hid`. */
 int bra_qwen_layer_desc_size(void);
 int bra_qwen_decode_step(const void* layers_host, int L, int B, int H, int Hq, int Hkv, int hd, int F, int Smax,
@@ -329,6 +331,24 @@ int bra_sample_embed(const float* logits, long ldl, int B, int V, float temperat
 /* synthetic EOS schedule for benchmarks / tests with random-init weights (SURVEY 8d "straggler run"): logits[b, token]
  * is raised above every other entry when *step_ptr == at[b], so row b draws `token` at that step.  B <= 64. */
 int bra_force_token(float* logits, long ldl, int B, int V, int token, const int* step_ptr, const int* at, void* stream);
+/* ---- sampler over tile maxima (round 4; k_grpo.hip: sample_tiles_kernel) -------
+ * tmax [B, ldm >= ceil(V / 16)] fp32: the maximum of every 16-column tile of the logits — left by the lm_head epilogue of the
+ * decode step functions (layer record 0: `head_tmax`) or computed by bra_tile_max.  Every one of the k best logits of a row
+ * lies in one of the k best tiles, so the top-k stage scans V / 16 maxima + 16 k logits instead of V logits; tokens, ties and
+ * draws are those of bra_sample / bra_sample_embed on the same inputs (TF:generation/logits_process.py:238,473,542). */
+int bra_tile_max(const float* logits, long ldl, int B, int V, float* tmax, long ldm, void* stream);
+/* bra_sample_embed over (logits, tmax) in two launches.  `step_ptr` null: the step index is the launch argument `step` (a
+ * token loop issued launch by launch needs no device-side counter).  pos0 / pos_out / cosT / sinT / hd / rope_rows (optional):
+ * pos_out[b] = pos0[b] + step, rope_rows[b] = (cos | sin) row of that position — the state bra_advance_counters would have
+ * left for the decode step that follows this draw (HF: cache_position += 1, TF:generation/utils.py:979-984). */
+int bra_sample_tiles(const float* logits, long ldl, const float* tmax, long ldm, int B, int V, float temperature, int top_k,
+                     float top_p, int do_sample, unsigned seed, const int* step_ptr, int step, void* finished, int pad_id,
+                     int eos_id, int eos_id2, int* out_ids, float* out_logp, int* tokens_out, long ldt, void* ws,
+                     const void* E, long lde, int H, void* x, long ldx, float* ss, int nss, const int* pos0, int* pos_out,
+                     const float* cosT, const float* sinT, int hd, float* rope_rows, void* stream);
+/* bra_force_token that also raises the token's tile maximum; `step_ptr` null: the step index is `step` */
+int bra_force_token_tiles(float* logits, long ldl, int B, int V, int token, const int* step_ptr, int step, const int* at,
+                          float* tmax, long ldm, void* stream);
 /* counters of the replayed token loop: pos[0..n) += 1, a[0] += 1, b[0] += 1 (a, b optional); when `rope_rows` is given, also
  * rope_rows[i][0..hd/2) = cosT[pos[i]], [hd/2..hd) = sinT[pos[i]] for the NEW positions (see bra_rope_rows) */
 int bra_advance_counters(int* pos, int n, int* a, int* b, const float* cosT, const float* sinT, int hd, float* rope_rows,

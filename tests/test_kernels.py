@@ -530,6 +530,110 @@ def test_sampler_two_eos_ids_and_forced_token(backend):
     assert out.tolist() == [11, 44, 33]
 
 
+@pytest.mark.parametrize("V,k", [(5000, 20), (5003, 20), (9000, 1), (6000, 64), (300, 7)])
+def test_sampler_over_tile_maxima_equals_full_scan(backend, V, k):
+    """bra_sample_tiles (top-k over the maxima of the logits' 16-column tiles, then over the 16 k logits of the k best tiles) draws
+    exactly the tokens bra_sample draws from the same logits: same (value desc, index asc) order, same ties, ragged last tile, a
+    row whose best values are all equal, fewer distinct tiles than k.  HF: TF:generation/logits_process.py:238,473,542."""
+    B = 4
+    g = torch.Generator().manual_seed(V + k)
+    logits = torch.randn(B, V, generator=g)
+    logits[1] = torch.round(logits[1] * 2) / 2                   # heavy ties across and inside tiles
+    logits[2, :] = -1.0
+    logits[2, V - 1] = logits[2, 17] = logits[2, 16] = 3.0      # ties at the ragged end and inside one tile
+    logits[3, 5:5 + 40] += 8.0                                   # the k best packed into three neighbouring tiles
+    dl = logits.to(backend)
+    tmax = ops.tile_max(dl)
+    want_tm = torch.nn.functional.pad(logits, (0, (-V) % 16), value=-3e38).view(B, -1, 16).amax(-1)
+    assert torch.equal(tmax.cpu(), want_tm)
+    do_sample = k > 1
+    out0 = torch.empty(B, dtype=torch.int32, device=backend)
+    out1 = torch.empty_like(out0)
+    step = torch.zeros(1, dtype=torch.int32, device=backend)
+    lp0 = torch.empty(B, device=backend)
+    lp1 = torch.empty(B, device=backend)
+    for s_ in range(12 if backend.type == "cpu" else 60):
+        step.fill_(s_)
+        if V >= 4096:
+            ops.sample(dl, 0.7, k if do_sample else 0, 0.9, do_sample, 31, step, None, 0, out0, out_logp=lp0)
+        else:                                       # (the one-workgroup-per-row kernel: the only full-scan form below 4096)
+            ops.sample(dl, 0.7, k if do_sample else 0, 0.9, do_sample, 31, step, None, 0, out0, out_logp=lp0, ws=None)
+        ops.sample_tiles(dl, tmax, 0.7, k if do_sample else 0, 0.9, do_sample, 31, step, None, 0, out1, out_logp=lp1)
+        assert out0.tolist() == out1.tolist(), (s_, out0.tolist(), out1.tolist())
+        assert torch.equal(lp0.cpu(), lp1.cpu())
+        # the step index as a launch argument == the device-side counter
+        out2 = torch.empty_like(out0)
+        ops.sample_tiles(dl, tmax, 0.7, k if do_sample else 0, 0.9, do_sample, 31, s_, None, 0, out2)
+        assert out2.tolist() == out1.tolist()
+    if not do_sample:
+        assert out1.tolist() == logits.argmax(-1).tolist()
+
+
+def test_sampler_over_tile_maxima_tail_work(backend):
+    """the drawing wave of bra_sample_tiles also gathers x = E[token] + its RMSNorm statistic (as bra_sample_embed) and leaves
+    pos0 + step and the (cos | sin) row of that position (what bra_advance_counters left for the next decode step); finished rows
+    emit pad, two EOS ids, bra_force_token_tiles keeps the tile maxima consistent"""
+    B, V, H, hd = 5, 4800, 64, 128
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(B, V, generator=g).to(backend)
+    tmax = ops.tile_max(logits)
+    E = rnd(V, H, dev=backend)
+    x = torch.zeros(B, H, dtype=BF, device=backend)
+    ss = torch.full((8, 32), 7.0, device=backend)
+    out, out_ref = torch.empty(B, dtype=torch.int32, device=backend), torch.empty(B, dtype=torch.int32, device=backend)
+    step = torch.full((1,), 3, dtype=torch.int32, device=backend)
+    cosT, sinT = torch.rand(64, hd // 2, device=backend), torch.rand(64, hd // 2, device=backend)
+    pos0 = torch.tensor([4, 9, 0, 31, 2], dtype=torch.int32, device=backend)
+    pos_out = torch.zeros_like(pos0)
+    rows = torch.zeros(B, hd, device=backend)
+    toks = torch.zeros(B, 8, dtype=torch.int32, device=backend)
+    ops.sample(logits, 0.6, 20, 0.95, True, 77, step, None, 0, out_ref)
+    ops.sample_tiles(logits, tmax, 0.6, 20, 0.95, True, 77, 3, None, 0, out, tokens_out=toks, embed=(E, x, ss),
+                     advance=(pos0, pos_out, cosT, sinT, hd, rows))
+    assert out.tolist() == out_ref.tolist()
+    assert toks[:, 3].tolist() == out.tolist() and int(toks.abs().sum()) == int(out.abs().sum())
+    assert torch.equal(x.cpu(), E[out.long()].cpu())
+    assert rel(ss[:B, 0], (x.float() ** 2).sum(1)) < 1e-5 and float(ss[:B, 1:].abs().max()) == 0 and float(ss[B:].min()) == 7.0
+    want_pos = pos0 + 3
+    assert torch.equal(pos_out.cpu(), want_pos.cpu())
+    assert torch.equal(rows.cpu(), torch.cat([cosT[want_pos.long()], sinT[want_pos.long()]], -1).cpu())
+    # finished rows emit pad; either EOS id finishes a row
+    lz = torch.zeros(3, V, device=backend)
+    lz[0, 11] = lz[1, 22] = lz[2, 33] = 9.0
+    tz = ops.tile_max(lz)
+    o3 = torch.empty(3, dtype=torch.int32, device=backend)
+    fin = torch.zeros(3, dtype=torch.uint8, device=backend)
+    ops.sample_tiles(lz, tz, 1.0, 0, 1.0, False, 0, 0, fin, 5, o3, eos_id=11, eos_id2=22)
+    assert o3.tolist() == [11, 22, 33] and fin.tolist() == [1, 1, 0]
+    ops.sample_tiles(lz, tz, 1.0, 0, 1.0, False, 0, 1, fin, 5, o3, eos_id=11, eos_id2=22)
+    assert o3.tolist() == [5, 5, 33]
+    # forced token at the scheduled step only (device counter and launch argument forms)
+    at = torch.tensor([5, 0, 7], dtype=torch.int32, device=backend)
+    st0 = torch.zeros(1, dtype=torch.int32, device=backend)
+    ops.force_token_tiles(lz, 4444, st0, at, tz)
+    ops.sample_tiles(lz, tz, 1.0, 0, 1.0, False, 0, st0, None, 0, o3)
+    assert o3.tolist() == [11, 4444, 33]
+    ops.force_token_tiles(lz, 4321, 7, at, tz)
+    ops.sample_tiles(lz, tz, 1.0, 0, 1.0, False, 0, 7, None, 0, o3)
+    assert o3.tolist() == [11, 4444, 4321]
+    assert torch.equal(tz.cpu(), ops.tile_max(lz).cpu())
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 8208, 512), (6, 4112, 256), (12, 4096, 256)])
+def test_lm_head_epilogue_leaves_tile_maxima(backend, M, N, K):
+    """the fp32-logits projection of the decode step (packed, norm folded: the lm_head) leaves the maximum of every 16-column tile
+    next to the logits — exactly the maxima of the logits it wrote"""
+    x, W = rnd(M, K, dev=backend), rnd(N, K, dev=backend, scale=0.1)
+    nw = (1.0 + 0.1 * torch.randn(K)).to(BF).to(backend)
+    ss = ops.row_sumsq(x, 256)
+    Wf = ops.dec_pack_weights(W, out_f32=True, norm_w=nw, rows=16 if M > 8 else 8)
+    tm = torch.full((M, N // 16), -7.0, device=backend)
+    y, _ = ops.dec_gemm2(x, Wf, ss_in=ss, norm_w=nw, out_f32=True, packed=3, tile_max=tm)
+    assert torch.equal(tm.cpu(), y.float().view(M, N // 16, 16).amax(-1).cpu())
+    y0, _ = ops.dec_gemm2(x, Wf, ss_in=ss, norm_w=nw, out_f32=True, packed=3)
+    assert torch.equal(y.cpu(), y0.cpu())
+
+
 def test_process_dna_embeddings_public_method(backend):
     """DNALLMModel.process_dna_embeddings (dna_llm.py:103-179): per batch item, the first `attention_mask.sum()` projected
     rows of each of its sequences, concatenated — against the golden fixture's oracle weights"""

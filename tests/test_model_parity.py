@@ -312,6 +312,38 @@ def test_shared_prefix_decode_kernel_matches_per_copy_decode(backend, monkeypatc
     assert (s_u[:, 0] == s_s[:, 0]).all()        # first token comes from the prefill in both
 
 
+@pytest.mark.parametrize("alias", [None, [0, 0, 2, 2]])
+def test_rollout_with_tile_maxima_sampler_equals_full_scan_sampler(backend, monkeypatch, alias):
+    """the token loop with the sampler over the lm_head's tile maxima (and, on the shared-prefix path, the step index / rotary rows
+    carried by the sampler's launch instead of bra_advance_counters) draws exactly the tokens of the loop with the full-scan
+    sampler: sampling, an EOS schedule, finished rows padded (HF `_sample`: TF:generation/utils.py:2876-2925)"""
+    fix = torch.load(os.path.join(GOLD, "tiny_b.pt"), weights_only=False)
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    rows = [0, 0, 1, 1]
+    ids, mask = b["input_ids"][rows], b["attention_mask"][rows]
+    dna = {k: v[rows] for k, v in b["dna_tokenized"].items()}
+    mm = {"dna_tokenized": dna, "batch_idx_map": [0, 1, 2, 3]}
+    sched = torch.tensor([3, 9, 1, 6], dtype=torch.int32, device=backend)
+    kw = dict(max_new_tokens=9, do_sample=True, temperature=0.6, top_k=20, top_p=0.95, eos_token_id=5, pad_token_id=0, seed=4,
+              eos_schedule=sched, return_full_length=True, use_graph=False, prompt_alias=alias)
+    monkeypatch.setenv("BRA_SAMPLE_TILES", "0")
+    want = m.generate(input_ids=ids, attention_mask=mask, **mm, **kw)
+    monkeypatch.setenv("BRA_SAMPLE_TILES", "1")
+    got = m.generate(input_ids=ids, attention_mask=mask, **mm, **kw)
+    assert torch.equal(got.cpu(), want.cpu()), (got.tolist(), want.tolist())
+    for bi, st in enumerate([3, 9, 1, 6]):
+        if st < 9:
+            assert int(got[bi, st]) == 5 and (got[bi, st + 1:] == 0).all()
+    kw["do_sample"] = False
+    kw.pop("eos_schedule")
+    monkeypatch.setenv("BRA_SAMPLE_TILES", "0")
+    want = m.generate(input_ids=ids, attention_mask=mask, **mm, **kw)
+    monkeypatch.setenv("BRA_SAMPLE_TILES", "1")
+    got = m.generate(input_ids=ids, attention_mask=mask, **mm, **kw)
+    assert torch.equal(got.cpu(), want.cpu())
+
+
 def test_decode_with_more_than_eight_sequences(backend):
     """12 sequences (2 prompts x 6 copies): the streaming projections run their 16-row form (16-column tiles, packed + norm-folded
     weights, 16-row statistics) under the shared-prefix attention; same choices as the op-by-op decode under teacher forcing"""
