@@ -29,6 +29,10 @@ struct DecOneArgs {
     float eps, scale;
     const int* t_ptr;                       // optional device-side t (graph replay: constant launch arguments)
     float inv_Hq, inv_npc, inv_Hkv, inv_ncc, inv_copies;   // reciprocals for the item decomposition (da_div)
+    // More than 16 query rows per (prompt, kv-head) — Qwen3-4B: 8 rollouts x G = 4 — are handled as `rsplit` VIRTUAL prompts per
+    // prompt: R and copies above are the virtual counts (R = prompts x rsplit, copies = rollouts / rsplit, copies x G <= 16); virtual
+    // prompt r reads the K / V^T / mask of prompt r / rsplit; sequence b = r x copies + copy is unchanged (rollouts are consecutive)
+    int rsplit; float inv_rsplit;
 };
 
 // The launch is latency-bound (one wave per item, a few microseconds in all): every instruction between kernel entry and the
@@ -302,10 +306,11 @@ __device__ __forceinline__ void dec_item_decode(const DecOneArgs& a, int w, cons
         w -= nK;
         const int q1 = da_div(w, a.inv_npc), c = w - q1 * a.npc;
         const int r = da_div(q1, a.inv_Hkv), hkv = q1 - r * a.Hkv;
+        const int rp = a.rsplit > 1 ? da_div(r, a.inv_rsplit) : r;          // the prompt whose K / V^T this virtual prompt reads
         d.kind = 2;
-        d.kbase = a.kp + r * a.kp_sr + hkv * a.kp_sh; d.kss = (int)a.kp_ss;
-        d.vbase = a.vtp + r * a.vt_sr + hkv * a.vt_sh; d.vsd = (int)a.vt_sd;
-        d.key0 = c * 64; d.nkeys = a.P; d.mask = a.pmask ? a.pmask + (long)r * a.P : nullptr;
+        d.kbase = a.kp + rp * a.kp_sr + hkv * a.kp_sh; d.kss = (int)a.kp_ss;
+        d.vbase = a.vtp + rp * a.vt_sr + hkv * a.vt_sh; d.vsd = (int)a.vt_sd;
+        d.key0 = c * 64; d.nkeys = a.P; d.mask = a.pmask ? a.pmask + (long)rp * a.P : nullptr;
         d.r = r; d.hkv = hkv; d.row_lo = 0; d.row_hi = 16; d.slot = c;
         return;
     }

@@ -49,7 +49,13 @@ extern "C" int bra_dec_attn_one(const void* qkv, long ldqkv, const void* qw, con
                                 int Hq, int Hkv, int hd, int P, int C, int t, float eps, float scale, const int* t_dev, void* stream) {
     if (R <= 0 || copies <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || P <= 0 || t < 0 || t >= C) return BRA_ERR_ARG;
     const int G = Hq / Hkv;
-    if (copies * G > 16) return BRA_ERR_UNSUPPORTED;
+    // more than 16 query rows per (prompt, kv-head): split the rollouts of a prompt into `rsplit` virtual prompts of <= 16 / G each
+    int rsplit = 1;
+    while (rsplit <= copies && (copies % rsplit || (copies / rsplit) * G > 16)) ++rsplit;
+    if (rsplit > copies || G > 16) return BRA_ERR_UNSUPPORTED;
+    const int R_phys = R;
+    R *= rsplit; copies /= rsplit;
+    (void)R_phys;
     if (!qkv || !qw || !kw || !cosT || !sinT || !pos || !kp || !vtp || !kc || !vct || !part_o || !part_ml || !o) return BRA_ERR_ARG;
     const int npc = (P + 63) / 64, ncc = (t + 63) / 64;
     if (vt_sd < (long)npc * 64 || vt_sd % 8 || kp_ss % 8 || cp < ((C + 63) / 64) * 64 || cp % 8 || ldqkv % 8 || ldo % 4) return BRA_ERR_ARG;
@@ -58,7 +64,8 @@ extern "C" int bra_dec_attn_one(const void* qkv, long ldqkv, const void* qw, con
                     (const bf16_t*)kp, kp_sr, kp_sh, kp_ss, (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask,
                     (bf16_t*)kc, (bf16_t*)vct, cp, part_o, part_ml, (bf16_t*)o, ldo,
                     R, copies, Hq, Hkv, P, C, t, nslot, npc, ncc, eps, scale, t_dev,
-                    1.f / (float)Hq, 1.f / (float)npc, 1.f / (float)Hkv, 1.f / (float)(ncc > 0 ? ncc : 1), 1.f / (float)copies};
+                    1.f / (float)Hq, 1.f / (float)npc, 1.f / (float)Hkv, 1.f / (float)(ncc > 0 ? ncc : 1), 1.f / (float)copies,
+                    rsplit, 1.f / (float)rsplit};
     bra_stream_t st = (bra_stream_t)stream;
     const int nitems = npc * Hkv * R + ncc * copies * Hkv * R + R * copies * Hq;
     // 24-bit factors / 32-bit element offsets inside one (prompt, kv-head) block, one activation matrix, the partial buffers

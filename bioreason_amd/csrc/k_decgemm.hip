@@ -328,7 +328,8 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     //  projection runs 16 waves to keep the single register round)
     const int nw = (WIDE && nsteps >= 128) ? 16 : (nsteps >= 64 ? 8 : 4);
     const int spw = (nsteps + nw - 1) / nw;
-    const int nl = (spw >= 12 && spw % 12 == 0) ? 12 : (spw > 4 ? 8 : 4);
+    const int nl = (spw >= 12 && spw % 12 == 0) ? 12 : (spw == 10 ? 10 : (spw > 4 ? 8 : 4));     // (10: K = 2560, Qwen3-4B's hidden size)
+    if (nl == 10 && nw != 8) return BRA_ERR_UNSUPPORTED;                                         // (only the 8-wave form is instantiated)
     if (NORM == 2 && (nsteps + nw * nl - 1) / (nw * nl) != 1) return BRA_ERR_UNSUPPORTED;     // folded norm: single-round path only
     const int ntiles = MODE ? g.N / 8 : (g.N + 15) / 16;
     // one workgroup of 8 waves (two of 4) per CU, looping over the tiles; the 16-wave form takes one tile per workgroup
@@ -354,7 +355,7 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     if (nw == 16) {
         if constexpr (WIDE != 0) { if (nl == 12) BRA_DG2(16, 12); else if (nl == 8) BRA_DG2(16, 8); else BRA_DG2(16, 4); }
     }
-    else if (nw == 8) { if (nl == 12) BRA_DG2(8, 12); else if (nl == 8) BRA_DG2(8, 8); else BRA_DG2(8, 4); }
+    else if (nw == 8) { if (nl == 12) BRA_DG2(8, 12); else if (nl == 10) BRA_DG2(8, 10); else if (nl == 8) BRA_DG2(8, 8); else BRA_DG2(8, 4); }
     else { if (nl == 12) BRA_DG2(4, 12); else if (nl == 8) BRA_DG2(4, 8); else BRA_DG2(4, 4); }
 #undef BRA_DG2
     return BRA_LAUNCH_STATUS();
@@ -384,7 +385,9 @@ extern "C" int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, 
     if (norm_w && (!ss_in || nss_in < 32 || nss_in % 32 || nss_in > 256)) return BRA_ERR_ARG;
     if (res && ldres % 4) return BRA_ERR_ARG;
     const bool wide = M > 8;                     // 9 .. 16 rows: 16-column tiles everywhere (a diagonal tile holds 8 rows)
-    const bool diag = !wide && !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256;
+    // 8-column (diagonal) tiles where 16-column tiles would leave CUs idle — as long as the N / 8 statistics partials they emit still
+    // fit the 256 a consumer folds (N = 2560, Qwen3-4B: 16-column tiles, 160 workgroups)
+    const bool diag = !wide && !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256 && N / 8 <= 256;
     if (ss_out && nss_out < (diag ? N / 8 : (N + 15) / 16)) return BRA_ERR_ARG;
     DecGemm2Args g = {(const bf16_t*)x, ldx, ss_in, nss_in, (const bf16_t*)norm_w, eps, (const bf16_t*)W, ldw,
                       (const bf16_t*)res, ldres, out, ldo, ss_out, nss_out, M, N, K, packed, (unsigned long long*)probe, 1.f / (float)K};
@@ -429,7 +432,7 @@ extern "C" int bra_dec_pack_weights(const void* W, long ldw, int N, int K, int a
 extern "C" int bra_dec_pack_weights_rows(const void* W, long ldw, int N, int K, int act, int out_f32, const void* norm_w, int rows,
                                          void* out, void* stream) {
     if (!W || !out || N <= 0 || K <= 0 || ldw % 8 || rows <= 0 || rows > 16) return BRA_ERR_ARG;
-    const bool diag = rows <= 8 && !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256;      // bra_dec_gemm2's rule
+    const bool diag = rows <= 8 && !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256 && N / 8 <= 256;      // bra_dec_gemm2's rule
     if (N % (diag ? 8 : 16) || K % (diag ? 64 : 32)) return BRA_ERR_UNSUPPORTED;
     const long nchunk = (long)N * K / 8;
     const dim3 grid((unsigned)((nchunk + 255) / 256));

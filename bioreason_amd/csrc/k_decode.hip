@@ -77,7 +77,7 @@ struct StepGemms {
 };
 static StepGemms step_gemms(float* ss_ws, int nss, int B, int H, int Nq, int Nqkv, int F, int V, float eps, void* stream) {
     StepGemms s;
-    const int nblk = (H % 8 == 0 && (H + 15) / 16 < 256) ? H / 8 : (H + 15) / 16;      // workgroups of an N = H projection
+    const int nblk = (H % 8 == 0 && (H + 15) / 16 < 256 && H / 8 <= 256) ? H / 8 : (H + 15) / 16;      // workgroups of an N = H projection (bra_dec_gemm2's tile rule)
     s.v2 = ss_ws && B <= 16 && nss >= 32 && nss % 32 == 0 && nss <= 256 && nss >= nblk;
     // two statistics arrays [rows][nss], rows = 8 or (9 .. 16 sequences) 16
     s.ssx = ss_ws; s.ssh = ss_ws ? ss_ws + (B > 8 ? 16 : 8) * (long)nss : nullptr; s.nss = nss;

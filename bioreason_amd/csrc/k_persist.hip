@@ -620,7 +620,10 @@ extern "C" int bra_qwen_layers_persist(const void* layers_dev, int L, int R, int
         if (ncu < NWG) return BRA_ERR_UNSUPPORTED;                  /* every workgroup must be resident */                        \
         for (int lo = first; lo < last; lo += win) {                                                                                \
             a.ph_lo = lo; a.ph_hi = lo + win < last ? lo + win : last;                                                            \
-            hipError_t e = hipMemsetAsync(sync, 0, sizeof(GridSync), st);                                                         \
+            /* counters and generations restart with every launch; `err` is STICKY: a barrier that gave up in ANY token step */ \
+            /* stays visible to the host's check after the rollout (the caller zeroes the whole buffer once per rollout), and */ \
+            /* every later barrier returns at once instead of spinning to its own timeout */                                     \
+            hipError_t e = hipMemsetAsync(sync, 0, offsetof(GridSync, err), st);                                                  \
             if (e != hipSuccess) return (int)e;                                                                                   \
             if (prefetch <= 0) BRA_LAUNCH((decode_persist_kernel<H_, NQ_, NKV_, F_, HD_, G_, 0>), dim3(NWG), dim3(512), 0, st, a); \
             else if (prefetch == 1) BRA_LAUNCH((decode_persist_kernel<H_, NQ_, NKV_, F_, HD_, G_, 1>), dim3(NWG), dim3(512), 0, st, a); \

@@ -185,7 +185,9 @@ class QwenEngine:
     def _down(x2d, A, scaling, n_targets):
         """s x A^T -> [rows, r_pad] (A = the adapter image [r_pad, K], one 32-row block per target)"""
         if x2d.shape[0] < QwenEngine.SMALL_M and A.shape[0] in (32, 64, 128):
-            return ops.lora_down_drop(x2d, A, scaling, 0.0, [0] * n_targets)
+            # p = 0: EVERY 32-row rank block of the image is live, whatever the adapters' rank (r = 64: one target spans two
+            # blocks; r = 16 x 3 targets: 48 rows in two blocks) — the kernel zeroes the blocks past the seeds it is given
+            return ops.lora_down_drop(x2d, A, scaling, 0.0, [0] * (A.shape[0] // 32))
         return ops.gemm_nt(x2d, A, alpha=scaling)
 
     @staticmethod

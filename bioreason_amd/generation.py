@@ -254,8 +254,10 @@ class SharedDecodeState:
         self.part_ml = torch.empty((B, eng.Hq, nch, 2), dtype=torch.float32, device=dev)
         self.cosT, self.sinT = eng.rope(P + C + 1)
         # persistent form of the layer loop (k_persist.hip): ONE launch for all decoder layers, bit-identical to the launched path.
-        # BRA_DEC_PERSIST: "0" launched kernels, "1" / "2" / "3" persistent with prefetch level 0 / 1 / 2; default: persistent where the
-        # kernel is instantiated for the shape (<= 8 sequences, packed + folded weights, one CU per workgroup)
+        # BRA_DEC_PERSIST: "0" (default) launched kernels; "1" / "2" / "3" opt into the persistent step with prefetch level 0 / 1 / 2
+        # where the kernel is instantiated for the shape (<= 8 sequences, packed + folded weights, one CU per workgroup) — measured
+        # slower than the launched step.  `sync` is zeroed here, once per rollout: the kernel's error word is
+        # sticky across the token steps, so persist_timed_out() after the loop sees a timeout of ANY step
         self.persist = None
         mode = os.environ.get("BRA_DEC_PERSIST", "0")
         if mode != "0" and self.attn_impl == "one" and use_packed and B <= 8 and all(Rw.get("folded") for Rw in self.rw) and dev.type == "cuda":
@@ -311,7 +313,7 @@ def _packed_ok(B: int, rw) -> bool:
 def _norm_stat_ws(eng, dev, rows: int = 8):
     """zeroed workspace [2][8 | 16][nss] of RMSNorm partial sums of squares for the bra_dec_gemm2 projections (None, 0: the
     hidden size has more column workgroups than the 256 partials a consumer folds -> first-generation kernels)"""
-    nblk = eng.H // 8 if (eng.H % 8 == 0 and (eng.H + 15) // 16 < 256) else (eng.H + 15) // 16
+    nblk = eng.H // 8 if (eng.H % 8 == 0 and (eng.H + 15) // 16 < 256 and eng.H // 8 <= 256) else (eng.H + 15) // 16
     nss = (nblk + 31) // 32 * 32
     if nss > 256 or os.environ.get("BRA_DEC_GEMM_V1") == "1":
         return None, 0
@@ -407,8 +409,12 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     kmask[:, :P] = am.to(torch.uint8)
     shared = None
     grp = _uniform_groups(prompt_alias) if prompt_alias is not None else None
-    use_shared = (grp is not None and shared_prefix_decode and native_step and decode_impl == "fused" and eng.hd >= 64
-                  and grp[1] * (eng.Hq // eng.Hkv) <= 16)
+    # (more than 16 query rows per (prompt, kv-head) — Qwen3-4B: 8 rollouts x G = 4 — run as virtual prompts of <= 16 rows each in
+    #  bra_dec_attn_one; the first-generation attention keeps the 16-row limit)
+    G_ = eng.Hq // eng.Hkv
+    rows_ok = grp is not None and (grp[1] * G_ <= 16 or (os.environ.get("BRA_DEC_ATTN", "one") == "one" and G_ <= 16
+                                                          and any(grp[1] % s_ == 0 and (grp[1] // s_) * G_ <= 16 for s_ in range(1, grp[1] + 1))))
+    use_shared = (grp is not None and shared_prefix_decode and native_step and decode_impl == "fused" and eng.hd >= 64 and rows_ok)
     if prompt_alias is None:
         cache = KVCache(eng, B, Smax, dev)
         hid = prefill(model, inputs_embeds, attention_mask, cache, pos_prompt)

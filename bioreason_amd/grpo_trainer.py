@@ -16,6 +16,7 @@ selects them (grpo_trainer.py:256-274).
 from __future__ import annotations
 
 import os
+import math
 import time
 from collections import defaultdict
 from dataclasses import dataclass, field
@@ -293,7 +294,7 @@ class DNALLMGRPOTrainer:
         sampler = self._get_train_sampler()
         gmb_ = per_rank * self.world
         steps_per_epoch = max(1, (len(sampler) // gmb_) // ga)
-        total = max_steps if max_steps is not None else max(1, int(a.num_train_epochs * steps_per_epoch))
+        total = max_steps if max_steps is not None else max(1, math.ceil(a.num_train_epochs * steps_per_epoch))   # (HF Trainer: math.ceil)
         self.runner.lr_schedule = self._lr_schedule(total)
         for epoch in range(epochs):
             stream = list(iter(sampler))
@@ -307,7 +308,9 @@ class DNALLMGRPOTrainer:
                 if self.runner.global_step != step_before:
                     gs = self.runner.global_step
                     if a.logging_steps and (gs % max(1, int(a.logging_steps)) == 0 or (a.logging_first_step and gs == 1)):
-                        self.log({"loss": float(loss), "learning_rate": self.runner.last_lr,
+                        # HF logs `_get_learning_rate()` AFTER `lr_scheduler.step()`: the rate of the NEXT optimiser step
+                        lr_next = self.runner.lr_schedule(gs) if self.runner.lr_schedule is not None else self.runner.last_lr
+                        self.log({"loss": float(loss), "learning_rate": float(lr_next),
                                   "epoch": epoch + lo / max(1, len(stream))})
                     if a.save_steps and a.save_strategy != "no" and gs % int(a.save_steps) == 0:
                         for cb in self.callbacks:

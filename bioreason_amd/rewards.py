@@ -67,16 +67,29 @@ reward_funcs_registry: Dict[str, Callable] = {
 }
 
 
-def text_reward_fn(tokenizer, names: List[str], prompts=None, answer=None) -> Callable:
-    """adapter for `GRPOStepRunner(reward_fn=...)`: decodes the sampled ids (skip_special_tokens, as
-    grpo_trainer.py:642-647 does) and evaluates the named reward functions -> fp32 [B, len(names)]"""
-    funcs = [reward_funcs_registry[n] for n in names]
+def reward_hop(processing_class, reward_funcs: List[Callable], prompts=None, extra: Optional[Dict[str, list]] = None) -> Callable:
+    """THE reward hop of the reference (grpo_trainer.py:643-676), the one implementation both entry points below use:
+    completion ids -> host -> `batch_decode(..., skip_special_tokens=True)` -> python reward functions -> [B, F] fp32 back on
+    the device.  Completions are wrapped as one-message conversations only for conversational prompts
+    (`is_conversational(inputs[0])`, :646-649: the prompt is a list of role / content messages); plain-string prompts hand the
+    reward functions plain strings.  `prompts` None (synthetic runs without a prompt column): the conversational shape, which is
+    what reason.py's reward functions take."""
+    conversational = bool(prompts) and isinstance(prompts[0], (list, tuple)) and len(prompts[0]) > 0 \
+        and isinstance(prompts[0][0], dict) and "role" in prompts[0][0] and "content" in prompts[0][0]
+    if prompts is None:
+        conversational = True
 
     def fn(completion_ids: torch.Tensor, completion_mask: torch.Tensor) -> torch.Tensor:
-        ids = completion_ids.masked_fill(completion_mask == 0, tokenizer.pad_token_id).tolist()
-        texts = tokenizer.batch_decode(ids, skip_special_tokens=True)
-        completions = [[{"role": "assistant", "content": t}] for t in texts]
-        cols = [f(prompts=prompts, completions=completions, answer=answer) for f in funcs]
-        return torch.tensor(cols, dtype=torch.float32, device=completion_ids.device).t().contiguous()
-
+        texts = processing_class.batch_decode(completion_ids.cpu().tolist(), skip_special_tokens=True)
+        completions = [[{"role": "assistant", "content": t}] for t in texts] if conversational else texts
+        cols = [f(prompts=prompts, completions=completions, **(extra or {})) for f in reward_funcs]
+        return torch.tensor(cols, dtype=torch.float32).t().contiguous().to(completion_ids.device)
     return fn
+
+
+def text_reward_fn(tokenizer, names: List[str], prompts=None, answer=None) -> Callable:
+    """`reward_hop` for reward functions named as in reason.py's registry (:312-320), with the `answer` dataset column
+    (`GRPOStepRunner(reward_fn=...)` of synthetic runs; a list of None prompts counts as no prompt column)"""
+    if prompts is not None and all(p is None for p in prompts):
+        prompts = None
+    return reward_hop(tokenizer, [reward_funcs_registry[n] for n in names], prompts=prompts, extra={"answer": answer})

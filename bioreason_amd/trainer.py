@@ -84,22 +84,7 @@ def token_stat_rewards(completion_ids: torch.Tensor, completion_mask: torch.Tens
     return torch.stack([r0, r1], dim=1)
 
 
-def text_reward_fn(processing_class, reward_funcs: List[Callable], prompts=None, extra: Optional[Dict[str, list]] = None) -> Callable:
-    """The reference's reward hop (grpo_trainer.py:643-676): completion ids -> host -> batch_decode -> python reward
-    functions -> [B, F] fp32 back on the device.  Completions are wrapped as one-message conversations only for conversational
-    prompts (`is_conversational(inputs[0])`, :646-649: the prompt is a list of role / content messages); plain-string prompts
-    hand the reward functions plain strings."""
-    conversational = bool(prompts) and isinstance(prompts[0], (list, tuple)) and len(prompts[0]) > 0 \
-        and isinstance(prompts[0][0], dict) and "role" in prompts[0][0] and "content" in prompts[0][0]
-    if prompts is None:
-        conversational = True              # synthetic runs without a prompt column: the shape reason.py's reward functions take
-
-    def fn(completion_ids: torch.Tensor, completion_mask: torch.Tensor) -> torch.Tensor:
-        texts = processing_class.batch_decode(completion_ids.cpu(), skip_special_tokens=True)
-        completions = [[{"role": "assistant", "content": t}] for t in texts] if conversational else texts
-        cols = [f(prompts=prompts, completions=completions, **(extra or {})) for f in reward_funcs]
-        return torch.tensor(cols, dtype=torch.float32).t().contiguous().to(completion_ids.device)
-    return fn
+from .rewards import reward_hop as text_reward_fn      # noqa: E402  (the reference's reward hop; ONE implementation, rewards.py)
 
 
 # =============================================================================================== data-parallel plumbing
@@ -221,7 +206,11 @@ class GRPOStepRunner(_DataParallelStep):
         return self._side[which]
 
     # ---- _generate_and_score_completions (:535-749) ---------------------------------------------------------------
-    def generate_and_score(self, batch: Dict, timing: bool = False, mark=lambda n: None) -> Dict:
+    def generate_and_score(self, batch: Dict, timing: bool = False, mark=lambda n: None, defer_ref_join: bool = False) -> Dict:
+        """`defer_ref_join` (step() only): the reference pass may still be running on its side stream when this returns — the
+        returned dict then carries the stream under "ref_join" and `compute_loss` joins it just before the loss reads
+        `ref_per_token_logps`.  Every other caller gets the join here: whatever it reads from the dict is complete on the
+        current stream."""
         m, c = self.model, self.cfg
         dev = batch["input_ids"].device
         mm = {"dna_tokenized": batch["dna_tokenized"], "batch_idx_map": batch["batch_idx_map"], "dna_alias": batch.get("dna_alias")}
@@ -299,6 +288,10 @@ class GRPOStepRunner(_DataParallelStep):
         adv, gmean, gstd = grpo.group_advantages(all_rewards, c.num_generations, self.rank, B)
         roll_metrics = torch.stack([packed_all[:, F].mean(), all_rewards.sum(1).mean(), gstd.mean()])
         mark("rewards")
+        if ref_join is not None and not defer_ref_join:
+            torch.cuda.current_stream(dev).wait_stream(ref_join)
+            ref_lp.record_stream(torch.cuda.current_stream(dev))
+            ref_join = None
         return {"prompt_ids": prompt_ids, "prompt_mask": prompt_mask, "completion_ids": completion_ids, "completion_mask": cmask,
                 "old_per_token_logps": old_lp, "ref_per_token_logps": ref_lp, "advantages": adv, "multimodal_inputs": mm,
                 "prompt_alias": batch.get("prompt_alias"), "ref_join": ref_join,
@@ -337,7 +330,7 @@ class GRPOStepRunner(_DataParallelStep):
         slot = self._step % ga
         mark("start")
         if self.global_step % c.num_iterations == 0:
-            inputs = self.generate_and_score(batch, timing, mark)
+            inputs = self.generate_and_score(batch, timing, mark, defer_ref_join=True)
             self._buffered_inputs[slot] = inputs
         else:
             inputs = self._buffered_inputs[slot]

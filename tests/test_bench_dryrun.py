@@ -49,6 +49,24 @@ def test_two_rank_self_launch_prints_one_line(emu_lib_path):
     assert d["metrics"]["completion_length"] == 3.0
 
 
+def test_eight_rank_self_launch_prints_one_line(emu_lib_path):
+    """the command the driver's SCALE record runs — `python bench.py --gpus 8` (the reference: `deepspeed --num_gpus=8 reason.py`,
+    sh_reason.sh:38-44) — with eight processes: rendezvous, argument forwarding, both collectives at world size 8, MAX-reduce of
+    the elapsed time, ONE line from rank 0"""
+    r = _run(["--gpus", "8", "--steps", "1", "--warmup", "1", "--completion-len", "2"], extra_env={"BRA_EMU_THREADS": "1"}, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, "exactly one JSON line (rank 0) expected, got %d" % len(lines)
+    d = lines[0]
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 8 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dryrun"] is True
+    assert d["config"]["parallelism"] == "dp8" and d["config"]["completion_len"] == 2
+    assert d["config"]["global_batch"] == 8 * 2                                                 # G = 2 rows per rank in the dry run
+    assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] / 1000.0)) < 1e-6 * d["value"]
+    assert "sft" not in d and "straggler" not in d
+
+
 def test_single_process_line_carries_the_secondary_legs(emu_lib_path):
     r = _run(["--steps", "1", "--warmup", "1", "--secondary-steps", "1", "--completion-len", "4"])
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]

@@ -123,6 +123,76 @@ def test_grpo_step_two_ranks_shared_prompt_groups(emu_lib_path):
         assert abs(mets[3] - want_loss) < 1e-5 * max(1.0, abs(want_loss)) and ncuts >= 1
 
 
+def _worker_uneven(rank, world, port, emu_path, q):
+    """4 ranks x 3 local rows, G = 4: the three groups of the global batch span the ranks UNEVENLY (rows 0-3 = rank 0 + one row of
+    rank 1; rows 4-7 = two of rank 1 + two of rank 2; rows 8-11 = one of rank 2 + rank 3) — the layout accelerate's contiguous
+    per-rank slices of RepeatRandomSampler's stream give when per_device_train_batch_size is not a multiple of G
+    (grpo_trainer.py:428-437 only asks (W x B_local) % G == 0; the advantages of :682-699 use the GATHERED rewards)"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BRA_EMU_THREADS="1")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bioreason_amd import _lib
+    _lib.use_library_for_tests(emu_path)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_model_parity import build, to_dev
+    from bioreason_amd.trainer import GRPOConfig, GRPOStepRunner
+    fix = torch.load(os.path.join(GOLD, "tiny_a.pt"), weights_only=False)
+    m = build(fix, torch.device("cpu"), True)
+    b0 = to_dev(fix["batch"], torch.device("cpu"))
+    b0.pop("labels")
+    rows = [(rank + j) % 2 for j in range(3)]                       # three local rows drawn from the fixture's two samples
+    dsel, bmap = [], []
+    for j, r in enumerate(rows):
+        for i, s_ in enumerate(b0["batch_idx_map"]):
+            if s_ == r:
+                dsel.append(i)
+                bmap.append(j)
+    b = {"input_ids": b0["input_ids"][rows], "attention_mask": b0["attention_mask"][rows],
+         "dna_tokenized": {k: v[dsel] for k, v in b0["dna_tokenized"].items()}, "batch_idx_map": bmap}
+    seen = {}
+
+    def reward(ids, mask):
+        r = torch.stack([(ids[:, 0] % 5).float() + 0.5 * rank, (ids[:, 1] % 3).float()], dim=1)
+        seen["local"] = r.clone()
+        return r
+
+    G = 4
+    runner = GRPOStepRunner(m, GRPOConfig(num_generations=G, max_completion_length=3, eos_token_id=None, seed=7, learning_rate=1e-3), reward)
+    out = runner.step(b)
+    gathered = [torch.empty_like(seen["local"]) for _ in range(world)]
+    dist.all_gather(gathered, seen["local"])
+    allr = torch.cat(gathered, 0).sum(1)                             # [12]
+    grp = allr.view(-1, G)
+    want_adv = ((allr - grp.mean(1).repeat_interleave(G)) / (grp.std(1).repeat_interleave(G) + 1e-4))[rank * 3:(rank + 1) * 3]
+    params = [torch.empty_like(m.arena.params) for _ in range(world)]
+    dist.all_gather(params, m.arena.params)
+    mets = [torch.empty_like(out["metrics_t"]) for _ in range(world)]
+    dist.all_gather(mets, out["metrics_t"])
+    got_adv = runner._buffered_inputs[0]["advantages"]
+    q.put((rank, all(bool(torch.equal(params[0], p_)) for p_ in params), all(bool(torch.equal(mets[0], m_)) for m_ in mets),
+           want_adv.tolist(), got_adv.tolist(), float(out["metrics_t"][1]), float(allr.mean())))
+    dist.destroy_process_group()
+
+
+def test_grpo_step_four_ranks_groups_span_ranks_unevenly(emu_lib_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_uneven, args=(r, 4, port, emu_lib_path, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=1500) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same_p, same_m, want_adv, got_adv, reward_mean, want_reward in res:
+        assert same_p, "replicas diverged after the optimiser step"
+        assert same_m, "metric record differs across ranks"
+        assert torch.allclose(torch.tensor(got_adv), torch.tensor(want_adv), atol=1e-5), (rank, got_adv, want_adv)
+        assert abs(reward_mean - want_reward) < 1e-5
+
+
 def _single_rank_worker(port, emu_path, q, dp):
     """one process; dp: a ONE-rank gloo group with BRA_DP_SINGLE_RANK=1 (every collective of the step issued, each the identity) — or no
     process group at all"""

@@ -971,6 +971,41 @@ def test_dec_attn_items_and_merge(backend, hd, Hq, Hkv, R, copies, P, C, t, use_
     assert rel(o.view(B, Hq, hd), ref) < 6e-3
 
 
+@pytest.mark.parametrize("r,n_targets", [(64, 1), (16, 3), (32, 3), (8, 2), (40, 3)])
+def test_lora_branch_without_dropout_at_any_rank(backend, r, n_targets):
+    """the no-dropout LoRA branch (engine._lora_fwd / _lora_bwd: x A^T, dy B through the row-block kernel below 8192 rows)
+    must be right for EVERY adapter rank, not just r = 32 — `lora_r` / `lora_rank` are user options of the reference
+    (train_dna_qwen.py:155-167, reason.py:376-388).  Compared with the plain GEMM statement of y = x W^T + s (x A^T) B^T."""
+    from bioreason_amd.engine import QwenEngine
+    M, K, Nj = 70, 96, 64
+    r_pad = (n_targets * r + 63) // 64 * 64
+    x, W = rnd(M, K, dev=backend), rnd(n_targets * Nj, K, dev=backend, scale=K ** -0.5)
+    A = torch.zeros(r_pad, K, dtype=BF, device=backend)
+    B_ = torch.zeros(n_targets * Nj, r_pad, dtype=BF, device=backend)
+    for j in range(n_targets):
+        A[j * r:(j + 1) * r] = rnd(r, K, dev=backend, scale=K ** -0.5, seed=j + 1)
+        B_[j * Nj:(j + 1) * Nj, j * r:(j + 1) * r] = rnd(Nj, r, dev=backend, scale=0.3, seed=j + 9)
+
+    class G:                                            # the fields of engine.LoraGroup the branch reads
+        pass
+    G.A, G.AT, G.B, G.BT = A, A.T.contiguous(), B_, B_.T.contiguous()
+    G.scaling, G.n_sizes, G.r = 2.0, [Nj] * n_targets, r
+    G.A_grad = torch.zeros(r_pad, K, device=backend)
+    G.B_grad = torch.zeros(n_targets * Nj, r_pad, device=backend)
+    y, t = QwenEngine._lora_fwd(x, W, G, True)
+    t_ref = 2.0 * (x.float() @ A.float().T)
+    assert rel(t, t_ref) < 4e-3, "x A^T: rank columns past the first 32 of a target (or past target count x 32) must be live"
+    y_ref = x.float() @ W.float().T + t_ref.to(BF).float() @ B_.float().T
+    assert rel(y, y_ref) < 6e-3
+    dy = rnd(M, n_targets * Nj, dev=backend, seed=77)
+    dx = QwenEngine._lora_bwd(dy, W.T.contiguous(), G, True, x, t)
+    dts_ref = 2.0 * (dy.float() @ B_.float())
+    dx_ref = dy.float() @ W.float() + dts_ref.to(BF).float() @ A.float()
+    assert rel(dx, dx_ref) < 6e-3
+    assert rel(G.A_grad, dts_ref.to(BF).float().T @ x.float()) < 6e-3
+    assert rel(G.B_grad, dy.float().T @ t.float()) < 6e-3
+
+
 @pytest.mark.parametrize("R,nlive", [(64, 1), (128, 3)])
 def test_lora_dropout_padded_rank_blocks(backend, R, nlive):
     """a fused projection pads its rank to 64 / 128 columns (o, down: 1 target in 64; q/k/v: 3 in 128): the kernels are told

@@ -72,8 +72,11 @@ def test_text_reward_adapter():
             words = {1: "<think>\n", 2: "x", 3: "\n</think>\n", 4: "cancer", 5: "\n"}
             return ["".join(words.get(i, "") for i in row) for row in ids]
 
-    fn = R.text_reward_fn(Tok(), ["xmlcount", "strict_format", "correctness"], prompts=[[{"content": "q"}]], answer=[["cancer", "cancer"]])
-    ids = torch.tensor([[1, 2, 3, 4, 5], [2, 2, 4, 9, 9]])
+    # (conversational prompts — role / content messages — as TRL's is_conversational tests them, grpo_trainer.py:646-649; the ids
+    #  behind a row's EOS are pad tokens, as generate leaves them: the reference decodes completion_ids unmasked, :644)
+    fn = R.text_reward_fn(Tok(), ["xmlcount", "strict_format", "correctness"], prompts=[[{"role": "user", "content": "q"}]] * 2,
+                          answer=[["cancer", "cancer"]])
+    ids = torch.tensor([[1, 2, 3, 4, 5], [2, 2, 0, 0, 0]])
     mask = torch.tensor([[1, 1, 1, 1, 1], [1, 1, 0, 0, 0]])
     out = fn(ids, mask)
     assert out.shape == (2, 3) and out.dtype == torch.float32

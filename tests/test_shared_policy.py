@@ -214,7 +214,7 @@ def test_ref_pass_on_side_stream_equals_main_stream(hip_device):
         m = build(fix, dev, True)
         runner = GRPOStepRunner(m, GRPOConfig(num_generations=2, max_completion_length=6, eos_token_id=None, seed=3, learning_rate=1e-3,
                                               overlap_ref_pass=overlap))
-        inputs = runner.generate_and_score(batch)
+        inputs = runner.generate_and_score(batch, defer_ref_join=True)
         if overlap:
             assert inputs["ref_join"] is not None
             torch.cuda.current_stream(dev).wait_stream(inputs["ref_join"])

@@ -21,7 +21,7 @@ for it in range(4):
             continue
         if isinstance(v, dict) and "input_ids" in v:
             batch = v
-    inputs = runner.generate_and_score(batch)
+    inputs = runner.generate_and_score(batch, defer_ref_join=True)
     lp = grpo.per_token_logps_shared_policy(model, inputs["prompt_ids"], inputs["prompt_mask"], inputs["completion_ids"],
                                             inputs["completion_mask"], inputs["prompt_alias"], **inputs["multimodal_inputs"])
     torch.cuda.current_stream(dev).wait_stream(inputs["ref_join"])
