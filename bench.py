@@ -491,6 +491,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary `sft` / `straggler` legs of the default run")
     ap.add_argument("--secondary-steps", type=int, default=5)
+    ap.add_argument("--no-qwen3-4b", action="store_true", help="skip the secondary `qwen3_4b` leg (the cfg-3 step with Qwen3-4B as the text model)")
     ap.add_argument("--no-graph", action="store_true", help="issue the rollout's decode steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-shared-decode", action="store_true", help="per-copy prompt K/V in the decode attention")
     ap.add_argument("--overlap-ref-chains", action="store_true", help="(experiment) the two chains of the reference pass on two streams as well")
@@ -632,6 +633,29 @@ def main():
                             "workload": "BASELINE config 2 (train_dna_qwen.py:179-213): B=%d distinct samples, P=%d, full-row lm_head "
                                         "logits + shifted CE on the last %d positions, backward, AdamW" % (f_B, dims.P, dims.label_tail)}
         del f_runner, f_step
+        if not dims.dry and not args.no_qwen3_4b:
+            # the LLM half of BASELINE configs 4-5 that needs no Evo2 oracle (README.md:84 "NT-500M + Qwen3-4B"): the cfg-3 GRPO
+            # step with Qwen3-4B (36 x 2560, 32 q / 8 kv heads, F = 9728) behind the same NT-v2-500M encoder.  Built after the
+            # headline model is done with its legs; 1 warm-up + `q_S` timed steps.
+            import gc
+            from bioreason_amd import configs as _cfgs
+            q_dims = Dims(False)
+            q_dims.text = dict(_cfgs.QWEN3_4B)
+            try:
+                q_model = build_model(q_dims, dev, args.lora_dropout)
+                q_S = max(1, min(3, S))
+                q_runner, q_step, q_B = make_grpo_leg(q_model, q_dims, R, Cn, rank, dev, args, None, q_S + 3)
+                q_el, _ = timed_steps(q_step, q_S, 2, 1, dev)
+                secondary["qwen3_4b"] = {"value": q_B * q_S / q_el, "unit": "samples/s", "ms_per_step": 1000.0 * q_el / q_S, "steps": q_S, "warmup": 2,
+                                         "workload": "the headline GRPO step (1 prompt x G=8, P=%d, C=%d, LoRA r=32 dropout %g, shared-prompt policy "
+                                                     "pass) with Qwen3-4B as the text model: 36 layers x 2560, 32 q-heads / 8 kv-heads (32 query rows "
+                                                     "per (prompt, kv-head) in the decode attention), intermediate 9728; NT-v2-500M encoder; random-init "
+                                                     "weights" % (q_dims.P, Cn, args.lora_dropout)}
+                del q_runner, q_step, q_model
+            except Exception as e:                    # (a secondary leg must never take the headline line down with it)
+                secondary["qwen3_4b"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            gc.collect()
+            torch.cuda.empty_cache()
 
     if rank == 0:
         samples = world * samples_per_step * args.steps

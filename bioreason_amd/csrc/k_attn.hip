@@ -101,7 +101,16 @@ __device__ __forceinline__ void store_trans(char* lds, const u32x4 (&r)[(HD * 8)
 #pragma unroll
     for (int i = 0; i < (HD * 8) / NT; ++i) {
         int q = tid + NT * i;
-        st16(lds + Tile<HD>::toff(q >> 3, q & 7), r[i]);
+        // rows d and d + 16 share (d & 1, (d >> 1) & 7), i.e. the banks of their 16-byte chunks: the two 8-byte halves of a chunk
+        // are swapped in rows with bit 4 set, so that the 8-byte fragment reads of 32 consecutive rows touch 64 distinct banks
+#ifdef BRA_ATTN_NO_HALF_SWAP           // (A/B builds only)
+        const bool sw = false;
+#else
+        const bool sw = ((q >> 3) >> 4) & 1;
+#endif
+        u32x4 v = r[i], w;
+        w.x = sw ? v.z : v.x; w.y = sw ? v.w : v.y; w.z = sw ? v.x : v.z; w.w = sw ? v.y : v.w;
+        st16(lds + Tile<HD>::toff(q >> 3, q & 7), w);
     }
 }
 
@@ -115,7 +124,11 @@ __device__ __forceinline__ u32x4 frag_rows(const char* lds, int rbase, int ds, i
 // register order of a 32x32 C/D fragment: {16s + 4h + 0..3, 16s + 4h + 8 + 0..3}, h = lane >> 5
 template <int HD>
 __device__ __forceinline__ u32x4 frag_trans(const char* lds, int dbase, int s, int lane) {
+#ifdef BRA_ATTN_NO_HALF_SWAP
     const int d = dbase + (lane & 31), h = lane >> 5;
+#else
+    const int d = dbase + (lane & 31), h = (lane >> 5) ^ ((d >> 4) & 1);     // (halves swapped in rows with bit 4 set: store_trans)
+#endif
     u32x2 p0 = ld8(lds + Tile<HD>::toff(d, 2 * s) + 8 * h);
     u32x2 p1 = ld8(lds + Tile<HD>::toff(d, 2 * s + 1) + 8 * h);
     u32x4 o; o.x = p0.x; o.y = p0.y; o.z = p1.x; o.w = p1.y;
@@ -131,6 +144,25 @@ __device__ __forceinline__ uint64_t key_valid_word(const AttnArgs& a, int b, int
     return wave_ballot(ok);
 }
 
+
+// Workgroup -> (sequence block, head, batch row) in DISPATCH order (x fastest, then y, z): the sequence block is the SLOWEST
+// coordinate and, under a causal mask, blocks are taken heaviest first — query block i of a causal pass visits i + 1 key tiles
+// (key block j is visited by the query tiles behind it), so with the block index fastest the heaviest workgroup of the last
+// (batch, head) pair started last and the chip idled behind it (B = 8, S = 2436: ~87 tile-units of makespan for 49 of work per slot).
+// Neighbouring workgroups are the heads of one batch row: the q-heads of a kv-group still share their K / V tiles in L2.
+__device__ __forceinline__ void attn_block_coords(int heavy_is_last, int& blk, int& head, int& b) {
+    const int nblk = (int)gridDim.x, nh = (int)gridDim.y, nb = (int)gridDim.z;
+    const int id = (int)blockIdx.x + nblk * ((int)blockIdx.y + nh * (int)blockIdx.z);
+    const int per = nh * nb;
+    const int x = id / per, rem = id - x * per;
+    blk = heavy_is_last ? nblk - 1 - x : x;
+    b = rem / nh;
+    head = rem - b * nh;
+#ifdef BRA_ATTN_LEGACY_ORDER          // (A/B builds only: block index fastest, as rounds 1-3 launched it)
+    blk = (int)blockIdx.x; head = (int)blockIdx.y; b = (int)blockIdx.z;
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // forward
 // NW waves per workgroup (32 queries each); 8 waves = 2 per SIMD share one staged K / V^T tile
@@ -140,8 +172,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
     constexpr int NT = NW * 64, QROWS = NW * 32;
     BRA_DYN_SMEM(smem);   // [2][K tile | V^T tile]
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int b = (int)blockIdx.z, hq = (int)blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
-    const int q0 = (int)blockIdx.x * QROWS;
+    int bx_, hq, b;
+    attn_block_coords(a.causal, bx_, hq, b);
+    const int hkv = hq / (a.Hq / a.Hkv);
+    const int q0 = bx_ * QROWS;
     const int qw0 = q0 + wave * 32;
     const int qi = qw0 + (lane & 31);                 // this lane's query
     const bf16_t* kb_ = a.k + b * a.k_sb + hkv * a.k_sh;
@@ -313,8 +347,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs a) {
     BRA_DYN_SMEM(smem);   // [2][K tile | V tile | K^T tile]
     constexpr int STAGE = 2 * T::KBYTES + T::TBYTES;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int b = (int)blockIdx.z, hq = (int)blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
-    const int q0 = (int)blockIdx.x * QROWS;
+    int bx_, hq, b;
+    attn_block_coords(a.causal, bx_, hq, b);
+    const int hkv = hq / (a.Hq / a.Hkv);
+    const int q0 = bx_ * QROWS;
     const int qw0 = q0 + wave * 32;
     const int qi = qw0 + (lane & 31);
     const int qr = qi < a.Sq ? qi : a.Sq - 1;
@@ -459,9 +495,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr int OFF_L = OFF_DT + (DV ? T::TBYTES : 0);
     constexpr int STAGE = OFF_L + 512;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int b = (int)blockIdx.z, hkv = (int)blockIdx.y;
+    int bx_, hkv, b;
+    attn_block_coords(0, bx_, hkv, b);                // (causal: key block 0 is the heaviest — ascending order is heaviest first)
     const int group = a.Hq / a.Hkv;
-    const int k0 = (int)blockIdx.x * KROWS;
+    const int k0 = bx_ * KROWS;
     const int kw0 = k0 + wave * 32;
     const int kj = kw0 + (lane & 31);                 // this lane's key
     const int kr = kj < a.Sk ? kj : a.Sk - 1;

@@ -233,8 +233,14 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(BRA_DG2_HEAD_PARAMS,
 #pragma unroll
             for (int u = 0; u < NL; ++u) st[u] = base + (MODE ? wave + NW * u : 2 * (wave + NW * (u >> 1)) + (u & 1));
             u32x4 w[NL], x[NL], nv[NL];
+            // (packed weights: chunk ((tile * nsteps + step) * 64 + lane) holds the lane's 8 elements of (tile, step) — K beyond one
+            //  register round, e.g. Qwen3-4B's o / down projections, walks the same image round by round)
+            const bf16_t* wpk = g.W + ((long)tile * nsteps * 64 + lane) * 8;
 #pragma unroll
-            for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; w[u] = ld16_nt(wp + (long)sc * KS); }
+            for (int u = 0; u < NL; ++u) {
+                const int sc = st[u] < nsteps ? st[u] : nsteps - 1;
+                w[u] = PK ? ld16_nt(wpk + (long)sc * 512) : ld16_nt(wp + (long)sc * KS);
+            }
 #pragma unroll
             for (int u = 0; u < NL; ++u) { const int sc = st[u] < nsteps ? st[u] : nsteps - 1; x[u] = ld16(xp + (long)sc * KS); }
             if (NORM == 1) {
@@ -335,7 +341,8 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     // one workgroup of 8 waves (two of 4) per CU, looping over the tiles; the 16-wave form takes one tile per workgroup
     const int gmax = nw == 16 ? ntiles : (nw >= 8 ? 256 : 512);
     const dim3 grid(ntiles < gmax ? ntiles : gmax);
-    if (WIDE && (nsteps + nw * nl - 1) / (nw * nl) != 1) return BRA_ERR_UNSUPPORTED;          // wide rows: single-round path only
+    // (wide rows beyond one register round — Qwen3-4B's down projection, K = 9728 — take the generic multi-round loop like 8 rows;
+    //  only the folded-norm form, refused above, is tied to the single-round path)
     // fast form: see the kernel; everything it assumes is checked here
     const bool fits32 = g.ldx < (1 << 24) && g.ldres < (1 << 24) && 16 * g.ldx < (1L << 30) && 16 * g.ldres + g.N < (1L << 30) &&
                         16L * g.nss_in < (1L << 24);

@@ -289,7 +289,7 @@ class DNALLMModel(nn.Module):
             if k in generation_kwargs and generation_kwargs[k] is not None:
                 kw[k] = generation_kwargs[k]
         for k in ("seed", "check_every", "return_full_length", "force_tokens", "native_step", "decode_impl", "prompt_alias",
-                  "use_graph", "shared_prefix_decode", "profile", "eos_schedule", "loop_events"):
+                  "use_graph", "shared_prefix_decode", "profile", "eos_schedule", "loop_events", "trace_logits"):
             if k in generation_kwargs:
                 kw[k] = generation_kwargs[k]
         if not kw.get("do_sample", False):

@@ -21,7 +21,7 @@ import torch
 
 from . import ops
 from ._lib import current_stream, get_lib
-from .engine import BF16, QwenEngine, SeqMeta
+from .engine import BF16, QwenEngine, SeqMeta, _nullctx
 
 
 class KVCache:
@@ -38,6 +38,50 @@ def prefill(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, ca
     eng = model.ensure_packed()
     B, S, H = inputs_embeds.shape
     kmask = attention_mask.to(torch.uint8).contiguous()
+    dev = inputs_embeds.device
+    # A few prompts (GRPO: ONE distinct prompt per GPU) give every kernel of the chain a grid of ~144 workgroups on 256 CUs.  The
+    # rows are then run as TWO chunks — [0, Sa) and [Sa, S) — on two HIP streams, chunk B one layer behind chunk A: B's queries attend
+    # to A's K / V rows of the same layer (one event per layer), both chains are in flight together and fill the chip.  Same kernels
+    # on the same rows: every row's result is the one-chunk result (rows of a GEMM are independent, a query visits its key tiles in
+    # the same order).  BRA_PREFILL_CHUNKS=1 keeps one chain.
+    two = (dev.type == "cuda" and os.environ.get("BRA_PREFILL_CHUNKS", "2") == "2" and B * S <= 4096 and S >= 1024)
+    if two or os.environ.get("BRA_PREFILL_CHUNKS_FORCE") == "2":
+        Sa = (S // 2 + 63) // 64 * 64 if S >= 256 else max(1, S // 2)
+        posm = pos.reshape(B, S)
+        ma = SeqMeta(B=B, S=Sa, pos=posm[:, :Sa].reshape(-1).contiguous(), kmask=kmask[:, :Sa].contiguous(), lora_on=model._lora_enabled,
+                     max_pos=cache.Smax + 1)
+        mb = SeqMeta(B=B, S=S - Sa, pos=posm[:, Sa:].reshape(-1).contiguous(), kmask=kmask, lora_on=model._lora_enabled,
+                     max_pos=cache.Smax + 1)
+        xe = inputs_embeds.to(BF16)
+        xa = xe[:, :Sa].reshape(B * Sa, H).contiguous()
+        xb = xe[:, Sa:].reshape(B * (S - Sa), H).contiguous()
+        side = None
+        if dev.type == "cuda":
+            side = getattr(eng, "_prefill_side", None)
+            if side is None:
+                side = eng._prefill_side = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            xb.record_stream(side)
+        for li in range(eng.L):
+            xa, _ = eng.layer_fwd(li, xa, ma, save=False, kv_out=(cache.k[li], cache.v[li], 0))
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+            with (torch.cuda.stream(side) if side is not None else _nullctx()):
+                if side is not None:
+                    side.wait_event(ev)
+                xb, _ = eng.layer_fwd(li, xb, mb, save=False, kv_out=(cache.k[li], cache.v[li], Sa, vt_sink))
+        with (torch.cuda.stream(side) if side is not None else _nullctx()):
+            last = (torch.arange(B, device=dev, dtype=torch.int32) * (S - Sa) + (S - Sa - 1))
+            out = ops.rmsnorm_fwd(ops.gather_rows(last, xb), eng.norm_w, eng.eps)
+        if side is not None:
+            main.wait_stream(side)
+            out.record_stream(main)
+            if vt_sink is not None:
+                for t_ in vt_sink:
+                    t_.record_stream(main)
+        return out
     meta = SeqMeta(B=B, S=S, pos=pos.reshape(-1).contiguous(), kmask=kmask, lora_on=model._lora_enabled,
                    max_pos=cache.Smax + 1)
     x = inputs_embeds.reshape(B * S, H).to(BF16).contiguous()

@@ -321,7 +321,12 @@ def test_shared_policy_pass_fullsize(runs):
     gr = ((g_sh - g_full).norm() / g_full.norm()).item()
     noise = max(v.get("refbf16_vs_fp32", 0.0) for k, v in RATIOS.items() if k.startswith("grad_l")) if any(k.startswith("grad_l") for k in RATIOS) else 3e-2
     RATIOS["shared_policy_vs_full"] = {"logps_maxabs": d, "grads_rel": gr, "grad_noise_refbf16": noise}
-    assert d <= 0.06, d
+    # two bf16 executions of the same pass: their largest log-prob difference over the 4 x C positions is bounded by the reference's
+    # OWN largest bf16 deviation from fp32 on these rows (measured in test_per_token_logps_fullsize; a max over 8x more positions
+    # than round 3's C = 32 is heavier-tailed than the fixed 0.06 it was held to)
+    d_ref = RATIOS.get("logps_maxabs", {}).get("refbf16", 0.04)
+    RATIOS["shared_policy_vs_full"]["logps_maxabs_refbf16"] = d_ref
+    assert d <= 2.0 * d_ref + 1e-3, (d, d_ref)
     assert gr <= 1.5 * noise, (gr, noise)       # the two passes differ by where bf16 roundings of dK / dV fall: inside the gradients' own bf16 noise
 
 

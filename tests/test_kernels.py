@@ -513,6 +513,29 @@ def test_dec_gemm2_packed_weights(backend, M, N, K, act, f32):
     assert rel(y2, yr) < 1.5e-2 and rel(y2, y0) < 1.5e-2
 
 
+@pytest.mark.parametrize("M,N,K,f32", [(8, 64, 9728, 0), (6, 64, 4096, 1), (8, 2560, 4096, 0), (8, 2560, 9728, 0), (12, 64, 4096, 1), (12, 64, 9728, 0),
+                                       (16, 2560, 9728, 0)])
+def test_dec_gemm2_packed_weights_beyond_one_register_round(backend, M, N, K, f32):
+    """Qwen3-4B widths: o_proj (K = 4096) and down_proj (K = 9728) need more k-steps than one register round of the streaming
+    projection holds (waves x chunks); the multi-round path must walk the fragment-packed image too (it used to address it as
+    row-major: silently wrong products)"""
+    if backend.type == "cpu" and N * K > 9000000:
+        pytest.skip("emulator: small shapes only")
+    x, W = rnd(M, K, dev=backend), rnd(N, K, dev=backend, scale=0.05)
+    r = None if f32 else rnd(M, N, dev=backend)
+    rows = 16 if M > 8 else 8
+    Wp = ops.dec_pack_weights(W, out_f32=bool(f32), rows=rows)
+    assert Wp is not None
+    y0, _ = ops.dec_gemm2(x, W, res=r, out_f32=bool(f32))
+    y1, s1 = ops.dec_gemm2(x, Wp, res=r, out_f32=bool(f32), packed=True, want_ss=not f32)
+    ref = x.float() @ W.float().T
+    if r is not None:
+        ref = ref.to(BF).float() + r.float()
+    assert rel(y1, ref) < 5e-3 and rel(y1, y0) < 5e-3
+    if not f32:
+        assert rel(s1[:M].sum(1), (y1.float() ** 2).sum(1)) < 1e-2
+
+
 def test_sampler_two_eos_ids_and_forced_token(backend):
     """a row finishes on EITHER listed EOS id (HF accepts a list; Qwen3's generation_config has two); bra_force_token raises
     one logit at the scheduled step only"""

@@ -344,6 +344,30 @@ def test_rollout_with_tile_maxima_sampler_equals_full_scan_sampler(backend, monk
     assert torch.equal(got.cpu(), want.cpu())
 
 
+@pytest.mark.parametrize("alias", [None, [0, 0, 2, 2]])
+def test_two_chunk_prefill_equals_one_chunk(backend, monkeypatch, alias):
+    """the prompt run as two row chunks, the second attending to the first's K / V rows of the same layer (on the GPU: two HIP
+    streams, one layer apart), leaves the same cache and the same first logits as the one-chain prefill: identical greedy tokens and
+    per-step logits (TF:qwen3:367-427 with a cache, TF:generation/utils.py:2261)"""
+    fix = torch.load(os.path.join(GOLD, "tiny_b.pt"), weights_only=False)
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    rows = [0, 0, 1, 1]
+    ids, mask = b["input_ids"][rows], b["attention_mask"][rows]
+    dna = {k: v[rows] for k, v in b["dna_tokenized"].items()}
+    mm = {"dna_tokenized": dna, "batch_idx_map": [0, 1, 2, 3]}
+    kw = dict(max_new_tokens=5, do_sample=False, eos_token_id=None, use_graph=False, prompt_alias=alias)
+    out = {}
+    for mode in ("1", "2"):
+        monkeypatch.setenv("BRA_PREFILL_CHUNKS", mode)
+        monkeypatch.setenv("BRA_PREFILL_CHUNKS_FORCE", mode)
+        tr = []
+        toks = m.generate(input_ids=ids, attention_mask=mask, **mm, trace_logits=tr, **kw)
+        out[mode] = (toks.cpu(), torch.stack([t.cpu() for t in tr]))
+    assert torch.equal(out["1"][0], out["2"][0])
+    assert torch.equal(out["1"][1], out["2"][1]), (out["1"][1] - out["2"][1]).abs().max()
+
+
 def test_decode_with_more_than_eight_sequences(backend):
     """12 sequences (2 prompts x 6 copies): the streaming projections run their 16-row form (16-column tiles, packed + norm-folded
     weights, 16-row statistics) under the shared-prefix attention; same choices as the op-by-op decode under teacher forcing"""

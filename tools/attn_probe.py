@@ -1,30 +1,49 @@
-"""Attention kernels at the bench shape (B=8, S=2436, 16 q-heads / 8 kv-heads, hd 128, causal): ms and TFLOP/s of
-bra_attn_fwd and bra_attn_bwd (dQ kernel + dK/dV kernel); run under rocprofv3 for per-kernel numbers."""
-import os, sys, time
+"""Attention kernels at the shapes the steps launch them with (16 q-heads / 8 kv-heads, hd 128, causal):
+  full      B = 8, S = 2436            the full-row policy pass / SFT (1280 forward workgroups)
+  prompt    B = 1, S = 2180            the prompt segment of a shared-prompt pass, the rollout's prefill (144 workgroups)
+  compl     B = 8, Sq = 256, Sk = 2436 the completion segment: queries attend to [prompt | own] (128 workgroups)
+ms and TFLOP/s (causal FLOPs = the visible half) of bra_attn_fwd and bra_attn_bwd (delta + 3 transposes + dQ + dK/dV); run under
+rocprofv3 for per-kernel numbers.  AP_SHAPES=full,prompt,compl selects; AP_CHECK=1 compares the forward with an fp32 torch statement."""
+import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bioreason_amd import ops
+from bioreason_amd import ops, _lib
+if os.environ.get("AP_LIB"):                      # A/B against another build of the library (e.g. libbioreason_hip_base.so)
+    _lib._LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), os.environ["AP_LIB"])
 
 dev = torch.device("cuda:0")
-B, S, Hq, Hkv, hd = int(os.environ.get("AP_B", 8)), int(os.environ.get("AP_S", 2436)), 16, 8, 128
+Hq, Hkv, hd = int(os.environ.get("AP_HQ", 16)), int(os.environ.get("AP_HKV", 8)), 128
 g = torch.Generator(device="cpu").manual_seed(0)
 def rnd(*s): return (torch.randn(*s, generator=g) * 0.5).to(torch.bfloat16).to(dev)
-q, k, v, do = rnd(B, S, Hq, hd), rnd(B, S, Hkv, hd), rnd(B, S, Hkv, hd), rnd(B, S, Hq, hd)
-kmask = torch.ones((B, S), dtype=torch.uint8, device=dev)
 scale = hd ** -0.5
-vt = ops.head_transpose(v)
-fl_fwd = 4.0 * B * Hq * S * S * hd / 2
-def timeit(fn, n=5):
+def timeit(fn, n=int(os.environ.get("AP_N", 8))):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-o, lse = ops.attn_fwd(q, k, vt, kmask, True, scale)
-ms = timeit(lambda: ops.attn_fwd(q, k, vt, kmask, True, scale))
-print("fwd ms %.3f  TFLOP/s %.1f" % (ms, fl_fwd / ms / 1e9), flush=True)
-ms = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, kmask, True, scale))
-print("bwd (delta + 3 transposes + dq + dkv) ms %.3f  TFLOP/s (2.5x fwd flops) %.1f" % (ms, 2.5 * fl_fwd / ms / 1e9), flush=True)
-dq, dk, dv = ops.attn_bwd(q, k, v, o, do, lse, kmask, True, scale)
-print("checksums dq %.6e dk %.6e dv %.6e" % (dq.float().abs().sum().item(), dk.float().abs().sum().item(), dv.float().abs().sum().item()))
+
+SHAPES = {"full": (8, 2436, 2436), "prompt": (1, 2180, 2180), "compl": (8, 256, 2436)}
+for name in os.environ.get("AP_SHAPES", "full,prompt,compl").split(","):
+    B, Sq, Sk = SHAPES[name]
+    q, k, v, do = rnd(B, Sq, Hq, hd), rnd(B, Sk, Hkv, hd), rnd(B, Sk, Hkv, hd), rnd(B, Sq, Hq, hd)
+    kmask = torch.ones((B, Sk), dtype=torch.uint8, device=dev)
+    vt = ops.head_transpose(v)
+    off = Sk - Sq
+    pairs = Sq * off + Sq * (Sq + 1) / 2                     # visible (query, key) pairs per (batch, head)
+    fl = 4.0 * B * Hq * pairs * hd
+    o, lse = ops.attn_fwd(q, k, vt, kmask, True, scale)
+    ms = timeit(lambda: ops.attn_fwd(q, k, vt, kmask, True, scale))
+    print(f"{name:7s} fwd ms {ms:.3f}  TFLOP/s {fl / ms / 1e9:.1f}", flush=True)
+    msb = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, kmask, True, scale))
+    print(f"{name:7s} bwd (delta + 3 transposes + dq + dkv) ms {msb:.3f}  TFLOP/s (2.5x fwd flops) {2.5 * fl / msb / 1e9:.1f}", flush=True)
+    if os.environ.get("AP_CHECK") == "1" and B * Sq * Sk <= 8 * 256 * 2436:
+        qf, kf, vf = q.float(), k.float().repeat_interleave(Hq // Hkv, 2), v.float().repeat_interleave(Hq // Hkv, 2)
+        sc = torch.einsum("bqhd,bkhd->bhqk", qf, kf) * scale
+        vis = torch.arange(Sk, device=dev)[None, :] <= (torch.arange(Sq, device=dev)[:, None] + off)
+        sc = sc.masked_fill(~vis, float("-inf"))
+        ref = torch.einsum("bhqk,bkhd->bqhd", sc.softmax(-1), vf)
+        print(f"{name:7s} fwd rel err vs fp32 {float((o.float() - ref).norm() / ref.norm()):.3e}", flush=True)
+    dq, dk, dv = ops.attn_bwd(q, k, v, o, do, lse, kmask, True, scale)
+    print(f"{name:7s} checksums o {o.float().abs().sum().item():.6e} dq {dq.float().abs().sum().item():.6e} dk {dk.float().abs().sum().item():.6e} dv {dv.float().abs().sum().item():.6e}", flush=True)
