@@ -687,8 +687,9 @@ def main():
             "roofline_mfma": {"bound": "mfma", "achieved": prof["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": prof["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "flops_per_launch": prof["flops_per_launch"], "algorithmic_bytes_per_launch": prof["bytes_per_launch"],
-                         "kernel": "gemm_ring_kernel<...> (256x256 LDS-ring MFMA tiles; carries most of the family's time) + "
-                                   "gemm_glds_kernel<...> (256x128: under-filled grids, row-split remainders) — every projection / "
+                         "kernel": "gemm_ring_kernel<...> (256x256 LDS-ring MFMA tiles) + gemm_glds_kernel<..., MI> (LDS-DMA tiles of "
+                                   "256 / 192 / 128 rows x 128 columns, height chosen per call so that the one-prompt shapes M = 2180 / "
+                                   "2048 fill the 256 CUs; row-split remainders) — every projection / "
                                    "lm_head GEMM of the prefill, ref, policy forward and backward passes that fills the chip; "
                                    "one launch = one API call (bra_gemm_bf16_nt)",
                          "launches": prof["launches"], "avg_launch_ms": prof["avg_launch_ms"],

@@ -84,6 +84,10 @@ class KernelLibrary:
             f.restype = ctypes.c_int
             f.argtypes = [ctypes.c_void_p if k == "ptr" else _CTYPES[k] for k, _ in args]
             self._fn[name] = f
+        # per function: (foreign function, number of arguments, indices of the pointer arguments) — the step issues thousands of
+        # these calls from Python, so the per-call work is kept to one pass over the pointer arguments only
+        self._fast = {name: (self._fn[name], len(args), tuple(i for i, (k, _) in enumerate(args) if k == "ptr"))
+                      for name, args in self.protos.items()}
 
     def call_rc(self, name: str, *args) -> int:
         """like call(), but hands BRA_ERR_UNSUPPORTED (-2) back to the caller instead of raising"""
@@ -95,26 +99,29 @@ class KernelLibrary:
             raise
 
     def call(self, name: str, *args) -> int:
-        f = self._fn[name]
-        proto = self.protos[name]
-        if len(args) != len(proto):
-            raise TypeError(f"{name}: expected {len(proto)} arguments, got {len(args)}")
-        conv = []
-        for (kind, aname), a in zip(proto, args):
-            if kind == "ptr":
-                if a is None:
-                    conv.append(None)
-                elif isinstance(a, torch.Tensor):
-                    if not self.emulated and not a.is_cuda:
-                        raise RuntimeError(f"{name}: argument {aname} is a CPU tensor; the HIP library needs device memory")
-                    conv.append(a.data_ptr())
-                else:
-                    conv.append(int(a))
-            elif kind == "float":
-                conv.append(float(a))
+        f, n, ptrs = self._fast[name]
+        if len(args) != n:
+            raise TypeError(f"{name}: expected {n} arguments, got {len(args)}")
+        conv = list(args)                      # ints / floats go to ctypes as they are (argtypes convert them)
+        check = not self.emulated
+        for i in ptrs:
+            a = conv[i]
+            if a is None:
+                continue
+            if isinstance(a, torch.Tensor):
+                if check and not a.is_cuda:
+                    raise RuntimeError(f"{name}: argument {self.protos[name][i][1]} is a CPU tensor; the HIP library needs device memory")
+                conv[i] = a.data_ptr()
             else:
-                conv.append(int(a))
-        rc = f(*conv)
+                conv[i] = int(a)
+        try:
+            rc = f(*conv)
+        except (ctypes.ArgumentError, TypeError):
+            # an argument ctypes cannot coerce by itself (a float where the prototype says int, a 0-d tensor, ...): convert by kind
+            for i, (kind, _) in enumerate(self.protos[name]):
+                if kind != "ptr":
+                    conv[i] = float(conv[i]) if kind == "float" else int(conv[i])
+            rc = f(*conv)
         if rc != 0:
             raise KernelError(name, rc)
         return rc

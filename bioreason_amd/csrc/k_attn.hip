@@ -101,16 +101,9 @@ __device__ __forceinline__ void store_trans(char* lds, const u32x4 (&r)[(HD * 8)
 #pragma unroll
     for (int i = 0; i < (HD * 8) / NT; ++i) {
         int q = tid + NT * i;
-        // rows d and d + 16 share (d & 1, (d >> 1) & 7), i.e. the banks of their 16-byte chunks: the two 8-byte halves of a chunk
-        // are swapped in rows with bit 4 set, so that the 8-byte fragment reads of 32 consecutive rows touch 64 distinct banks
-#ifdef BRA_ATTN_NO_HALF_SWAP           // (A/B builds only)
-        const bool sw = false;
-#else
-        const bool sw = ((q >> 3) >> 4) & 1;
-#endif
-        u32x4 v = r[i], w;
-        w.x = sw ? v.z : v.x; w.y = sw ? v.w : v.y; w.z = sw ? v.x : v.z; w.w = sw ? v.y : v.w;
-        st16(lds + Tile<HD>::toff(q >> 3, q & 7), w);
+        // (measured, round 4: swapping the 8-byte halves of a chunk in rows with bit 4 set — on paper rows d and d + 16 share the banks
+        //  of their chunks under the 8-byte fragment reads — changed nothing at B = 8 and cost the 4-wave dK / dV kernel 15-22 %)
+        st16(lds + Tile<HD>::toff(q >> 3, q & 7), r[i]);
     }
 }
 
@@ -124,11 +117,7 @@ __device__ __forceinline__ u32x4 frag_rows(const char* lds, int rbase, int ds, i
 // register order of a 32x32 C/D fragment: {16s + 4h + 0..3, 16s + 4h + 8 + 0..3}, h = lane >> 5
 template <int HD>
 __device__ __forceinline__ u32x4 frag_trans(const char* lds, int dbase, int s, int lane) {
-#ifdef BRA_ATTN_NO_HALF_SWAP
     const int d = dbase + (lane & 31), h = lane >> 5;
-#else
-    const int d = dbase + (lane & 31), h = (lane >> 5) ^ ((d >> 4) & 1);     // (halves swapped in rows with bit 4 set: store_trans)
-#endif
     u32x2 p0 = ld8(lds + Tile<HD>::toff(d, 2 * s) + 8 * h);
     u32x2 p1 = ld8(lds + Tile<HD>::toff(d, 2 * s + 1) + 8 * h);
     u32x4 o; o.x = p0.x; o.y = p0.y; o.z = p1.x; o.w = p1.y;

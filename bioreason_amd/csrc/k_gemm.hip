@@ -522,9 +522,14 @@ __global__ __launch_bounds__(BM * 2) void gemm_nt_kernel(GemmArgs g) {
 // lane l lands at (row l>>3, physical chunk l&7) and therefore fetches logical chunk (l&7) ^ (l>>3).
 // SKEW: fragment reads of the next half K-step are issued before the MFMAs of the current one (the barrier sits
 // between the two halves), so LDS latency hides behind matrix work instead of stalling both waves of a SIMD at once.
-template <int EPI, int SKEW>
+// MI (round 4): fragments of 16 rows per wave, i.e. the tile is BM = 64 MI rows high — 256 (MI = 4, the original), 192 or 128.  One
+// prompt x eight rollouts gives the step's GEMMs M = 2180 / 2048 rows: at N = 2048 a 256-row tile leaves 144 / 128 workgroups on 256
+// CUs; 192-row tiles cover M = 2180 with 12 x 16 = 192 workgroups of 3/4 the work each, 128-row tiles cover M = 2048 with exactly 256.
+// Same K order per output element in every variant (bit-identical results); the smaller tiles pay more fragment reads per MFMA
+// (MI + 4 reads for 4 MI MFMAs) and more L2 -> LDS bytes per flop, which is why they are picked only where they fill the chip.
+template <int EPI, int SKEW, int MI = 4>
 __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmArgs g) {
-    constexpr int BM = 256, BN = 128, BK = 64;
+    constexpr int BM = 64 * MI, BN = 128, BK = 64;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     BRA_DYN_SMEM(smem);
     const int tid = (int)threadIdx.x;
@@ -556,55 +561,59 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmArgs g) {
     }
     const int nt = kt_end - kt_begin;
 
-    // per-lane source rows of this wave's 4 A pieces and 2 B pieces (clamped: rows past M / N are never stored)
+    // per-lane source rows of this wave's MI A pieces and 2 B pieces (clamped: rows past M / N are never stored); a piece = 8 rows
     const int prow = lane >> 3, lchunk = ((lane & 7) ^ (lane >> 3)) * 8;
-    int rowA[4], rowB[2];          // rows only (6 VGPRs): nothing here may spill — a scratch reload in the K loop
+    int rowA[MI], rowB[2];         // rows only: nothing here may spill — a scratch reload in the K loop
 #pragma unroll                     // carries a vmcnt(0) that would drain the DMA queue
-    for (int j = 0; j < 4; ++j) { int r = m0 + wave * 32 + j * 8 + prow; rowA[j] = r < g.M ? r : g.M - 1; }
+    for (int j = 0; j < MI; ++j) { int r = m0 + wave * (8 * MI) + j * 8 + prow; rowA[j] = r < g.M ? r : g.M - 1; }
 #pragma unroll
     for (int j = 0; j < 2; ++j) { int r = n0 + wave * 16 + j * 8 + prow; rowB[j] = r < g.N ? r : g.N - 1; }
     auto issue = [&](int kt, int stage) {
-        char* sa = smem + stage * STAGE + wave * (32 * 128);
+        char* sa = smem + stage * STAGE + wave * (8 * MI * 128);
         char* sb = smem + stage * STAGE + A_BYTES + wave * (16 * 128);
         const bool main = kt < nk1;
         const bf16_t* Ap = (main ? g.A : g.A2) + (long)(main ? kt : kt - nk1) * BK + lchunk;
         const bf16_t* Bp = (main ? g.B : g.B2) + (long)(main ? kt : kt - nk1) * BK + lchunk;
         const long la = main ? g.lda : g.lda2, lb = main ? g.ldb : g.ldb2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(Ap + (long)rowA[j] * la, sa + j * 1024);
+        for (int j = 0; j < MI; ++j) glds16(Ap + (long)rowA[j] * la, sa + j * 1024);
 #pragma unroll
         for (int j = 0; j < 2; ++j) glds16(Bp + (long)rowB[j] * lb, sb + j * 1024);
     };
+    constexpr int NDMA = MI + 2;   // wave-instructions per K-tile issue: the counted waits below keep ONE tile in flight
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][MI];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
     auto compute = [&](int stage) {
         const char* sa = smem + stage * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
-            u32x4 fa[4], fb[4];
+            u32x4 fa[MI], fb[4];
             const int c = kk * 4 + fq;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int rowa = wm * 64 + i * 16 + fr;
-                int rowb = wn * 64 + i * 16 + fr;
+            for (int i = 0; i < MI; ++i) {
+                int rowa = wm * (16 * MI) + i * 16 + fr;
                 fa[i] = ld16(sa + rowa * 128 + swz_chunk<64>(rowa, c) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int rowb = wn * 64 + i * 16 + fr;
                 fb[i] = ld16(sb + rowb * 128 + swz_chunk<64>(rowb, c) * 16);
             }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma_16x16x32(fb[ni], fa[mi], acc[ni][mi]);
+                for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = mfma_16x16x32(fb[ni], fa[mi], acc[ni][mi]);
         }
     };
 
     issue(kt_begin, 0);
-    if (nt > 1) { issue(kt_begin + 1, 1); wait_vmcnt<6>(); } else { wait_vmcnt<0>(); }
+    if (nt > 1) { issue(kt_begin + 1, 1); wait_vmcnt<NDMA>(); } else { wait_vmcnt<0>(); }
     raw_barrier();
     int stage = 0;
     if (!SKEW) {
@@ -613,32 +622,35 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmArgs g) {
             const bool ahead = t + 2 < nt;
             if (ahead) issue(kt_begin + t + 2, s2);        // stage s2 was last read during step t-1: every wave is past that barrier
             compute(stage);
-            if (ahead) wait_vmcnt<6>(); else wait_vmcnt<0>();   // tile t+1 has landed; tile t+2 may still be in flight
+            if (ahead) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();   // tile t+1 has landed; tile t+2 may still be in flight
             raw_barrier();
             stage = stage + 1 == 3 ? 0 : stage + 1;
         }
     } else {
-        auto read_frags = [&](int stg, int kk, u32x4 (&fa)[4], u32x4 (&fb)[4]) {
+        auto read_frags = [&](int stg, int kk, u32x4 (&fa)[MI], u32x4 (&fb)[4]) {
             const char* sa = smem + stg * STAGE;
             const char* sb = sa + A_BYTES;
             const int c = kk * 4 + fq;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int rowa = wm * 64 + i * 16 + fr;
-                int rowb = wn * 64 + i * 16 + fr;
+            for (int i = 0; i < MI; ++i) {
+                int rowa = wm * (16 * MI) + i * 16 + fr;
                 fa[i] = ld16(sa + rowa * 128 + swz_chunk<64>(rowa, c) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int rowb = wn * 64 + i * 16 + fr;
                 fb[i] = ld16(sb + rowb * 128 + swz_chunk<64>(rowb, c) * 16);
             }
         };
-        auto mma = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[4]) {
+        auto mma = [&](const u32x4 (&fa)[MI], const u32x4 (&fb)[4]) {
             setprio(1);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma_16x16x32(fb[ni], fa[mi], acc[ni][mi]);
+                for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = mfma_16x16x32(fb[ni], fa[mi], acc[ni][mi]);
             setprio(0);
         };
-        u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+        u32x4 fa0[MI], fb0[4], fa1[MI], fb1[4];
         read_frags(0, 0, fa0, fb0);
         for (int t = 0; t < nt; ++t) {
             int s2 = stage + 2; s2 = s2 >= 3 ? s2 - 3 : s2;
@@ -647,14 +659,14 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmArgs g) {
             if (ahead) issue(kt_begin + t + 2, s2);
             read_frags(stage, 1, fa1, fb1);
             mma(fa0, fb0);
-            if (ahead) wait_vmcnt<6>(); else wait_vmcnt<0>();
+            if (ahead) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();
             raw_barrier();                                   // all reads of `stage` are done, tile t+1 has landed
             if (t + 1 < nt) read_frags(s1, 0, fa0, fb0);
             mma(fa1, fb1);
             stage = s1;
         }
     }
-    gemm_epilogue<EPI>(g, acc, m0, n0, wm, wn, lane, tile_n);
+    gemm_epilogue_w<EPI, MI>(g, acc, m0 + wm * (16 * MI), n0 + wn * 64, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -976,6 +988,10 @@ static int pick_variant(const GemmArgs& g) {
         if (t >= 140 && (t <= 256 || 100 * t >= ring_min_fill_pct * rounds * 256)) return 6;
     }
     if (g.K % 64 == 0 && g.K2 % 64 == 0 && tiles256 >= 128) return 5;
+    // (round 4) the LDS-DMA kernel at 128-row tiles where 256-row tiles are too few: encoder o / ffn-down at 2052 rows x N = 1024 —
+    // 136 tiles: 276 / 409 TFLOP/s against 217 / 293 for the register-staged kernel (profiles/r4_gemm_variants_smallm.txt)
+    const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
+    if (g.K % 64 == 0 && g.K2 % 64 == 0 && tiles128 >= 128) return 5;
     return 0;
 }
 
@@ -990,20 +1006,51 @@ static int launch_gemm_v(const GemmArgs& g, bra_stream_t stream) {
     return BRA_LAUNCH_STATUS();
 }
 
-template <int EPI>
-static int launch_glds(const GemmArgs& g, bra_stream_t stream) {
-    const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
+// tile height of the LDS-DMA kernel for this call: 256, 192 or 128 rows (see gemm_glds_kernel).  Cost model = rounds of 256 workgroups
+// x rows per tile / relative efficiency of the tile; it reproduces the fastest height of every shape measured with
+// tools/gemm_variants.py GV_SMALLM=1 (profiles/r4_gemm_variants_smallm.txt: M = 2180 -> 192 rows at N = 2048: +17-20 %; M = 2048 -> 128 rows: +39-42 %);
+// ties go to the taller tile.  bra_gemm_set_variant(9 / 10) pins 192 / 128 for A/B runs (5 = 256).
+static knob_t<int> g_forced_glds_rows(0);
+static int pick_glds_rows(const GemmArgs& g) {
+    { const int fr = g_forced_glds_rows; if (fr) return fr; }
+    if (g_forced_variant >= 0) return 256;
+    const long tn = (g.N + 127) / 128, sk = g.split_k > 1 ? g.split_k : 1;
+    const int bms[3] = {256, 192, 128};
+    const double eff[3] = {1.0, 0.95, 0.86};
+    int best = 256;
+    double best_cost = 1e30;
+    for (int i = 0; i < 3; ++i) {
+        const long t = ((g.M + bms[i] - 1) / bms[i]) * tn * sk;
+        const double cost = (double)((t + 255) / 256) * bms[i] / eff[i];
+        if (cost < best_cost * 0.97) { best_cost = cost; best = bms[i]; }
+    }
+    return best;
+}
+
+template <int EPI, int MI>
+static int launch_glds_mi(const GemmArgs& g, bra_stream_t stream, bool skew) {
+    constexpr int BM = 64 * MI;
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + 127) / 128);
     int grid = tiles;
     if (EPI == EPI_ATOMIC) grid = tiles * (g.split_k > 0 ? g.split_k : 1);
-    const size_t smem = 3 * (size_t)(256 + 128) * 64 * 2;
-    if (pick_variant(g) >= 5) {
-        BRA_ALLOW_SMEM((gemm_glds_kernel<EPI, 1>), smem);
-        BRA_LAUNCH((gemm_glds_kernel<EPI, 1>), dim3(grid), dim3(512), smem, stream, g);
+    const size_t smem = 3 * (size_t)(BM + 128) * 64 * 2;
+    if (skew) {
+        BRA_ALLOW_SMEM((gemm_glds_kernel<EPI, 1, MI>), smem);
+        BRA_LAUNCH((gemm_glds_kernel<EPI, 1, MI>), dim3(grid), dim3(512), smem, stream, g);
     } else {
-        BRA_ALLOW_SMEM((gemm_glds_kernel<EPI, 0>), smem);
-        BRA_LAUNCH((gemm_glds_kernel<EPI, 0>), dim3(grid), dim3(512), smem, stream, g);
+        BRA_ALLOW_SMEM((gemm_glds_kernel<EPI, 0, MI>), smem);
+        BRA_LAUNCH((gemm_glds_kernel<EPI, 0, MI>), dim3(grid), dim3(512), smem, stream, g);
     }
     return BRA_LAUNCH_STATUS();
+}
+
+template <int EPI>
+static int launch_glds(const GemmArgs& g, bra_stream_t stream) {
+    const bool skew = pick_variant(g) >= 5;
+    const int rows = pick_glds_rows(g);
+    if (rows == 128) return launch_glds_mi<EPI, 2>(g, stream, skew);
+    if (rows == 192) return launch_glds_mi<EPI, 3>(g, stream, skew);
+    return launch_glds_mi<EPI, 4>(g, stream, skew);
 }
 
 template <int EPI>
@@ -1091,6 +1138,8 @@ static int check_common(const GemmArgs& g) {
 using namespace bra;
 
 extern "C" int bra_gemm_set_variant(int v) {
+    bra::g_forced_glds_rows = 0;
+    if (v == 9 || v == 10) { bra::g_forced_glds_rows = v == 9 ? 192 : 128; v = 5; }      // the LDS-DMA kernel at 192 / 128-row tiles
     bra::g_forced_variant = v;
     if (v == 6) bra::ring_two_phase = 0;                 // 6 = four-phase ring, 7 = two-phase ring (A/B measurements)
     if (v == 7 || v < 0) bra::ring_two_phase = 1;

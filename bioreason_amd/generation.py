@@ -43,8 +43,9 @@ def prefill(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, ca
     # rows are then run as TWO chunks — [0, Sa) and [Sa, S) — on two HIP streams, chunk B one layer behind chunk A: B's queries attend
     # to A's K / V rows of the same layer (one event per layer), both chains are in flight together and fill the chip.  Same kernels
     # on the same rows: every row's result is the one-chunk result (rows of a GEMM are independent, a query visits its key tiles in
-    # the same order).  BRA_PREFILL_CHUNKS=1 keeps one chain.
-    two = (dev.type == "cuda" and os.environ.get("BRA_PREFILL_CHUNKS", "2") == "2" and B * S <= 4096 and S >= 1024)
+    # the same order).  Measured at one prompt of 2180 rows (round 4, tools/decode_probe.py): 16.0 ms against 15.6 ms for one chain —
+    # the half-height GEMMs lose what the overlap gains — so it is OPT-IN (BRA_PREFILL_CHUNKS=2), kept for wider prompts.
+    two = (dev.type == "cuda" and os.environ.get("BRA_PREFILL_CHUNKS", "1") == "2" and B * S <= 4096 and S >= 1024)
     if two or os.environ.get("BRA_PREFILL_CHUNKS_FORCE") == "2":
         Sa = (S // 2 + 63) // 64 * 64 if S >= 256 else max(1, S // 2)
         posm = pos.reshape(B, S)

@@ -90,7 +90,7 @@ class GemmProfile:
 
     def wants(self, M: int, N: int, K: int, K2: int) -> bool:
         """dominant_only: exactly the launches k_gemm.hip's pick_variant() sends to the LDS-DMA MFMA kernels (gemm_ring_kernel
-        256x256 / gemm_glds_kernel 256x128, MFMA-bound); otherwise every launch with M >= min_m (that also counts the N = 32
+        256x256 / gemm_glds_kernel 256 | 192 | 128 x 128, MFMA-bound); otherwise every launch with M >= min_m (that also counts the N = 32
         LoRA projections, which are HBM-bound reads of the activations)"""
         if not self.dominant_only:
             return M >= self.min_m
@@ -100,7 +100,9 @@ class GemmProfile:
         rounds = (t + 255) // 256
         if t >= 140 and (t <= 256 or 100 * t >= 75 * rounds * 256):
             return True
-        return ((M + 255) // 256) * ((N + 127) // 128) >= 128     # ... else the 256 x 128 LDS-DMA kernel
+        if ((M + 255) // 256) * ((N + 127) // 128) >= 128:        # ... else the LDS-DMA kernel (256 / 192 / 128-row tiles) ...
+            return True
+        return ((M + 127) // 128) * ((N + 127) // 128) >= 128     # ... also where only its 128-row tiles are numerous enough (round 4)
 
     def summary(self):
         torch.cuda.synchronize()
