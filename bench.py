@@ -500,6 +500,9 @@ def main():
     ap.add_argument("--no-overlap-ref", action="store_true", help="reference-policy pass on the main stream instead of beside the policy forward")
     ap.add_argument("--no-shared-policy", action="store_true",
                     help="policy forward / backward over every row's full prompt (independent LoRA-dropout masks per copy, as the reference draws them)")
+    ap.add_argument("--round3-kernels", action="store_true",
+                    help="A/B on one box: round 3's kernel choices (256-row LDS-DMA tiles only, block-index-fastest attention grids, "
+                         "full-scan sampler + advance_counters launch); a secondary measurement, never the headline")
     ap.add_argument("--completion-len", type=int, default=None)
     ap.add_argument("--lora-dropout", type=float, default=LORA_DROPOUT, help="PEFT lora_dropout of the policy pass (reference: 0.05)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the oracle timing leg and print its JSON")
@@ -543,6 +546,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
 
     from bioreason_amd import ops
+    if args.round3_kernels:
+        from bioreason_amd._lib import get_lib
+        get_lib().call("bra_gemm_set_glds_rows", 256)
+        get_lib().call("bra_attn_set_block_order", 1)
+        os.environ["BRA_SAMPLE_TILES"] = "0"
     model = build_model(dims, dev, args.lora_dropout)
     R = args.prompts_per_gpu
     Cn = args.completion_len if args.completion_len is not None else dims.c
@@ -711,6 +719,9 @@ def main():
                         "event pairs); `achieved` above is measured inside the timed steps, where three chains share the chip"}
         if dims.dry:
             line["dryrun"] = True
+        if args.round3_kernels:
+            line["ab_note"] = "A/B run with round 3's kernel choices (--round3-kernels): not the shipped configuration"
+
         # `roofline` = the kernel family that is dominant BY TIME in the step: the rollout's token loop in a GRPO step (HBM-bound weight
         # streaming: 60-70 % of the step), the MFMA GEMM family in an SFT step; the other family keeps its own key
         line["roofline"] = line["roofline_mfma"]

@@ -43,6 +43,7 @@ struct AttnArgs {
     const uint8_t* kmask;                        // [B, Sk] 1 = key may be attended, or null
     int B, Hq, Hkv, Sq, Sk;
     int causal, q_off;                           // causal: key j visible to query i iff j <= i + q_off
+    int legacy_order;                            // A/B knob (bra_attn_set_block_order): block index fastest, as rounds 1-3 launched
     float scale;
 };
 
@@ -139,7 +140,8 @@ __device__ __forceinline__ uint64_t key_valid_word(const AttnArgs& a, int b, int
 // (key block j is visited by the query tiles behind it), so with the block index fastest the heaviest workgroup of the last
 // (batch, head) pair started last and the chip idled behind it (B = 8, S = 2436: ~87 tile-units of makespan for 49 of work per slot).
 // Neighbouring workgroups are the heads of one batch row: the q-heads of a kv-group still share their K / V tiles in L2.
-__device__ __forceinline__ void attn_block_coords(int heavy_is_last, int& blk, int& head, int& b) {
+__device__ __forceinline__ void attn_block_coords(int legacy, int heavy_is_last, int& blk, int& head, int& b) {
+    if (legacy) { blk = (int)blockIdx.x; head = (int)blockIdx.y; b = (int)blockIdx.z; return; }
     const int nblk = (int)gridDim.x, nh = (int)gridDim.y, nb = (int)gridDim.z;
     const int id = (int)blockIdx.x + nblk * ((int)blockIdx.y + nh * (int)blockIdx.z);
     const int per = nh * nb;
@@ -147,9 +149,6 @@ __device__ __forceinline__ void attn_block_coords(int heavy_is_last, int& blk, i
     blk = heavy_is_last ? nblk - 1 - x : x;
     b = rem / nh;
     head = rem - b * nh;
-#ifdef BRA_ATTN_LEGACY_ORDER          // (A/B builds only: block index fastest, as rounds 1-3 launched it)
-    blk = (int)blockIdx.x; head = (int)blockIdx.y; b = (int)blockIdx.z;
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
     BRA_DYN_SMEM(smem);   // [2][K tile | V^T tile]
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     int bx_, hq, b;
-    attn_block_coords(a.causal, bx_, hq, b);
+    attn_block_coords(a.legacy_order, a.causal, bx_, hq, b);
     const int hkv = hq / (a.Hq / a.Hkv);
     const int q0 = bx_ * QROWS;
     const int qw0 = q0 + wave * 32;
@@ -337,7 +336,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int STAGE = 2 * T::KBYTES + T::TBYTES;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     int bx_, hq, b;
-    attn_block_coords(a.causal, bx_, hq, b);
+    attn_block_coords(a.legacy_order, a.causal, bx_, hq, b);
     const int hkv = hq / (a.Hq / a.Hkv);
     const int q0 = bx_ * QROWS;
     const int qw0 = q0 + wave * 32;
@@ -485,7 +484,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr int STAGE = OFF_L + 512;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     int bx_, hkv, b;
-    attn_block_coords(0, bx_, hkv, b);                // (causal: key block 0 is the heaviest — ascending order is heaviest first)
+    attn_block_coords(a.legacy_order, 0, bx_, hkv, b);                // (causal: key block 0 is the heaviest — ascending order is heaviest first)
     const int group = a.Hq / a.Hkv;
     const int k0 = bx_ * KROWS;
     const int kw0 = k0 + wave * 32;
@@ -889,6 +888,12 @@ static int launch_dkv(const AttnArgs& a, bra_stream_t st) {
     return rc ? rc : launch_dkv_v<HD, 2, NW>(a, st);
 }
 
+#ifdef BRA_EMU
+static int g_attn_legacy_order = 0;
+#else
+static std::atomic<int> g_attn_legacy_order{0};
+#endif
+
 static int attn_check(int B, int Hq, int Hkv, int Sq, int Sk, int hd) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0 || Hq % Hkv) return BRA_ERR_ARG;
     if (hd != 32 && hd != 64 && hd != 128) return BRA_ERR_UNSUPPORTED;
@@ -909,6 +914,7 @@ extern "C" int bra_attn_fwd(const void* q, long q_sb, long q_ss, long q_sh, cons
     a.o = (bf16_t*)o; a.o_sb = o_sb; a.o_ss = o_ss; a.o_sh = o_sh;
     a.lse = lse; a.kmask = (const uint8_t*)kmask;
     a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = Sq; a.Sk = Sk; a.causal = causal; a.q_off = q_off; a.scale = scale;
+    a.legacy_order = g_attn_legacy_order;
     bra_stream_t st = (bra_stream_t)stream;
     if (hd == 128) return launch_fwd<128>(a, st);
     if (hd == 64) return launch_fwd<64>(a, st);
@@ -941,12 +947,15 @@ extern "C" int bra_attn_bwd(const void* q, long q_sb, long q_ss, long q_sh, cons
     a.dk = (bf16_t*)dk; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dk_sh = dk_sh;
     a.dv = (bf16_t*)dv; a.dv_sb = dv_sb; a.dv_ss = dv_ss; a.dv_sh = dv_sh;
     a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = Sq; a.Sk = Sk; a.causal = causal; a.q_off = q_off; a.scale = scale;
+    a.legacy_order = g_attn_legacy_order;
     bra_stream_t st = (bra_stream_t)stream;
     int r;
     if (hd == 128) { r = launch_dq<128>(a, st); if (r) return r; return launch_dkv<128>(a, st); }
     if (hd == 64) { r = launch_dq<64>(a, st); if (r) return r; return launch_dkv<64>(a, st); }
     r = launch_dq<32>(a, st); if (r) return r; return launch_dkv<32>(a, st);
 }
+
+extern "C" int bra_attn_set_block_order(int legacy) { g_attn_legacy_order = legacy ? 1 : 0; return 0; }
 
 extern "C" int bra_attn_decode_nchunk(int len) { return (len + 127) / 128; }
 

@@ -1145,6 +1145,11 @@ extern "C" int bra_gemm_set_variant(int v) {
     if (v == 7 || v < 0) bra::ring_two_phase = 1;
     return 0;
 }
+extern "C" int bra_gemm_set_glds_rows(int rows) {
+    if (rows != 0 && rows != 128 && rows != 192 && rows != 256) return BRA_ERR_ARG;
+    bra::g_forced_glds_rows = rows;
+    return 0;
+}
 extern "C" int bra_gemm_set_ring_fill(int pct) { bra::ring_min_fill_pct = pct; return 0; }
 extern "C" int bra_gemm_set_row_split(int on) { bra::ring_row_split = on; return 0; }
 

@@ -15,7 +15,7 @@
  *     failed, or a negative BRA_ERR_* for a rejected argument; nothing throws,
  *     nothing allocates, nothing synchronises; workspaces come from the caller.
  *   - all compute entry points are re-entrant and thread-safe.  The ONLY process-wide mutable state is five test /
- *     benchmark knobs — bra_gemm_set_variant, bra_gemm_set_ring_fill, bra_gemm_set_row_split, bra_debug_set_probe, bra_persist_set_stamps —
+ *     benchmark knobs — bra_gemm_set_variant, bra_gemm_set_ring_fill, bra_gemm_set_row_split, bra_gemm_set_glds_rows, bra_attn_set_block_order, bra_debug_set_probe, bra_persist_set_stamps —
  *     held in atomics (a concurrent launch sees the old or the new value, never a torn one), an init-once
  *     "dynamic LDS opted in" flag per kernel and device, and an init-once device-properties cache.  The knobs select
  *     between bit-identical tilings (results do not depend on them); production callers never touch them.
@@ -55,6 +55,12 @@ int bra_gemm_set_ring_fill(int pct);
 /* row split of the per-shape choice (default on): when the last round of 256 x 256 tiles would be less than half full, the
  * tile-rows that fill whole rounds go to the ring kernel and the remaining rows to the 256 x 128 kernel (two launches) */
 int bra_gemm_set_row_split(int on);
+/* tile height of the LDS-DMA kernel (round 4): 0 = chosen per call (256 / 192 / 128 rows, whichever fills the 256 CUs best),
+ * 256 = rounds 1-3 (A/B measurements); bra_gemm_set_variant(9 / 10) pins 192 / 128 together with the kernel */
+int bra_gemm_set_glds_rows(int rows);
+/* attention forward / backward: 1 = launch order of rounds 1-3 (query / key block index fastest), 0 (default) = block index
+ * slowest and, under a causal mask, heaviest blocks first (A/B measurements) */
+int bra_attn_set_block_order(int legacy);
 
 /* C[M,N] (f32, pre-zeroed or holding a running gradient) += alpha * A[M,K] B[N,K]^T with the K range cut
  * into `split_k` slices and combined by atomics: weight gradients of LoRA A/B and dna_projection, where
