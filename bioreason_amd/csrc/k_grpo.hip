@@ -475,6 +475,116 @@ __global__ __launch_bounds__(64) void sample_tiles_kernel(const float* logits, l
     if (ss) for (int c = lane; c < nss; c += 64) ss[(long)row * nss + c] = c == 0 ? acc : 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// General sampler: top_k = 0 (HF: top-k "disabled") or top_k > 64 — the warped distribution can then have thousands of survivors,
+// so the fast paths above (temperature / top-p / multinomial over <= 64 sorted survivors) do not apply.  One workgroup per row,
+// everything by passes over the row's logits (L2-resident: 600 KB at Qwen3's vocabulary):
+//   m = max, kept_k = { l >= the top_k-th largest value }   (TopKLogitsWarper keeps ties of the k-th value: `scores < kth` is removed)
+//   kept_p = { l in kept_k : mass of kept_k strictly above l  <  top_p }   (TopPLogitsWarper on the ascending sort: token i is removed
+//            iff cumsum_i <= 1 - top_p, i.e. iff the mass sorted AFTER it is >= top_p; min_tokens_to_keep = 1 holds: nothing is above
+//            the maximum.  Tokens of EQUAL value at the boundary are kept or dropped together here; HF's stable sort may split them)
+//   draw   = multinomial over kept_p in INDEX order (same distribution as HF's; the uniform comes from the same counter hash)
+// The two thresholds are found by bisection on the order-preserving integer image of the float (<= 32 passes each): exact, slow
+// (~0.1-0.3 ms per token) — a functional path for configurations outside GRPO's top_k = 20 (TF:generation/logits_process.py:238,473,542).
+template <int NT>
+__device__ __forceinline__ float blk_sum_f(float v, float* red) {
+    v = wave_sum<64>(v);
+    __syncthreads();
+    if (lane_id() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void sample_full_kernel(const float* logits, long ldl, int V, float temperature, int top_k, float top_p,
+                                                         uint32_t seed, const int* step_ptr, int step_arg, uint8_t* finished, int pad_id,
+                                                         int eos_id, int eos_id2, int* out_ids, float* out_logp, int* tokens_out, long ldt) {
+    __shared__ float red[NT / 64];
+    __shared__ float scan[NT];
+    const int row = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const float* lr = logits + (long)row * ldl;
+    const float inv_t = 1.f / temperature;
+    float m = -3.0e38f;
+    for (int j = tid; j < V; j += NT) m = fmaxf(m, lr[j]);
+    m = block_max<NT / 64>(m, red);
+    // ---- top-k: the largest x with count(ord(l) >= x) >= k  (= image of the k-th largest value)
+    uint32_t kmin = 0u;
+    if (top_k > 0 && top_k < V) {
+        uint32_t lo = 0u, hi = ord_f32(m);
+        while (lo < hi) {
+            const uint32_t mid = lo + (uint32_t)(((uint64_t)hi - lo + 1ull) >> 1);
+            float c = 0.f;
+            for (int j = tid; j < V; j += NT) c += ord_f32(lr[j]) >= mid ? 1.f : 0.f;     // (counts < 2^24: exact in fp32)
+            c = blk_sum_f<NT>(c, red);
+            if (c >= (float)top_k) lo = mid; else hi = mid - 1u;
+        }
+        kmin = lo;
+    }
+    auto e_of = [&](float l) { return __expf((l - m) * inv_t); };
+    float zk = 0.f;
+    for (int j = tid; j < V; j += NT) { const float l = lr[j]; zk += ord_f32(l) >= kmin ? e_of(l) : 0.f; }
+    zk = blk_sum_f<NT>(zk, red);
+    // ---- top-p: the smallest x >= kmin with  mass(kept_k, ord(l) > x) < top_p * zk
+    uint32_t pmin = kmin;
+    if (top_p < 1.f) {
+        const float P = top_p * zk;
+        uint32_t lo = kmin, hi = ord_f32(m);               // ok(hi) holds: nothing lies above the maximum
+        while (lo < hi) {
+            const uint32_t mid = lo + (uint32_t)(((uint64_t)hi - lo) >> 1);
+            float ms = 0.f;
+            for (int j = tid; j < V; j += NT) { const float l = lr[j]; ms += ord_f32(l) > mid ? e_of(l) : 0.f; }      // (mid >= kmin: all of these are in kept_k)
+            ms = blk_sum_f<NT>(ms, red);
+            if (ms < P) hi = mid; else lo = mid + 1u;
+        }
+        pmin = lo;
+    }
+    // ---- multinomial over { ord(l) >= pmin } in index order: thread t owns indices [t per, (t + 1) per)
+    const int per = (V + NT - 1) / NT;
+    const int j0 = tid * per, j1 = (j0 + per) < V ? (j0 + per) : V;
+    float mine = 0.f;
+    for (int j = j0; j < j1; ++j) { const float l = lr[j]; mine += ord_f32(l) >= pmin ? e_of(l) : 0.f; }
+    scan[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        const int step = step_ptr ? step_ptr[0] : step_arg;
+        float zf = 0.f;
+        for (int t = 0; t < NT; ++t) zf += scan[t];
+        const float u = uniform01(seed, (uint32_t)step, (uint32_t)row) * zf;
+        // the thread whose index range holds the draw (the last range with mass takes a draw that rounding pushed past the total)
+        float run = 0.f, before = 0.f;
+        int owner = 0;
+        for (int t = 0; t < NT; ++t) {
+            if (scan[t] > 0.f) {
+                owner = t; before = run;
+                if (u < run + scan[t]) break;
+                run += scan[t];
+            }
+        }
+        const int o0 = owner * per, o1 = (o0 + per) < V ? (o0 + per) : V;
+        int pick = 0;
+        float ep = 1.f, a2 = 0.f;
+        for (int j = o0; j < o1; ++j) {
+            const float l = lr[j];
+            if (ord_f32(l) >= pmin) {
+                const float e = e_of(l);
+                pick = j; ep = e;
+                if (u < before + a2 + e) break;
+                a2 += e;
+            }
+        }
+        int choice = pick;
+        const int was_finished = finished ? (int)finished[row] : 0;
+        if (was_finished) choice = pad_id;
+        out_ids[row] = choice;
+        if (out_logp) out_logp[row] = __logf(ep / zf);
+        if (tokens_out) tokens_out[(long)row * ldt + step] = choice;
+        if (finished && ((eos_id >= 0 && choice == eos_id) || (eos_id2 >= 0 && choice == eos_id2))) finished[row] = 1;
+    }
+}
+
 // synthetic EOS schedule (bench / tests: random-init weights never emit EOS on their own): row b's logit of `token` is
 // raised above everything else at the step its schedule names, so the sampler — greedy or warped — draws it there.
 __global__ __launch_bounds__(64) void force_token_kernel(float* logits, long ldl, int B, int token, const int* step_ptr, int step_arg,
@@ -661,6 +771,20 @@ extern "C" int bra_force_token_tiles(float* logits, long ldl, int B, int V, int 
     if (B == 0) return 0;
     if (!logits || !at || token < 0 || token >= V || B > 64 || (tmax && ldm < (V + 15) / 16)) return BRA_ERR_ARG;
     BRA_LAUNCH(force_token_kernel, dim3(1), dim3(64), 0, stream, logits, ldl, B, token, step_ptr, step, at, tmax, ldm);
+    return BRA_LAUNCH_STATUS();
+}
+
+// temperature -> top-k -> top-p -> multinomial for ANY top_k: 0 = no top-k filter (HF's "disabled"), > 64 as given (see
+// sample_full_kernel: exact thresholds by bisection, a slow functional path; 1..64 is what bra_sample / bra_sample_tiles serve).
+// `step_ptr` null: the step index is `step`.
+extern "C" int bra_sample_full(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p, unsigned seed,
+                               const int* step_ptr, int step, void* finished, int pad_id, int eos_id, int eos_id2, int* out_ids,
+                               float* out_logp, int* tokens_out, long ldt, void* stream) {
+    if (B == 0) return 0;
+    if (!logits || !out_ids || V <= 0 || temperature <= 0.f || top_k < 0 || !(top_p > 0.f)) return BRA_ERR_ARG;
+    if (V >= (1 << 24)) return BRA_ERR_UNSUPPORTED;
+    BRA_LAUNCH((sample_full_kernel<1024>), dim3(B), dim3(1024), 0, stream, logits, ldl, V, temperature, top_k, top_p > 1.f ? 1.f : top_p,
+               (uint32_t)seed, step_ptr, step, (uint8_t*)finished, pad_id, eos_id, eos_id2, out_ids, out_logp, tokens_out, ldt);
     return BRA_LAUNCH_STATUS();
 }
 

@@ -522,7 +522,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         ops.tile_max(logits, tmax)
         sample_ws = torch.empty((2 * B * 8 * kk,), dtype=torch.float32, device=dev)
     fuse_embed = (dstate is not None and dstate.ss_ws is not None and force_tokens is None and sample_ws is not None
-                  and B <= 16)
+                  and B <= 16 and (not do_sample or 1 <= top_k <= 64))     # (top_k = 0 / > 64: the general sampler, no fused gather)
     rope_args = None
     if shared is not None and getattr(shared, "rope_rows", None) is not None:
         rope_args = (shared.cosT, shared.sinT, eng.hd, shared.rope_rows)

@@ -434,8 +434,12 @@ def sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished,
     statistic of that row (two-stage path only: V >= 4096)."""
     B, V = logits.shape
     if do_sample and not (1 <= top_k <= 64):
-        raise NotImplementedError("sampling needs 1 <= top_k <= 64 on the HIP path: temperature / top-p / multinomial run over "
-                                  "at most 64 survivors (HF's top_k=0 'disabled' is not supported; GRPO uses top_k=20)")
+        # HF's top_k = 0 ("disabled") or more than 64 survivors: the general kernel (exact thresholds by bisection; slow — see
+        # bra_sample_full).  The fused embedding gather of the fast paths is not part of it: the caller's step embeds the token.
+        if embed is not None:
+            raise NotImplementedError("the fused embedding gather needs 1 <= top_k <= 64 (callers fall back to the unfused step)")
+        return sample_full(logits, temperature, top_k, top_p, seed, step_t, finished, pad_id, out_ids, out_logp, eos_id=eos_id,
+                           eos_id2=eos_id2, tokens_out=tokens_out)
     if ws is None and V >= 4096:
         k = min(top_k, 64) if top_k > 0 else 64
         ws = torch.empty((2 * B * 64 * k,), dtype=torch.float32, device=logits.device)
@@ -448,6 +452,17 @@ def sample(logits, temperature, top_k, top_p, do_sample, seed, step_t, finished,
         return out_ids
     get_lib().call("bra_sample", logits, _ld(logits), B, V, temperature, top_k, top_p, int(do_sample), seed & 0xFFFFFFFF,
                    step_t, finished, pad_id, eos_id, eos_id2, out_ids, out_logp, tokens_out, ldt, ws, current_stream(logits))
+    return out_ids
+
+
+def sample_full(logits, temperature, top_k, top_p, seed, step, finished, pad_id, out_ids, out_logp=None, eos_id=-1, eos_id2=-1,
+                tokens_out=None):
+    """temperature -> top-k -> top-p -> multinomial for ANY top_k >= 0 (0: HF's 'disabled'); `step`: device int32 [1], python int or None"""
+    B, V = logits.shape
+    ldt = tokens_out.stride(0) if tokens_out is not None else 0
+    step_ptr, step_i = (step, 0) if isinstance(step, torch.Tensor) else (None, int(step or 0))
+    get_lib().call("bra_sample_full", logits, _ld(logits), B, V, temperature, max(int(top_k), 0), top_p, seed & 0xFFFFFFFF, step_ptr, step_i,
+                   finished, pad_id, eos_id, eos_id2, out_ids, out_logp, tokens_out, ldt, current_stream(logits))
     return out_ids
 
 

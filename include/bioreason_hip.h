@@ -352,6 +352,12 @@ int bra_sample_tiles(const float* logits, long ldl, const float* tmax, long ldm,
                      int eos_id, int eos_id2, int* out_ids, float* out_logp, int* tokens_out, long ldt, void* ws,
                      const void* E, long lde, int H, void* x, long ldx, float* ss, int nss, const int* pos0, int* pos_out,
                      const float* cosT, const float* sinT, int hd, float* rope_rows, void* stream);
+/* sampling with top_k = 0 (HF: top-k disabled) or top_k > 64: thresholds of TopKLogitsWarper / TopPLogitsWarper found by bisection over
+ * the row's logits, multinomial over the survivors (one workgroup per row; exact, ~0.1-0.3 ms per token: a functional path — GRPO's
+ * top_k = 20 takes bra_sample_tiles).  Ties of equal logits at the top-p boundary are kept or dropped together. */
+int bra_sample_full(const float* logits, long ldl, int B, int V, float temperature, int top_k, float top_p, unsigned seed,
+                    const int* step_ptr, int step, void* finished, int pad_id, int eos_id, int eos_id2, int* out_ids,
+                    float* out_logp, int* tokens_out, long ldt, void* stream);
 /* bra_force_token that also raises the token's tile maximum; `step_ptr` null: the step index is `step` */
 int bra_force_token_tiles(float* logits, long ldl, int B, int V, int token, const int* step_ptr, int step, const int* at,
                           float* tmax, long ldm, void* stream);

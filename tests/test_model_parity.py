@@ -368,6 +368,27 @@ def test_two_chunk_prefill_equals_one_chunk(backend, monkeypatch, alias):
     assert torch.equal(out["1"][1], out["2"][1]), (out["1"][1] - out["2"][1]).abs().max()
 
 
+def test_generate_with_top_k_disabled(backend):
+    """HF's `top_k = 0` (no top-k filter; `GenerationConfig.top_k` of a caller that disables it) runs the rollout through the general
+    sampler: tokens inside the vocabulary, reproducible for a seed, first token equal on the shared-prefix and per-copy paths (both
+    draw it from the prefill's logits with the same counter-based uniform)"""
+    fix = torch.load(os.path.join(GOLD, "tiny_b.pt"), weights_only=False)
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    rows = [0, 0, 1, 1]
+    ids, mask = b["input_ids"][rows], b["attention_mask"][rows]
+    dna = {k: v[rows] for k, v in b["dna_tokenized"].items()}
+    mm = {"dna_tokenized": dna, "batch_idx_map": [0, 1, 2, 3]}
+    kw = dict(max_new_tokens=4, do_sample=True, temperature=0.8, top_k=0, top_p=0.9, eos_token_id=None, seed=3, use_graph=False)
+    a = m.generate(input_ids=ids, attention_mask=mask, **mm, **kw)
+    a2 = m.generate(input_ids=ids, attention_mask=mask, **mm, **kw)
+    s_ = m.generate(input_ids=ids, attention_mask=mask, **mm, prompt_alias=[0, 0, 2, 2], **kw)
+    V = fix["config"]["text"]["vocab_size"]
+    assert a.shape == (4, 4) and int(a.min()) >= 0 and int(a.max()) < V
+    assert torch.equal(a, a2)
+    assert torch.equal(a[:, 0].cpu(), s_[:, 0].cpu())
+
+
 def test_decode_with_more_than_eight_sequences(backend):
     """12 sequences (2 prompts x 6 copies): the streaming projections run their 16-row form (16-column tiles, packed + norm-folded
     weights, 16-row statistics) under the shared-prefix attention; same choices as the op-by-op decode under teacher forcing"""

@@ -4,7 +4,7 @@
 #   profiles/<tag>_bench_kernel_stats.csv     rocprofv3 --kernel-trace --stats of `bench.py --steps 1 --warmup 1` (3 steps in the trace)
 #   profiles/<tag>_pmc_*.csv                  separate rocprofv3 --pmc passes on the SAME command (FETCH_SIZE | WRITE_SIZE | SQ busy counters)
 #   profiles/<tag>_pmc_gemm.json              dominant-kernel traffic per launch + the kernel-source hash bench.py checks
-tag=${1:-r3_x}
+tag=${1:-r4_x}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 out=$R/gpurun_out/evidence_$tag; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
