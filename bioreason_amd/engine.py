@@ -182,12 +182,14 @@ class QwenEngine:
     SMALL_M = 8192
 
     @staticmethod
-    def _down(x2d, A, scaling, n_targets):
-        """s x A^T -> [rows, r_pad] (A = the adapter image [r_pad, K], one 32-row block per target)"""
+    def _down(x2d, A, scaling, live_rows):
+        """s x A^T -> [rows, r_pad] (A = the adapter image [r_pad, K]; its first `live_rows` = targets x rank rows are adapters, the
+        rest padding)"""
         if x2d.shape[0] < QwenEngine.SMALL_M and A.shape[0] in (32, 64, 128):
-            # p = 0: EVERY 32-row rank block of the image is live, whatever the adapters' rank (r = 64: one target spans two
-            # blocks; r = 16 x 3 targets: 48 rows in two blocks) — the kernel zeroes the blocks past the seeds it is given
-            return ops.lora_down_drop(x2d, A, scaling, 0.0, [0] * (A.shape[0] // 32))
+            # p = 0: every 32-row block that holds adapter rows is live, whatever the rank (r = 64: one target spans two blocks;
+            # r = 16 x 3 targets: 48 rows in two blocks); the kernel zeroes the blocks past the seeds it is given — the all-padding
+            # blocks (r = 32 x 3 targets in a 128-row image: the fourth) are not multiplied
+            return ops.lora_down_drop(x2d, A, scaling, 0.0, [0] * min(A.shape[0] // 32, (live_rows + 31) // 32))
         return ops.gemm_nt(x2d, A, alpha=scaling)
 
     @staticmethod
@@ -197,7 +199,7 @@ class QwenEngine:
             if drop is not None:
                 t = ops.lora_down_drop(x2d, G.A, G.scaling, drop[0], drop[1])
             else:
-                t = QwenEngine._down(x2d, G.A, G.scaling, len(G.n_sizes))
+                t = QwenEngine._down(x2d, G.A, G.scaling, len(G.n_sizes) * G.r)
             return ops.gemm_nt(x2d, W, a2=t, b2=G.B, res=res, out=out), t
         return ops.gemm_nt(x2d, W, res=res, out=out), None
 
@@ -205,7 +207,7 @@ class QwenEngine:
     def _lora_bwd(dy, WT, G: Optional[LoraGroup], on: bool, x2d, t, drop=None):
         """dx = dy W (+ dropout'(s (dy B) A)); accumulates dA, dB into the arena."""
         if G is not None and on:
-            dts = QwenEngine._down(dy, G.BT, G.scaling, len(G.n_sizes))   # [T, r_pad] = s * dy B
+            dts = QwenEngine._down(dy, G.BT, G.scaling, len(G.n_sizes) * G.r)   # [T, r_pad] = s * dy B
             if drop is not None:
                 dxl = ops.lora_up_drop(dts, G.AT, drop[0], drop[1])      # the branch's input gradient, masked per target
                 dx = ops.gemm_nt(dy, WT, res=dxl)

@@ -103,6 +103,12 @@ class _LayerDesc(ctypes.Structure):
                    ("head_tmax", ctypes.c_void_p)])
 
 
+def _layer_table(n: int):
+    """host array of `n` layer records; the record layout is the library's (k_decode.hip `Layer`): sizes must agree"""
+    assert ctypes.sizeof(_LayerDesc) == get_lib()._dll.bra_qwen_layer_desc_size(), "layer record out of sync with libbioreason_hip.so"
+    return (_LayerDesc * n)()
+
+
 class DecodeState:
     """Host descriptor table + device workspaces for `bra_qwen_decode_step` (one native call per token)."""
 
@@ -110,7 +116,7 @@ class DecodeState:
         eng: QwenEngine = model.engine
         dev = eng.device
         self.eng, self.cache, self.B = eng, cache, B
-        arr = (_LayerDesc * eng.L)()
+        arr = _layer_table(eng.L)
         for i, L in enumerate(eng.layers):
             d = arr[i]
             d.ln1, d.ln2, d.qn, d.kn = L.ln1.data_ptr(), L.ln2.data_ptr(), L.qn.data_ptr(), L.kn.data_ptr()
@@ -208,7 +214,7 @@ class FusedDecodeState:
         self.rw = rollout_weights(model, rows=B)
         self.ss_ws, self.nss = _norm_stat_ws(eng, eng.device, rows=B)
         use_packed = self.ss_ws is not None and _packed_ok(B, self.rw)
-        arr = (_LayerDesc * eng.L)()
+        arr = _layer_table(eng.L)
         for i, (L, R) in enumerate(zip(eng.layers, self.rw)):
             d = arr[i]
             d.ln1, d.ln2, d.qn, d.kn = L.ln1.data_ptr(), L.ln2.data_ptr(), L.qn.data_ptr(), L.kn.data_ptr()
@@ -272,7 +278,7 @@ class SharedDecodeState:
         self.vt_pitch = vtp[0].shape[-1]
         self.ss_ws, self.nss = _norm_stat_ws(eng, dev, rows=B)
         use_packed = self.ss_ws is not None and _packed_ok(B, self.rw)
-        arr = (_LayerDesc * eng.L)()
+        arr = _layer_table(eng.L)
         for i, (L, Rw) in enumerate(zip(eng.layers, self.rw)):
             d = arr[i]
             d.ln1, d.ln2, d.qn, d.kn = L.ln1.data_ptr(), L.ln2.data_ptr(), L.qn.data_ptr(), L.kn.data_ptr()
