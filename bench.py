@@ -707,6 +707,7 @@ def main():
             "step_frac_of_mfma_peak_executed": ex / 1e12 / (elapsed / args.steps) / PEAK_BF16_TFLOPS,
             "phases_ms": {k: round(v, 2) for k, v in headline_timers.items()},
             "loss": loss,
+            "hbm_reserved_gib": (torch.cuda.max_memory_reserved(dev) / 2.0 ** 30) if dev.type == "cuda" else None,   # peak of the caching allocator over all legs run so far (of 288)
             "parity_tolerance": "bf16-noise-relative: every compared quantity within 1.25x the reference's OWN bf16-vs-fp32 distance "
                                 "(tests/test_fullsize_parity.py, tests/test_model_parity.py); north_star's 1e-3 rel is below one bf16 "
                                 "rounding (4e-3) and is met only by the log-probs",

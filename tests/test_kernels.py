@@ -393,7 +393,7 @@ def test_sampler_greedy_and_topk(backend):
     step = torch.zeros(1, dtype=torch.int32, device=backend)
     T, k, p = 0.6, 20, 0.95
     draws = []
-    for s in range(200 if backend.type == "cuda" else 80):
+    for s in range(200 if backend.type == "cuda" else 48):
         step.fill_(s)
         ops.sample(logits, T, k, p, True, 1234, step, None, 0, out)
         draws.append(out.clone().cpu())
@@ -638,6 +638,38 @@ def test_sampler_over_tile_maxima_equals_full_scan(backend, V, k):
         assert out2.tolist() == out1.tolist()
     if not do_sample:
         assert out1.tolist() == logits.argmax(-1).tolist()
+
+
+@pytest.mark.gpu
+def test_sampler_over_tile_maxima_at_qwen3_vocabulary(hip_device):
+    """the bench's sampler call — B = 8 rows, V = 151 936 (9 496 tiles in 8 slices), T = 0.6 / top-k 20 / top-p 0.95 — through the lm_head
+    epilogue's tile maxima against the full-scan sampler on the same logits: identical tokens and log-probs over 300 steps, also with
+    a forced EOS logit (bra_force_token_tiles) and bf16-grid logits (many exact ties across tiles)"""
+    dev = hip_device
+    B, V, K = 8, 151936, 256
+    x, W = rnd(B, K, dev=dev), rnd(V, K, dev=dev, scale=0.3)
+    nw = (1.0 + 0.1 * torch.randn(K)).to(BF).to(dev)
+    ss = ops.row_sumsq(x, 256)
+    Wf = ops.dec_pack_weights(W, out_f32=True, norm_w=nw)
+    tm = torch.empty(B, V // 16, device=dev)
+    logits, _ = ops.dec_gemm2(x, Wf, ss_in=ss, norm_w=nw, out_f32=True, packed=3, tile_max=tm)
+    assert torch.equal(tm, logits.view(B, V // 16, 16).amax(-1))
+    lg2 = logits.to(BF).float()                     # values on the bf16 grid: exact ties are common
+    for lg in (logits, lg2):
+        tmx = ops.tile_max(lg)
+        o0, o1 = torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)
+        l0, l1 = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        at = torch.tensor([3, 50, 7, 299, 0, 120, 9, 11], dtype=torch.int32, device=dev)
+        lg_a, lg_b = lg.clone(), lg.clone()
+        for s_ in range(300):
+            step.fill_(s_)
+            ops.force_token(lg_a, 151645, step, at)
+            ops.force_token_tiles(lg_b, 151645, s_, at, tmx)
+            ops.sample(lg_a, 0.6, 20, 0.95, True, 42, step, None, 0, o0, out_logp=l0)
+            ops.sample_tiles(lg_b, tmx, 0.6, 20, 0.95, True, 42, s_, None, 0, o1, out_logp=l1)
+            assert torch.equal(o0, o1) and torch.equal(l0, l1), s_
+        assert torch.equal(lg_a, lg_b) and torch.equal(tmx, ops.tile_max(lg_b))
 
 
 def test_sampler_over_tile_maxima_tail_work(backend):
