@@ -44,6 +44,12 @@ struct AttnArgs {
     int B, Hq, Hkv, Sq, Sk;
     int causal, q_off;                           // causal: key j visible to query i iff j <= i + q_off
     int legacy_order;                            // A/B knob (bra_attn_set_block_order): block index fastest, as rounds 1-3 launched
+    // forward with the key range cut into `nsplit` parts (grids that cannot fill the chip: one prompt, the 256-query completion
+    // segment): part s of a query block visits its tiles [ntile s / nsplit, ntile (s + 1) / nsplit) and leaves the unnormalised
+    // O (fp32) and (running max, sum) per query; attn_combine_kernel merges the parts in order
+    int nsplit;
+    float* part_o;                               // [B, Hq, nsplit, Sq, hd]
+    float* part_ml;                              // [B, Hq, nsplit, Sq, 2]
     float scale;
 };
 
@@ -163,6 +169,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
     int bx_, hq, b;
     attn_block_coords(a.legacy_order, a.causal, bx_, hq, b);
     const int hkv = hq / (a.Hq / a.Hkv);
+    const int nsp = a.nsplit > 1 ? a.nsplit : 1;
+    const int sp = nsp > 1 ? bx_ % nsp : 0;           // (grid x = query blocks x key parts: the parts of a block are neighbours)
+    if (nsp > 1) bx_ /= nsp;
     const int q0 = bx_ * QROWS;
     const int qw0 = q0 + wave * 32;
     const int qi = qw0 + (lane & 31);                 // this lane's query
@@ -190,20 +199,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
         int last = q0 + QROWS - 1 + a.q_off + 1;
         kv_end = last < kv_end ? last : kv_end;
     }
-    const int ntile = kv_end > 0 ? (kv_end + 63) / 64 : 0;
+    const int ntile_all = kv_end > 0 ? (kv_end + 63) / 64 : 0;
+    const int t_first = nsp > 1 ? (ntile_all * sp) / nsp : 0;
+    const int ntile = nsp > 1 ? (ntile_all * (sp + 1)) / nsp : ntile_all;      // this part's tiles: [t_first, ntile)
 
     u32x4 rk[(64 * T::CH) / NT], rv[(HD * 8) / NT];
-    if (ntile > 0) {
-        load_rows<HD, NT>(rk, kb_, a.k_ss, 0, a.Sk, tid);
-        load_trans<HD, NT>(rv, vtb, a.vt_sd, 0, tid);
-        store_rows<HD, NT>(smem, rk, tid);
-        store_trans<HD, NT>(smem + T::KBYTES, rv, tid);
+    if (ntile > t_first) {
+        load_rows<HD, NT>(rk, kb_, a.k_ss, t_first * 64, a.Sk, tid);
+        load_trans<HD, NT>(rv, vtb, a.vt_sd, t_first * 64, tid);
+        store_rows<HD, NT>(smem + (t_first & 1) * (T::KBYTES + T::TBYTES), rk, tid);
+        store_trans<HD, NT>(smem + (t_first & 1) * (T::KBYTES + T::TBYTES) + T::KBYTES, rv, tid);
     }
     __syncthreads();
 
     // key-validity word of the NEXT tile is requested one iteration ahead (its mask load is a dependent L2 round trip)
-    uint64_t valid_next = ntile > 0 ? key_valid_word(a, b, 0, lane) : 0ull;
-    for (int t = 0; t < ntile; ++t) {
+    uint64_t valid_next = ntile > t_first ? key_valid_word(a, b, t_first * 64, lane) : 0ull;
+    for (int t = t_first; t < ntile; ++t) {
         const int kv0 = t * 64;
         const int tl = opaque_i(tid), ll = opaque_i(lane);      // per-iteration copies: keeps address math out of registers across the loop
         const char* sk = smem + (t & 1) * (T::KBYTES + T::TBYTES);
@@ -307,6 +318,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
         __syncthreads();
     }
 
+    if (nsp > 1) {
+        // this part's unnormalised O and (max, sum) per query; lane (query, h) owns d = 32 db + 8 g + 4 h + 0..3
+        if (qi < a.Sq) {
+            const long row = (((long)b * a.Hq + hq) * nsp + sp) * a.Sq + qi;
+            float* op = a.part_o + row * HD;
+#pragma unroll
+            for (int db = 0; db < T::DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 w = {o[db][4 * g + 0], o[db][4 * g + 1], o[db][4 * g + 2], o[db][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(op + db * 32 + 8 * g + 4 * h) = w;
+                }
+            if (h == 0) { a.part_ml[row * 2] = m_run; a.part_ml[row * 2 + 1] = l_run; }
+        }
+        return;
+    }
     if (qi < a.Sq) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
         bf16_t* op = a.o + b * a.o_sb + (long)qi * a.o_ss + hq * a.o_sh;
@@ -322,6 +349,38 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
         if (a.lse && h == 0)
             a.lse[((long)b * a.Hq + hq) * a.Sq + qi] = l_run > 0.f ? (m_run + log2f(l_run)) * kLn2 : kNeg;
     }
+}
+
+// merges the key parts of a split forward (fixed order: deterministic): one lane per (query, 4 dims)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a) {
+    constexpr int LR = HD / 4;                        // lanes per query row
+    const long row = (long)blockIdx.x * (256 / LR) + (int)threadIdx.x / LR;     // (b, hq, qi) flattened
+    const int d4 = (int)threadIdx.x % LR;
+    const long nrow = (long)a.B * a.Hq * a.Sq;
+    if (row >= nrow) return;
+    const int qi = (int)(row % a.Sq);
+    const long bh = row / a.Sq;
+    const int hq = (int)(bh % a.Hq), b = (int)(bh / a.Hq);
+    const int ns = a.nsplit;
+    float m = kNeg;
+    for (int s_ = 0; s_ < ns; ++s_) m = fmaxf(m, a.part_ml[((bh * ns + s_) * a.Sq + qi) * 2]);
+    float l = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s_ = 0; s_ < ns; ++s_) {
+        const long pr = (bh * ns + s_) * a.Sq + qi;
+        const float ms = a.part_ml[pr * 2], ls = a.part_ml[pr * 2 + 1];
+        const float w = ls > 0.f ? fast_exp2(ms - m) : 0.f;
+        l += ls * w;
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(a.part_o + pr * HD + d4 * 4);
+        acc += ov * w;
+    }
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    u32x2 w2;
+    w2.x = pack_bf2(acc[0] * inv, acc[1] * inv);
+    w2.y = pack_bf2(acc[2] * inv, acc[3] * inv);
+    st8(a.o + b * a.o_sb + (long)qi * a.o_ss + hq * a.o_sh + d4 * 4, w2);
+    if (a.lse && d4 == 0) a.lse[bh * a.Sq + qi] = l > 0.f ? (m + log2f(l)) * kLn2 : kNeg;
 }
 
 // ---------------------------------------------------------------------------
@@ -842,10 +901,17 @@ template <int HD>
 static int launch_fwd(const AttnArgs& a, bra_stream_t st) {
     const size_t smem = 2 * (Tile<HD>::KBYTES + Tile<HD>::TBYTES);
     if (HD >= 64 && a.Sq > 128) {
+        const int ns = a.nsplit > 1 ? a.nsplit : 1;
         BRA_ALLOW_SMEM((attn_fwd_kernel<HD, (HD >= 64 ? 8 : 4)>), smem);
-        BRA_LAUNCH((attn_fwd_kernel<HD, (HD >= 64 ? 8 : 4)>), dim3((a.Sq + 255) / 256, a.Hq, a.B), dim3(512), smem, st, a);
+        BRA_LAUNCH((attn_fwd_kernel<HD, (HD >= 64 ? 8 : 4)>), dim3(((a.Sq + 255) / 256) * ns, a.Hq, a.B), dim3(512), smem, st, a);
+        int rc = BRA_LAUNCH_STATUS();
+        if (rc || ns == 1) return rc;
+        const long rows = (long)a.B * a.Hq * a.Sq;
+        constexpr int RPB = 256 / (HD / 4);
+        BRA_LAUNCH((attn_combine_kernel<HD>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, a);
         return BRA_LAUNCH_STATUS();
     }
+    if (a.nsplit > 1) return BRA_ERR_UNSUPPORTED;
     BRA_ALLOW_SMEM((attn_fwd_kernel<HD, 4>), smem);
     BRA_LAUNCH((attn_fwd_kernel<HD, 4>), dim3((a.Sq + 127) / 128, a.Hq, a.B), dim3(256), smem, st, a);
     return BRA_LAUNCH_STATUS();
@@ -919,6 +985,34 @@ extern "C" int bra_attn_fwd(const void* q, long q_sb, long q_ss, long q_sh, cons
     if (hd == 128) return launch_fwd<128>(a, st);
     if (hd == 64) return launch_fwd<64>(a, st);
     return launch_fwd<32>(a, st);
+}
+
+// bra_attn_fwd with the key range of every query block cut into `nsplit` parts (2 .. 8) that run as separate workgroups, then one
+// merge launch: for grids that cannot fill the chip (one prompt: 144 workgroups with a triangular load; a 256-query completion segment:
+// 128).  part_o fp32 [B, Hq, nsplit, Sq, hd], part_ml fp32 [B, Hq, nsplit, Sq, 2]: caller-owned workspaces.  Same softmax / PV
+// arithmetic per tile; the parts are merged in key order (TF:qwen3:185-207).  Needs Sq > 128 and hd >= 64.
+extern "C" int bra_attn_fwd_split(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss,
+                                  long k_sh, const void* vt, long vt_sb, long vt_sh, long vt_sd, void* o, long o_sb,
+                                  long o_ss, long o_sh, float* lse, const void* kmask, int B, int Hq, int Hkv, int Sq,
+                                  int Sk, int hd, int causal, int q_off, float scale, int nsplit, float* part_o, float* part_ml,
+                                  void* stream) {
+    int e = attn_check(B, Hq, Hkv, Sq, Sk, hd);
+    if (e) return e;
+    if (!q || !k || !vt || !o || vt_sd % 8 || vt_sd < ((Sk + 63) / 64) * 64) return BRA_ERR_ARG;
+    if (nsplit < 2 || nsplit > 8 || !part_o || !part_ml || o_sh % 4 || o_ss % 4 || o_sb % 4) return BRA_ERR_ARG;
+    if (hd < 64 || Sq <= 128) return BRA_ERR_UNSUPPORTED;
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.q_sb = q_sb; a.q_ss = q_ss; a.q_sh = q_sh;
+    a.k = (const bf16_t*)k; a.k_sb = k_sb; a.k_ss = k_ss; a.k_sh = k_sh;
+    a.vt = (const bf16_t*)vt; a.vt_sb = vt_sb; a.vt_sh = vt_sh; a.vt_sd = vt_sd;
+    a.o = (bf16_t*)o; a.o_sb = o_sb; a.o_ss = o_ss; a.o_sh = o_sh;
+    a.lse = lse; a.kmask = (const uint8_t*)kmask;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = Sq; a.Sk = Sk; a.causal = causal; a.q_off = q_off; a.scale = scale;
+    a.legacy_order = g_attn_legacy_order;
+    a.nsplit = nsplit; a.part_o = part_o; a.part_ml = part_ml;
+    bra_stream_t st = (bra_stream_t)stream;
+    if (hd == 128) return launch_fwd<128>(a, st);
+    return launch_fwd<64>(a, st);
 }
 
 extern "C" int bra_attn_bwd(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss,

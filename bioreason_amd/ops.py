@@ -301,7 +301,7 @@ def head_transpose(x: torch.Tensor) -> torch.Tensor:
 
 
 def attn_fwd(q, k, vt, kmask, causal: bool, scale: float, q_off: Optional[int] = None, need_lse: bool = True,
-             out: Optional[torch.Tensor] = None):
+             out: Optional[torch.Tensor] = None, nsplit: Optional[int] = None):
     """q: [B,Sq,Hq,hd] view, k: [B,Sk,Hkv,hd] view, vt: [B,Hkv,hd,pitch]; -> (o [B,Sq,Hq,hd] contiguous, lse [B,Hq,Sq])"""
     B, Sq, Hq, hd = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
@@ -309,9 +309,32 @@ def attn_fwd(q, k, vt, kmask, causal: bool, scale: float, q_off: Optional[int] =
         q_off = Sk - Sq
     o = out if out is not None else torch.empty((B, Sq, Hq, hd), dtype=BF16, device=q.device)
     lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device) if need_lse else None
+    ns = attn_fwd_split_parts(B, Hq, Sq, Sk, hd, causal) if nsplit is None else int(nsplit)
+    if ns > 1:
+        # grids that cannot fill the chip (one prompt: 144 workgroups; a 256-query completion segment: 128): the key range of every
+        # query block in `ns` parts + one merge launch (bra_attn_fwd_split)
+        part_o = torch.empty((B, Hq, ns, Sq, hd), dtype=torch.float32, device=q.device)
+        part_ml = torch.empty((B, Hq, ns, Sq, 2), dtype=torch.float32, device=q.device)
+        get_lib().call("bra_attn_fwd_split", q, *_bsh_strides(q), k, *_bsh_strides(k), vt, vt.stride(0), vt.stride(1), vt.stride(2),
+                       o, *_bsh_strides(o), lse, kmask, B, Hq, Hkv, Sq, Sk, hd, int(causal), q_off, scale, ns, part_o, part_ml,
+                       current_stream(q))
+        return o, lse
     get_lib().call("bra_attn_fwd", q, *_bsh_strides(q), k, *_bsh_strides(k), vt, vt.stride(0), vt.stride(1), vt.stride(2),
                    o, *_bsh_strides(o), lse, kmask, B, Hq, Hkv, Sq, Sk, hd, int(causal), q_off, scale, current_stream(q))
     return o, lse
+
+
+ATTN_SPLIT = os.environ.get("BRA_ATTN_SPLIT", "1") == "1"
+
+
+def attn_fwd_split_parts(B: int, Hq: int, Sq: int, Sk: int, hd: int, causal: bool) -> int:
+    """key parts per query block of the forward: 1 unless the grid of 256-query workgroups is far from filling 256 CUs"""
+    if not ATTN_SPLIT or hd < 64 or Sq <= 128 or Sk < 1024:
+        return 1
+    wgs = ((Sq + 255) // 256) * Hq * B
+    if wgs >= 200:
+        return 1
+    return max(1, min(4, (300 + wgs // 2) // wgs))
 
 
 def attn_bwd(q, k, v, o, dout, lse, kmask, causal: bool, scale: float, q_off: Optional[int] = None):

@@ -153,6 +153,13 @@ int bra_attn_fwd(const void* q, long q_sb, long q_ss, long q_sh, const void* k, 
                  const void* vt, long vt_sb, long vt_sh, long vt_sd, void* o, long o_sb, long o_ss, long o_sh,
                  float* lse, const void* kmask, int B, int Hq, int Hkv, int Sq, int Sk, int hd, int causal,
                  int q_off, float scale, void* stream);
+/* bra_attn_fwd with every query block's key range cut into `nsplit` (2..8) parts that run as separate workgroups + one merge launch
+ * (grids that cannot fill the 256 CUs: one prompt, a 256-query completion segment).  part_o fp32 [B, Hq, nsplit, Sq, hd] and part_ml
+ * fp32 [B, Hq, nsplit, Sq, 2] are caller-owned workspaces; needs Sq > 128, hd >= 64. */
+int bra_attn_fwd_split(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss, long k_sh,
+                       const void* vt, long vt_sb, long vt_sh, long vt_sd, void* o, long o_sb, long o_ss, long o_sh,
+                       float* lse, const void* kmask, int B, int Hq, int Hkv, int Sq, int Sk, int hd, int causal,
+                       int q_off, float scale, int nsplit, float* part_o, float* part_ml, void* stream);
 int bra_attn_bwd(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss, long k_sh,
                  const void* v, long v_sb, long v_ss, long v_sh, const void* dout, long do_sb, long do_ss, long do_sh,
                  const void* kt, long kt_sb, long kt_sh, long kt_sd, const void* qt, long qt_sb, long qt_sh,

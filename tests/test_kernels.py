@@ -236,6 +236,36 @@ def test_attn_fwd_bwd(backend, hd, Hq, Hkv, Sq, Sk, causal, pad):
     assert rel(dv, vf.grad) < 1.5e-2
 
 
+
+@pytest.mark.parametrize("hd,Hq,Hkv,Sq,Sk,causal,pad,ns", [(128, 4, 2, 300, 300, True, "left", 2), (128, 2, 1, 256, 700, True, None, 3),
+                                                         (64, 2, 2, 200, 200, False, "right", 2), (128, 4, 2, 520, 520, True, None, 4)])
+def test_attn_fwd_split_equals_unsplit(backend, hd, Hq, Hkv, Sq, Sk, causal, pad, ns):
+    """the forward with every query block's key range cut into `ns` parts + the merge launch (bra_attn_fwd_split: grids that cannot fill
+    the chip) against the one-part forward: same softmax(QK^T)V up to the fp32 re-association of the merge (one extra bf16 rounding
+    never: the parts stay fp32), same LSE; causal with a prefix (Sk > Sq), padding on either side, a part that sees no key of a query
+    (TF:qwen3:185-207)"""
+    B = 2
+    q, k, v = rnd(B, Sq, Hq, hd, dev=backend, seed=1), rnd(B, Sk, Hkv, hd, dev=backend, seed=2), rnd(B, Sk, Hkv, hd, dev=backend, seed=3)
+    kmask = torch.ones(B, Sk, dtype=torch.uint8, device=backend)
+    if pad == "left":
+        kmask[0, :70] = 0                      # (more than one key tile: the first part of row 0's early queries sees nothing)
+    elif pad == "right":
+        kmask[1, Sk - 13:] = 0
+    scale = hd ** -0.5
+    vt = ops.head_transpose(v)
+    o1, l1 = ops.attn_fwd(q, k, vt, kmask if pad else None, causal, scale, nsplit=1)
+    o2, l2 = ops.attn_fwd(q, k, vt, kmask if pad else None, causal, scale, nsplit=ns)
+    live = torch.isfinite(l1.cpu()) & (l1.cpu() > -1e29)
+    assert rel(o2, o1) < 3e-3
+    assert (l2.cpu()[live] - l1.cpu()[live]).abs().max() < 2e-4
+    assert torch.equal(l2.cpu()[~live], l1.cpu()[~live])
+    # the automatic choice: one part for grids that fill the chip, more for one prompt / a short completion segment
+    assert ops.attn_fwd_split_parts(8, 16, 2436, 2436, 128, True) == 1
+    assert ops.attn_fwd_split_parts(1, 16, 2180, 2180, 128, True) == 2
+    assert ops.attn_fwd_split_parts(8, 16, 256, 2436, 128, True) == 2
+    assert ops.attn_fwd_split_parts(1, 16, 1090, 1090, 128, True) == 4
+
+
 @pytest.mark.parametrize("hd,Hq,Hkv,L", [(128, 4, 2, 300), (64, 2, 2, 129), (32, 4, 1, 64)])
 def test_attn_decode(backend, hd, Hq, Hkv, L):
     B, Smax = 3, 320
