@@ -50,6 +50,11 @@ struct AttnArgs {
     int nsplit;
     float* part_o;                               // [B, Hq, nsplit, Sq, hd]
     float* part_ml;                              // [B, Hq, nsplit, Sq, 2]
+    // backward: the dQ kernel splits its key range the same way (`nsplit`, fp32 parts in `part_o`), the dK / dV kernel its loop
+    // over (q-head, query tile) iterations (`nsplit_kv`, parts [B, Hkv, nsplit_kv, Sk, hd]); attn_sum_parts_kernel adds the parts in order
+    int nsplit_kv;
+    float* part_dk;
+    float* part_dv;
     float scale;
 };
 
@@ -383,6 +388,25 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a) {
     if (a.lse && d4 == 0) a.lse[bh * a.Sq + qi] = l > 0.f ? (m + log2f(l)) * kLn2 : kNeg;
 }
 
+// out[b, s, h, :] = sum over the parts of part[b, h, part, s, :] (fp32, in part order) rounded to bf16: the split backward kernels
+template <int HD>
+__global__ __launch_bounds__(256) void attn_sum_parts_kernel(const float* part, int ns, int B, int H, int S, bf16_t* out, long o_sb, long o_ss,
+                                                             long o_sh) {
+    constexpr int LR = HD / 4;
+    const long row = (long)blockIdx.x * (256 / LR) + (int)threadIdx.x / LR;     // (b, h, s) flattened
+    const int d4 = (int)threadIdx.x % LR;
+    if (row >= (long)B * H * S) return;
+    const int si = (int)(row % S);
+    const long bh = row / S;
+    const int hh = (int)(bh % H), b = (int)(bh / H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s_ = 0; s_ < ns; ++s_) acc += *reinterpret_cast<const f32x4*>(part + ((bh * ns + s_) * S + si) * HD + d4 * 4);
+    u32x2 w2;
+    w2.x = pack_bf2(acc[0], acc[1]);
+    w2.y = pack_bf2(acc[2], acc[3]);
+    st8(out + b * o_sb + (long)si * o_ss + hh * o_sh + d4 * 4, w2);
+}
+
 // ---------------------------------------------------------------------------
 // backward, dQ:   one workgroup = 128 queries of one (batch, q-head); loops over key tiles.
 //   S^T = K Q^T, dP^T = V dO^T (both [key][q], query on lanes), dS^T = P^T * (dP^T - delta[q]) * scale
@@ -397,6 +421,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs a) {
     int bx_, hq, b;
     attn_block_coords(a.legacy_order, a.causal, bx_, hq, b);
     const int hkv = hq / (a.Hq / a.Hkv);
+    const int nsp = a.nsplit > 1 ? a.nsplit : 1;
+    const int sp = nsp > 1 ? bx_ % nsp : 0;
+    if (nsp > 1) bx_ /= nsp;
     const int q0 = bx_ * QROWS;
     const int qw0 = q0 + wave * 32;
     const int qi = qw0 + (lane & 31);
@@ -425,20 +452,23 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs a) {
 
     int kv_end = a.Sk;
     if (a.causal) { int last = q0 + QROWS - 1 + a.q_off + 1; kv_end = last < kv_end ? last : kv_end; }
-    const int ntile = kv_end > 0 ? (kv_end + 63) / 64 : 0;
+    const int ntile_all = kv_end > 0 ? (kv_end + 63) / 64 : 0;
+    const int t_first = nsp > 1 ? (ntile_all * sp) / nsp : 0;
+    const int ntile = nsp > 1 ? (ntile_all * (sp + 1)) / nsp : ntile_all;      // this part's key tiles: [t_first, ntile)
 
     u32x4 rk[(64 * T::CH) / NT], rv[(64 * T::CH) / NT], rt[(HD * 8) / NT];
-    if (ntile > 0) {
-        load_rows<HD, NT>(rk, kb_, a.k_ss, 0, a.Sk, tid);
-        load_rows<HD, NT>(rv, vb_, a.v_ss, 0, a.Sk, tid);
-        load_trans<HD, NT>(rt, ktb, a.kt_sd, 0, tid);
-        store_rows<HD, NT>(smem, rk, tid);
-        store_rows<HD, NT>(smem + T::KBYTES, rv, tid);
-        store_trans<HD, NT>(smem + 2 * T::KBYTES, rt, tid);
+    if (ntile > t_first) {
+        char* s0_ = smem + (t_first & 1) * STAGE;
+        load_rows<HD, NT>(rk, kb_, a.k_ss, t_first * 64, a.Sk, tid);
+        load_rows<HD, NT>(rv, vb_, a.v_ss, t_first * 64, a.Sk, tid);
+        load_trans<HD, NT>(rt, ktb, a.kt_sd, t_first * 64, tid);
+        store_rows<HD, NT>(s0_, rk, tid);
+        store_rows<HD, NT>(s0_ + T::KBYTES, rv, tid);
+        store_trans<HD, NT>(s0_ + 2 * T::KBYTES, rt, tid);
     }
     __syncthreads();
 
-    for (int t = 0; t < ntile; ++t) {
+    for (int t = t_first; t < ntile; ++t) {
         const int kv0 = t * 64;
         const int tl = opaque_i(tid), ll = opaque_i(lane);      // see forward
         const int hl = ll >> 5;
@@ -507,6 +537,19 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs a) {
         }
         __syncthreads();
     }
+    if (nsp > 1) {
+        if (qi < a.Sq) {
+            float* op = a.part_o + ((((long)b * a.Hq + hq) * nsp + sp) * a.Sq + qi) * HD;
+#pragma unroll
+            for (int db = 0; db < T::DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 w = {dq[db][4 * g + 0], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(op + db * 32 + 8 * g + 4 * h) = w;
+                }
+        }
+        return;
+    }
     if (qi < a.Sq) {
         bf16_t* op = a.dq + b * a.dq_sb + (long)qi * a.dq_ss + hq * a.dq_sh;
 #pragma unroll
@@ -545,6 +588,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs a) {
     int bx_, hkv, b;
     attn_block_coords(a.legacy_order, 0, bx_, hkv, b);                // (causal: key block 0 is the heaviest — ascending order is heaviest first)
     const int group = a.Hq / a.Hkv;
+    const int nsp = a.nsplit_kv > 1 ? a.nsplit_kv : 1;
+    const int sp = nsp > 1 ? bx_ % nsp : 0;
+    if (nsp > 1) bx_ /= nsp;
     const int k0 = bx_ * KROWS;
     const int kw0 = k0 + wave * 32;
     const int kj = kw0 + (lane & 31);                 // this lane's key
@@ -575,7 +621,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs a) {
     if (a.causal) { int first = k0 - a.q_off; qt_begin = first > 0 ? first / 64 : 0; }
     const int qt_end = (a.Sq + 63) / 64;
     const int per_head = qt_end > qt_begin ? qt_end - qt_begin : 0;
-    const int nit = per_head * group;
+    const int nit_all = per_head * group;
+    const int it_first = nsp > 1 ? (nit_all * sp) / nsp : 0;
+    const int nit = nsp > 1 ? (nit_all * (sp + 1)) / nsp : nit_all;          // this part's (q-head, query tile) iterations: [it_first, nit)
 
     u32x4 rq[(64 * T::CH) / NT], rd[DK ? (64 * T::CH) / NT : 1], rqt[DK ? (HD * 8) / NT : 1], rdt[DV ? (HD * 8) / NT : 1];
     float rl = 0.f;   // threads 0..63: lse, 64..127: delta
@@ -605,10 +653,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs a) {
         if constexpr (DV) store_trans<HD, NT>(s + OFF_DT, rdt, tid);
         if (tid < 128) reinterpret_cast<float*>(s + OFF_L)[tid] = rl;
     };
-    if (nit > 0) { issue(0, tid); commit(0, tid); }
+    if (nit > it_first) { issue(it_first, tid); commit(it_first & 1, tid); }
     __syncthreads();
 
-    for (int it = 0; it < nit; ++it) {
+    for (int it = it_first; it < nit; ++it) {
         const int s0 = (qt_begin + it % per_head) * 64;
         const char* sq = smem + (it & 1) * STAGE;
         const char* sd = sq + OFF_D;
@@ -677,6 +725,25 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
         if (more) commit((it + 1) & 1, tl);
         __syncthreads();
+    }
+    if (nsp > 1) {
+        if (kj < a.Sk) {
+            const long row = ((((long)b * a.Hkv + hkv) * nsp + sp) * a.Sk + kj) * HD;
+#pragma unroll
+            for (int db = 0; db < T::DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr (DK) {
+                        f32x4 w = {dk[db][4 * g + 0], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(a.part_dk + row + db * 32 + 8 * g + 4 * h) = w;
+                    }
+                    if constexpr (DV) {
+                        f32x4 w = {dv[db][4 * g + 0], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(a.part_dv + row + db * 32 + 8 * g + 4 * h) = w;
+                    }
+                }
+        }
+        return;
     }
     if (kj < a.Sk) {
         bf16_t* kp = a.dk + b * a.dk_sb + (long)kj * a.dk_ss + hkv * a.dk_sh;
@@ -917,11 +984,27 @@ static int launch_fwd(const AttnArgs& a, bra_stream_t st) {
     return BRA_LAUNCH_STATUS();
 }
 template <int HD>
+static int launch_sum_parts(const float* part, int ns, int B, int H, int S, bf16_t* out, long sb, long ss, long sh, bra_stream_t st) {
+    const long rows = (long)B * H * S;
+    constexpr int RPB = 256 / (HD / 4);
+    BRA_LAUNCH((attn_sum_parts_kernel<HD>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, part, ns, B, H, S, out, sb, ss, sh);
+    return BRA_LAUNCH_STATUS();
+}
+
+template <int HD>
 static int launch_dq(const AttnArgs& a, bra_stream_t st) {
     const size_t smem = 2 * (2 * Tile<HD>::KBYTES + Tile<HD>::TBYTES);
     if (HD >= 64 && a.Sq > 128) {
+        const int ns = a.nsplit > 1 ? a.nsplit : 1;
         BRA_ALLOW_SMEM((attn_bwd_dq_kernel<HD, (HD >= 64 ? 8 : 4)>), smem);
-        BRA_LAUNCH((attn_bwd_dq_kernel<HD, (HD >= 64 ? 8 : 4)>), dim3((a.Sq + 255) / 256, a.Hq, a.B), dim3(512), smem, st, a);
+        BRA_LAUNCH((attn_bwd_dq_kernel<HD, (HD >= 64 ? 8 : 4)>), dim3(((a.Sq + 255) / 256) * ns, a.Hq, a.B), dim3(512), smem, st, a);
+        if (ns > 1) {
+            int rc = BRA_LAUNCH_STATUS();
+            if (rc) return rc;
+            return launch_sum_parts<HD>(a.part_o, ns, a.B, a.Hq, a.Sq, a.dq, a.dq_sb, a.dq_ss, a.dq_sh, st);
+        }
+    } else if (a.nsplit > 1) {
+        return BRA_ERR_UNSUPPORTED;
     } else {
         BRA_ALLOW_SMEM((attn_bwd_dq_kernel<HD, 4>), smem);
         BRA_LAUNCH((attn_bwd_dq_kernel<HD, 4>), dim3((a.Sq + 127) / 128, a.Hq, a.B), dim3(256), smem, st, a);
@@ -938,6 +1021,21 @@ static int launch_dkv_v(const AttnArgs& a, bra_stream_t st) {
 }
 template <int HD>
 static int launch_dkv(const AttnArgs& a, bra_stream_t st) {
+    if (a.nsplit_kv > 1) {
+        // (one prompt: 144 four-wave workgroups with a triangular load — the (q-head, query tile) loop of every key block in parts;
+        //  only the one-launch dK + dV form is split: the shapes that take the two 8-wave kernels fill the chip)
+        const bool fused = HD < 128 || (a.Sk > 128 && (a.Sq <= 512 || (long)((a.Sk + 255) / 256) * a.Hkv * a.B < 256));
+        if (!fused) return BRA_ERR_UNSUPPORTED;
+        constexpr int NW4 = 4;
+        const size_t smem = 2 * (Tile<HD>::KBYTES + Tile<HD>::KBYTES + Tile<HD>::TBYTES + Tile<HD>::TBYTES + 512);
+        BRA_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, 0, NW4>), smem);
+        BRA_LAUNCH((attn_bwd_dkv_kernel<HD, 0, NW4>), dim3(((a.Sk + NW4 * 32 - 1) / (NW4 * 32)) * a.nsplit_kv, a.Hkv, a.B), dim3(NW4 * 64), smem, st, a);
+        int rc = BRA_LAUNCH_STATUS();
+        if (rc) return rc;
+        rc = launch_sum_parts<HD>(a.part_dk, a.nsplit_kv, a.B, a.Hkv, a.Sk, a.dk, a.dk_sb, a.dk_ss, a.dk_sh, st);
+        if (rc) return rc;
+        return launch_sum_parts<HD>(a.part_dv, a.nsplit_kv, a.B, a.Hkv, a.Sk, a.dv, a.dv_sb, a.dv_ss, a.dv_sh, st);
+    }
     if (HD < 128) return launch_dkv_v<HD, 0, 4>(a, st);
     constexpr int NW = HD >= 128 ? 8 : 4;              // 8 waves = 2 per SIMD share one staged query tile
     if (a.Sk <= 128) {
@@ -1015,14 +1113,15 @@ extern "C" int bra_attn_fwd_split(const void* q, long q_sb, long q_ss, long q_sh
     return launch_fwd<64>(a, st);
 }
 
-extern "C" int bra_attn_bwd(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss,
+static int attn_bwd_impl(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss,
                             long k_sh, const void* v, long v_sb, long v_ss, long v_sh, const void* dout, long do_sb,
                             long do_ss, long do_sh, const void* kt, long kt_sb, long kt_sh, long kt_sd,
                             const void* qt, long qt_sb, long qt_sh, long qt_sd, const void* dot, long dot_sb,
                             long dot_sh, long dot_sd, const float* lse, const float* delta, const void* kmask,
                             void* dq, long dq_sb, long dq_ss, long dq_sh, void* dk, long dk_sb, long dk_ss,
                             long dk_sh, void* dv, long dv_sb, long dv_ss, long dv_sh, int B, int Hq, int Hkv,
-                            int Sq, int Sk, int hd, int causal, int q_off, float scale, void* stream) {
+                            int Sq, int Sk, int hd, int causal, int q_off, float scale, int nsplit_dq, float* part_dq, int nsplit_kv, float* part_dk,
+                            float* part_dv, void* stream) {
     int e = attn_check(B, Hq, Hkv, Sq, Sk, hd);
     if (e) return e;
     if (!q || !k || !v || !dout || !kt || !qt || !dot || !lse || !delta || !dq || !dk || !dv) return BRA_ERR_ARG;
@@ -1042,11 +1141,46 @@ extern "C" int bra_attn_bwd(const void* q, long q_sb, long q_ss, long q_sh, cons
     a.dv = (bf16_t*)dv; a.dv_sb = dv_sb; a.dv_ss = dv_ss; a.dv_sh = dv_sh;
     a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = Sq; a.Sk = Sk; a.causal = causal; a.q_off = q_off; a.scale = scale;
     a.legacy_order = g_attn_legacy_order;
+    if (nsplit_dq > 1) { if (nsplit_dq > 8 || !part_dq) return BRA_ERR_ARG; a.nsplit = nsplit_dq; a.part_o = part_dq; }
+    if (nsplit_kv > 1) { if (nsplit_kv > 8 || !part_dk || !part_dv) return BRA_ERR_ARG; a.nsplit_kv = nsplit_kv; a.part_dk = part_dk; a.part_dv = part_dv; }
+    if ((nsplit_dq > 1 || nsplit_kv > 1) && ((dq_sb | dq_ss | dq_sh | dk_sb | dk_ss | dk_sh | dv_sb | dv_ss | dv_sh) & 3)) return BRA_ERR_ARG;
     bra_stream_t st = (bra_stream_t)stream;
     int r;
     if (hd == 128) { r = launch_dq<128>(a, st); if (r) return r; return launch_dkv<128>(a, st); }
     if (hd == 64) { r = launch_dq<64>(a, st); if (r) return r; return launch_dkv<64>(a, st); }
     r = launch_dq<32>(a, st); if (r) return r; return launch_dkv<32>(a, st);
+}
+
+extern "C" int bra_attn_bwd(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss,
+                            long k_sh, const void* v, long v_sb, long v_ss, long v_sh, const void* dout, long do_sb,
+                            long do_ss, long do_sh, const void* kt, long kt_sb, long kt_sh, long kt_sd,
+                            const void* qt, long qt_sb, long qt_sh, long qt_sd, const void* dot, long dot_sb,
+                            long dot_sh, long dot_sd, const float* lse, const float* delta, const void* kmask,
+                            void* dq, long dq_sb, long dq_ss, long dq_sh, void* dk, long dk_sb, long dk_ss,
+                            long dk_sh, void* dv, long dv_sb, long dv_ss, long dv_sh, int B, int Hq, int Hkv,
+                            int Sq, int Sk, int hd, int causal, int q_off, float scale, void* stream) {
+    return attn_bwd_impl(q, q_sb, q_ss, q_sh, k, k_sb, k_ss, k_sh, v, v_sb, v_ss, v_sh, dout, do_sb, do_ss, do_sh, kt, kt_sb, kt_sh, kt_sd,
+                         qt, qt_sb, qt_sh, qt_sd, dot, dot_sb, dot_sh, dot_sd, lse, delta, kmask, dq, dq_sb, dq_ss, dq_sh, dk, dk_sb, dk_ss,
+                         dk_sh, dv, dv_sb, dv_ss, dv_sh, B, Hq, Hkv, Sq, Sk, hd, causal, q_off, scale, 1, nullptr, 1, nullptr, nullptr, stream);
+}
+
+// bra_attn_bwd for grids that cannot fill the chip: the dQ kernel's key range in `nsplit_dq` parts (part_dq fp32 [B, Hq, nsplit_dq, Sq,
+// hd]), the one-launch dK + dV kernel's (q-head, query tile) loop in `nsplit_kv` parts (part_dk / part_dv fp32 [B, Hkv, nsplit_kv, Sk,
+// hd]); the parts are added in order by a sum launch each.  1 = no split for that kernel.  Same per-tile arithmetic.
+extern "C" int bra_attn_bwd_split(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss,
+                                  long k_sh, const void* v, long v_sb, long v_ss, long v_sh, const void* dout, long do_sb,
+                                  long do_ss, long do_sh, const void* kt, long kt_sb, long kt_sh, long kt_sd,
+                                  const void* qt, long qt_sb, long qt_sh, long qt_sd, const void* dot, long dot_sb,
+                                  long dot_sh, long dot_sd, const float* lse, const float* delta, const void* kmask,
+                                  void* dq, long dq_sb, long dq_ss, long dq_sh, void* dk, long dk_sb, long dk_ss,
+                                  long dk_sh, void* dv, long dv_sb, long dv_ss, long dv_sh, int B, int Hq, int Hkv,
+                                  int Sq, int Sk, int hd, int causal, int q_off, float scale, int nsplit_dq, float* part_dq,
+                                  int nsplit_kv, float* part_dk, float* part_dv, void* stream) {
+    if (nsplit_dq < 1 || nsplit_kv < 1) return BRA_ERR_ARG;
+    return attn_bwd_impl(q, q_sb, q_ss, q_sh, k, k_sb, k_ss, k_sh, v, v_sb, v_ss, v_sh, dout, do_sb, do_ss, do_sh, kt, kt_sb, kt_sh, kt_sd,
+                         qt, qt_sb, qt_sh, qt_sd, dot, dot_sb, dot_sh, dot_sd, lse, delta, kmask, dq, dq_sb, dq_ss, dq_sh, dk, dk_sb, dk_ss,
+                         dk_sh, dv, dv_sb, dv_ss, dv_sh, B, Hq, Hkv, Sq, Sk, hd, causal, q_off, scale, nsplit_dq, part_dq, nsplit_kv, part_dk,
+                         part_dv, stream);
 }
 
 extern "C" int bra_attn_set_block_order(int legacy) { g_attn_legacy_order = legacy ? 1 : 0; return 0; }

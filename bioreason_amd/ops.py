@@ -337,8 +337,21 @@ def attn_fwd_split_parts(B: int, Hq: int, Sq: int, Sk: int, hd: int, causal: boo
     return max(1, min(4, (300 + wgs // 2) // wgs))
 
 
-def attn_bwd(q, k, v, o, dout, lse, kmask, causal: bool, scale: float, q_off: Optional[int] = None):
-    """all of q,k,v,o,dout are [B,S,H,hd] views; returns dq, dk, dv (contiguous [B,S,H,hd])"""
+def attn_bwd_split_parts(B: int, Hq: int, Hkv: int, Sq: int, Sk: int, hd: int, causal: bool):
+    """-> (key parts of the dQ kernel, loop parts of the one-launch dK + dV kernel); (1, 1) for grids that fill the chip"""
+    ns_dq = attn_fwd_split_parts(B, Hq, Sq, Sk, hd, causal)              # same grid as the forward: 256-query workgroups
+    ns_kv = 1
+    if ATTN_SPLIT and hd >= 64 and Sq >= 1024 and Sk > 128:
+        wgs = ((Sk + 127) // 128) * Hkv * B                              # 128-key workgroups of the one-launch form
+        fused = hd < 128 or ((Sk + 255) // 256) * Hkv * B < 256          # (k_attn.hip launch_dkv: Sq > 512 here)
+        if fused and wgs < 200:
+            ns_kv = max(1, min(4, (300 + wgs // 2) // wgs))
+    return ns_dq, ns_kv
+
+
+def attn_bwd(q, k, v, o, dout, lse, kmask, causal: bool, scale: float, q_off: Optional[int] = None, nsplit=None):
+    """all of q,k,v,o,dout are [B,S,H,hd] views; returns dq, dk, dv (contiguous [B,S,H,hd]).  `nsplit` = (dQ parts, dK/dV parts) or
+    None: chosen by the grid size (attn_bwd_split_parts)"""
     B, Sq, Hq, hd = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
     if q_off is None:
@@ -353,6 +366,17 @@ def attn_bwd(q, k, v, o, dout, lse, kmask, causal: bool, scale: float, q_off: Op
     dq = torch.empty((B, Sq, Hq, hd), dtype=BF16, device=q.device)
     dk = torch.empty((B, Sk, Hkv, hd), dtype=BF16, device=q.device)
     dv = torch.empty((B, Sk, Hkv, hd), dtype=BF16, device=q.device)
+    ns_dq, ns_kv = attn_bwd_split_parts(B, Hq, Hkv, Sq, Sk, hd, causal) if nsplit is None else nsplit
+    if ns_dq > 1 or ns_kv > 1:
+        part_dq = torch.empty((B, Hq, ns_dq, Sq, hd), dtype=torch.float32, device=q.device) if ns_dq > 1 else None
+        part_dk = torch.empty((B, Hkv, ns_kv, Sk, hd), dtype=torch.float32, device=q.device) if ns_kv > 1 else None
+        part_dv = torch.empty((B, Hkv, ns_kv, Sk, hd), dtype=torch.float32, device=q.device) if ns_kv > 1 else None
+        lib.call("bra_attn_bwd_split", q, *_bsh_strides(q), k, *_bsh_strides(k), v, *_bsh_strides(v), dout, *_bsh_strides(dout),
+                 kt, kt.stride(0), kt.stride(1), kt.stride(2), qt, qt.stride(0), qt.stride(1), qt.stride(2),
+                 dot, dot.stride(0), dot.stride(1), dot.stride(2), lse, delta, kmask,
+                 dq, *_bsh_strides(dq), dk, *_bsh_strides(dk), dv, *_bsh_strides(dv),
+                 B, Hq, Hkv, Sq, Sk, hd, int(causal), q_off, scale, ns_dq, part_dq, ns_kv, part_dk, part_dv, st)
+        return dq, dk, dv
     lib.call("bra_attn_bwd", q, *_bsh_strides(q), k, *_bsh_strides(k), v, *_bsh_strides(v), dout, *_bsh_strides(dout),
              kt, kt.stride(0), kt.stride(1), kt.stride(2), qt, qt.stride(0), qt.stride(1), qt.stride(2),
              dot, dot.stride(0), dot.stride(1), dot.stride(2), lse, delta, kmask,

@@ -167,6 +167,16 @@ int bra_attn_bwd(const void* q, long q_sb, long q_ss, long q_sh, const void* k, 
                  const float* delta, const void* kmask, void* dq, long dq_sb, long dq_ss, long dq_sh, void* dk,
                  long dk_sb, long dk_ss, long dk_sh, void* dv, long dv_sb, long dv_ss, long dv_sh, int B, int Hq,
                  int Hkv, int Sq, int Sk, int hd, int causal, int q_off, float scale, void* stream);
+/* bra_attn_bwd for grids that cannot fill the 256 CUs: the dQ kernel's key range in `nsplit_dq` parts (part_dq fp32 [B, Hq, nsplit_dq,
+ * Sq, hd]), the one-launch dK + dV kernel's (q-head, query tile) loop in `nsplit_kv` parts (part_dk / part_dv fp32 [B, Hkv, nsplit_kv,
+ * Sk, hd]); the parts are added in order by a sum launch each; 1 = that kernel is not split. */
+int bra_attn_bwd_split(const void* q, long q_sb, long q_ss, long q_sh, const void* k, long k_sb, long k_ss, long k_sh,
+                 const void* v, long v_sb, long v_ss, long v_sh, const void* dout, long do_sb, long do_ss, long do_sh,
+                 const void* kt, long kt_sb, long kt_sh, long kt_sd, const void* qt, long qt_sb, long qt_sh,
+                 long qt_sd, const void* dot, long dot_sb, long dot_sh, long dot_sd, const float* lse,
+                 const float* delta, const void* kmask, void* dq, long dq_sb, long dq_ss, long dq_sh, void* dk,
+                 long dk_sb, long dk_ss, long dk_sh, void* dv, long dv_sb, long dv_ss, long dv_sh, int B, int Hq,
+                 int Hkv, int Sq, int Sk, int hd, int causal, int q_off, float scale, int nsplit_dq, float* part_dq, int nsplit_kv, float* part_dk, float* part_dv, void* stream);
 /* one decode step over the KV cache [B,Hkv,Smax,hd] (HF DynamicCache + sdpa, TF:generation/utils.py:2876-2925).
  * part_o f32 [B,Hq,nchunk,hd], part_ml f32 [B,Hq,nchunk,2], nchunk = bra_attn_decode_nchunk(len). */
 int bra_attn_decode_nchunk(int len);

@@ -237,6 +237,34 @@ def test_attn_fwd_bwd(backend, hd, Hq, Hkv, Sq, Sk, causal, pad):
 
 
 
+@pytest.mark.parametrize("hd,Hq,Hkv,Sq,Sk,causal,pad,ns", [(128, 4, 2, 300, 300, True, "left", (2, 2)), (128, 2, 1, 256, 700, True, None, (3, 1)),
+                                                         (64, 2, 2, 200, 200, False, "right", (2, 3)), (128, 4, 1, 520, 520, True, None, (4, 4)),
+                                                         (128, 2, 2, 600, 600, True, None, (1, 2))])
+def test_attn_bwd_split_equals_unsplit(backend, hd, Hq, Hkv, Sq, Sk, causal, pad, ns):
+    """the backward with the dQ kernel's key range and the one-launch dK + dV kernel's (q-head, query tile) loop cut into parts + the
+    sum launches (bra_attn_bwd_split) against the one-part backward: the parts stay fp32 and are added in order, so the results differ
+    from the unsplit kernels only by fp32 re-association before the one bf16 rounding (TF:qwen3:185-207 backward)"""
+    B = 2
+    q, k, v = rnd(B, Sq, Hq, hd, dev=backend, seed=1), rnd(B, Sk, Hkv, hd, dev=backend, seed=2), rnd(B, Sk, Hkv, hd, dev=backend, seed=3)
+    do = rnd(B, Sq, Hq, hd, dev=backend, seed=4)
+    kmask = torch.ones(B, Sk, dtype=torch.uint8, device=backend)
+    if pad == "left":
+        kmask[0, :70] = 0
+    elif pad == "right":
+        kmask[1, Sk - 13:] = 0
+    scale = hd ** -0.5
+    vt = ops.head_transpose(v)
+    o, lse = ops.attn_fwd(q, k, vt, kmask if pad else None, causal, scale, nsplit=1)
+    want = ops.attn_bwd(q, k, v, o, do, lse, kmask if pad else None, causal, scale, nsplit=(1, 1))
+    got = ops.attn_bwd(q, k, v, o, do, lse, kmask if pad else None, causal, scale, nsplit=ns)
+    for g_, w_, nm in zip(got, want, ("dq", "dk", "dv")):
+        assert rel(g_, w_) < 3e-3, nm
+        assert torch.isfinite(g_.float()).all()
+    assert ops.attn_bwd_split_parts(8, 16, 8, 2436, 2436, 128, True) == (1, 1)
+    assert ops.attn_bwd_split_parts(1, 16, 8, 2180, 2180, 128, True) == (2, 2)
+    assert ops.attn_bwd_split_parts(8, 16, 8, 256, 2436, 128, True) == (2, 1)
+
+
 @pytest.mark.parametrize("hd,Hq,Hkv,Sq,Sk,causal,pad,ns", [(128, 4, 2, 300, 300, True, "left", 2), (128, 2, 1, 256, 700, True, None, 3),
                                                          (64, 2, 2, 200, 200, False, "right", 2), (128, 4, 2, 520, 520, True, None, 4)])
 def test_attn_fwd_split_equals_unsplit(backend, hd, Hq, Hkv, Sq, Sk, causal, pad, ns):
