@@ -332,6 +332,9 @@ using namespace bra;
 
 static inline int ew_grid(long n) {
     long g = (n + 255) / 256;
+#ifdef BRA_EMU
+    if (g > 32) g = 32;                  // (host executor: one fiber per thread — the kernels are grid-stride loops, a small grid is the same work)
+#endif
     if (g > 2048) g = 2048;
     if (g < 1) g = 1;
     return (int)g;

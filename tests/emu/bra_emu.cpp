@@ -4,12 +4,41 @@
 // fiber that cannot proceed yields to the round-robin scheduler.
 #include "bra_emu.h"
 
-#include <ucontext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
+
+#if !defined(__x86_64__)
+#error "bra_emu's fiber switch is written for x86-64 (System V ABI)"
+#endif
+
+// Fiber switch: callee-saved registers + stack pointer, nothing else (glibc's swapcontext also saves the signal mask — one
+// rt_sigprocmask system call per switch, and a kernel under this executor switches fibers at every barrier and wave exchange).
+extern "C" void bra_emu_switch(void** save_sp, void* const* load_sp);
+__asm__(
+    ".text\n"
+    ".globl bra_emu_switch\n"
+    ".type bra_emu_switch,@function\n"
+    "bra_emu_switch:\n"
+    "    pushq %rbp\n"
+    "    pushq %rbx\n"
+    "    pushq %r12\n"
+    "    pushq %r13\n"
+    "    pushq %r14\n"
+    "    pushq %r15\n"
+    "    movq %rsp, (%rdi)\n"
+    "    movq (%rsi), %rsp\n"
+    "    popq %r15\n"
+    "    popq %r14\n"
+    "    popq %r13\n"
+    "    popq %r12\n"
+    "    popq %rbx\n"
+    "    popq %rbp\n"
+    "    ret\n"
+    ".size bra_emu_switch, .-bra_emu_switch\n");
 
 namespace bra_emu {
 
@@ -22,14 +51,14 @@ constexpr size_t kStackBytes = 256 * 1024;
 constexpr int kXWords = 16;  // 32-bit words per lane per exchange
 
 struct Fiber {
-    ucontext_t ctx;
+    void* sp = nullptr;          // saved stack pointer while the fiber is switched out
     char* stack = nullptr;
     bool done = false;
     unsigned coll = 0;  // number of wave exchanges this lane has done
 };
 
 struct Worker {
-    ucontext_t sched;
+    void* sched = nullptr;       // saved stack pointer of the scheduler loop
     std::vector<Fiber> fibers;
     int nthreads = 0;
     int cur = 0;
@@ -50,7 +79,22 @@ thread_local Worker* W = nullptr;
 
 void yield_to_sched() {
     Worker* w = W;
-    swapcontext(&w->fibers[w->cur].ctx, &w->sched);
+    bra_emu_switch(&w->fibers[w->cur].sp, &w->sched);
+}
+
+// fiber stacks are kept for the life of the process (a launch of 512-thread workgroups would otherwise map and fault 128 MB per worker)
+std::mutex g_stack_mu;
+std::vector<char*> g_stack_pool;
+char* stack_get() {
+    {
+        std::lock_guard<std::mutex> lk(g_stack_mu);
+        if (!g_stack_pool.empty()) { char* p = g_stack_pool.back(); g_stack_pool.pop_back(); return p; }
+    }
+    return (char*)aligned_alloc(64, kStackBytes);
+}
+void stack_put(char* p) {
+    std::lock_guard<std::mutex> lk(g_stack_mu);
+    g_stack_pool.push_back(p);
 }
 
 void fiber_entry() {
@@ -71,7 +115,8 @@ void fiber_entry() {
         w->wave_arrived[wv] = 0;
         w->wave_gen[wv]++;
     }
-    swapcontext(&f.ctx, &w->sched);
+    bra_emu_switch(&f.sp, &w->sched);
+    abort();                     // (a finished fiber is never resumed)
 }
 
 void set_thread_idx(Worker* w, int lin) {
@@ -97,11 +142,13 @@ void run_block(Worker* w) {
         Fiber& f = w->fibers[i];
         f.done = false;
         f.coll = 0;
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = kStackBytes;
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        // first switch into the fiber: six zeroed callee-saved registers are popped, `ret` enters fiber_entry with the stack
+        // aligned as after a call (one dummy return-address slot below the 16-byte aligned top)
+        uint64_t* sp = (uint64_t*)(((uintptr_t)f.stack + kStackBytes) & ~(uintptr_t)15);
+        *--sp = 0;
+        *--sp = (uint64_t)(uintptr_t)&fiber_entry;
+        for (int r = 0; r < 6; ++r) *--sp = 0;
+        f.sp = sp;
     }
     while (w->alive > 0) {
         uint64_t before = w->progress;
@@ -109,7 +156,7 @@ void run_block(Worker* w) {
             if (w->fibers[i].done) continue;
             w->cur = i;
             set_thread_idx(w, i);
-            swapcontext(&w->sched, &w->fibers[i].ctx);
+            bra_emu_switch(&w->sched, &w->fibers[i].sp);
         }
         if (w->progress == before && w->alive > 0) {
             fprintf(stderr, "bra_emu: deadlock in block (%u,%u,%u): %d fibers alive, %d at barrier\n",
@@ -182,7 +229,7 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<vo
         w.nthreads = T;
         w.body = &body;
         w.fibers.resize(T);
-        for (int i = 0; i < T; ++i) w.fibers[i].stack = (char*)malloc(kStackBytes);
+        for (int i = 0; i < T; ++i) w.fibers[i].stack = stack_get();
         w.xbuf = (uint32_t*)malloc(sizeof(uint32_t) * 2 * kMaxWaves * 64 * kXWords);
         w.smem_cap = dyn_smem_bytes + 64;
         w.smem = (char*)aligned_alloc(64, (w.smem_cap + 63) / 64 * 64);
@@ -196,7 +243,7 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<vo
             t_blockIdx.z = (unsigned)(b / ((size_t)grid.x * grid.y));
             run_block(&w);
         }
-        for (int i = 0; i < T; ++i) free(w.fibers[i].stack);
+        for (int i = 0; i < T; ++i) stack_put(w.fibers[i].stack);
         free(w.xbuf);
         free(w.smem);
         W = nullptr;

@@ -22,6 +22,12 @@ def _makefile_flags():
 
 
 def _asm(src, tmp_path):
+    # `make isa` (run by __graft_entry__.build() beside the library) leaves the same assembly under csrc/build: taken when it is
+    # newer than every source it depends on, otherwise compiled here (1-2 minutes for k_decgemm.hip)
+    made = os.path.join(CSRC, "build", src.replace(".hip", ".s"))
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip")) or f == "Makefile"]
+    if os.path.exists(made) and os.path.getmtime(made) >= max(os.path.getmtime(d) for d in deps):
+        return open(made).read()
     out = os.path.join(str(tmp_path), src + ".s")
     subprocess.run([HIPCC, *_makefile_flags(), "-I", CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out], check=True,
                    stderr=subprocess.DEVNULL)
