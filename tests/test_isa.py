@@ -25,7 +25,7 @@ def _asm(src, tmp_path):
     # `make isa` (run by __graft_entry__.build() beside the library) leaves the same assembly under csrc/build: taken when it is
     # newer than every source it depends on, otherwise compiled here (1-2 minutes for k_decgemm.hip)
     made = os.path.join(CSRC, "build", src.replace(".hip", ".s"))
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip")) or f == "Makefile"]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f in (src, "Makefile")]      # = the Makefile rule's
     if os.path.exists(made) and os.path.getmtime(made) >= max(os.path.getmtime(d) for d in deps):
         return open(made).read()
     out = os.path.join(str(tmp_path), src + ".s")
