@@ -408,6 +408,66 @@ def decode_step(model, tok: torch.Tensor, cache: KVCache, kmask: torch.Tensor, p
     return ops.rmsnorm_fwd(x, eng.norm_w, eng.eps)
 
 
+MAX_DECODE_ROWS = 16            # sequences per launch of the streaming decode kernels (bra_dec_gemm2: one 16-row MFMA tile)
+
+
+def _row_chunks(B: int, prompt_alias):
+    """[lo, hi) row ranges of at most MAX_DECODE_ROWS rows: consecutive whole prompt groups (rows with the same alias) where they
+    fit, a larger group in pieces"""
+    if prompt_alias is None:
+        runs = [(i, i + 1) for i in range(B)]
+    else:
+        al = [int(a) for a in prompt_alias]
+        runs, lo = [], 0
+        for i in range(1, B + 1):
+            if i == B or al[i] != al[lo]:
+                runs.append((lo, i))
+                lo = i
+    chunks, cur = [], None
+    for lo, hi in runs:
+        while hi - lo > MAX_DECODE_ROWS:                       # a group of more than 16 copies: pieces of 16
+            if cur is not None:
+                chunks.append(cur)
+                cur = None
+            chunks.append((lo, lo + MAX_DECODE_ROWS))
+            lo += MAX_DECODE_ROWS
+        if cur is not None and hi - cur[0] <= MAX_DECODE_ROWS:
+            cur = (cur[0], hi)
+        else:
+            if cur is not None:
+                chunks.append(cur)
+            cur = (lo, hi)
+    if cur is not None:
+        chunks.append(cur)
+    return chunks
+
+
+def _generate_in_row_chunks(model, inputs_embeds, attention_mask, prompt_alias, force_tokens, eos_schedule, seed, kw):
+    B = inputs_embeds.shape[0]
+    eos_ = kw["eos_token_id"]
+    eos0 = (list(eos_)[0] if len(eos_) else None) if isinstance(eos_, (list, tuple)) else eos_
+    pad = int(kw["pad_token_id"]) if kw["pad_token_id"] is not None else (int(eos0) if eos0 is not None else 0)
+    outs = []
+    for ci, (lo, hi) in enumerate(_row_chunks(B, prompt_alias)):
+        alias = None
+        if prompt_alias is not None:
+            al = [int(a) for a in prompt_alias[lo:hi]]
+            first = {}
+            alias = [first.setdefault(a, i) for i, a in enumerate(al)]          # re-based: index of the group's first row in the chunk
+        outs.append(generate(model, inputs_embeds[lo:hi], attention_mask[lo:hi], prompt_alias=alias,
+                             force_tokens=None if force_tokens is None else force_tokens[lo:hi],
+                             eos_schedule=None if eos_schedule is None else eos_schedule[lo:hi].contiguous(),
+                             seed=seed + 7919 * ci,                               # rows restart at 0 in every chunk: distinct draw streams
+                             **kw))
+    T = max(o.shape[1] for o in outs)
+    full = torch.full((B, T), pad, dtype=torch.long, device=inputs_embeds.device)
+    r = 0
+    for o in outs:
+        full[r:r + o.shape[0], :o.shape[1]] = o
+        r += o.shape[0]
+    return full
+
+
 @torch.no_grad()
 def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int = 20,
              do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
@@ -430,6 +490,16 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     eng = model.ensure_packed()
     B, P, H = inputs_embeds.shape
     dev = inputs_embeds.device
+    if B > MAX_DECODE_ROWS and native_step and decode_impl == "fused":
+        # the streaming decode kernels take up to 16 sequences per launch (one MFMA tile of rows); the reference's
+        # per_device_train_batch_size is free (grpo_config.py), so larger batches run as consecutive row chunks — whole prompt
+        # groups where they fit — each with its own prefill, cache and token loop
+        return _generate_in_row_chunks(model, inputs_embeds, attention_mask, prompt_alias, force_tokens, eos_schedule, seed,
+                                       dict(max_new_tokens=max_new_tokens, do_sample=do_sample, temperature=temperature, top_k=top_k,
+                                            top_p=top_p, eos_token_id=eos_token_id, pad_token_id=pad_token_id, check_every=check_every,
+                                            return_full_length=return_full_length, native_step=native_step, decode_impl=decode_impl,
+                                            use_graph=use_graph, shared_prefix_decode=shared_prefix_decode, profile=profile,
+                                            loop_events=loop_events))
     import time as _time
     _t0 = [_time.perf_counter()]
 

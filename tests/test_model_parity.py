@@ -454,3 +454,46 @@ def test_graph_replayed_rollout_equals_eager_rollout(backend, alias):
         g_e = m.generate(input_ids=ids, attention_mask=mask, **mm, **extra, use_graph=False, **kw)
         g_g = m.generate(input_ids=ids, attention_mask=mask, **mm, **extra, use_graph=True, **kw)
         assert g_e.shape == g_g.shape and (g_e == g_g).all()
+
+
+def test_decode_with_more_than_sixteen_sequences(backend):
+    """20 sequences (2 prompts x 10 copies, more than the 16 rows the streaming projections take): `generate` must still run —
+    the reference's `per_device_train_batch_size` is free (grpo_config.py) — on whichever kernels take that many rows, with the same
+    choices as the op-by-op decode under teacher forcing and sampled draws inside the warped support"""
+    fix = torch.load(os.path.join(GOLD, "tiny_b.pt"), weights_only=False)
+    cfg = fix["config"]
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    rows = [0] * 10 + [1] * 10
+    ids, mask = b["input_ids"][rows], b["attention_mask"][rows]
+    dna = {k: v[rows] for k, v in b["dna_tokenized"].items()}
+    mm = {"dna_tokenized": dna, "batch_idx_map": list(range(20))}
+    want = fix["fp32_lora"]["greedy_ids"][rows].to(backend)
+    scores = fix["fp32_lora"]["greedy_scores"][rows]
+    kw = dict(max_new_tokens=cfg["gen_tokens"], do_sample=False, eos_token_id=None, force_tokens=want)
+    g_u = m.generate(input_ids=ids, attention_mask=mask, **mm, decode_impl="unfused", **kw)
+    g_s = m.generate(input_ids=ids, attention_mask=mask, **mm, prompt_alias=[0] * 10 + [10] * 10, **kw)
+    assert g_s.shape == g_u.shape == (20, cfg["gen_tokens"])
+    diff = (g_u != g_s).nonzero().tolist()
+    for bi, t in diff:
+        a, c = int(g_u[bi, t]), int(g_s[bi, t])
+        assert abs((scores[bi, t, a] - scores[bi, t, c]).item()) < 0.02 * scores[bi, t].abs().max().item() + 0.05
+    assert len(diff) <= 6
+    # the copies of a prompt are the same sequence under teacher forcing: identical choices within a group
+    for lo in (0, 10):
+        assert all(torch.equal(g_s[lo], g_s[lo + j]) for j in range(1, 10))
+    s = m.generate(input_ids=ids, attention_mask=mask, **mm, prompt_alias=[0] * 10 + [10] * 10, max_new_tokens=3, do_sample=True,
+                   temperature=0.6, top_k=20, top_p=0.95, eos_token_id=None, seed=5)
+    assert s.shape == (20, 3) and int(s.min()) >= 0 and int(s.max()) < cfg["text"]["vocab_size"]
+
+
+def test_row_chunks_of_a_large_batch():
+    from bioreason_amd.generation import _row_chunks
+    assert _row_chunks(24, [0] * 8 + [8] * 8 + [16] * 8) == [(0, 16), (16, 24)]          # whole groups where they fit
+    assert _row_chunks(20, [0] * 10 + [10] * 10) == [(0, 10), (10, 20)]
+    assert _row_chunks(20, [0] * 20) == [(0, 16), (16, 20)]                              # one group of 20 copies: pieces
+    assert _row_chunks(40, None) == [(0, 16), (16, 32), (32, 40)]
+    assert _row_chunks(21, [0] * 18 + [18] * 3) == [(0, 16), (16, 21)]                   # a leftover piece rides with the next group
+    for B, al in [(24, [0] * 8 + [8] * 8 + [16] * 8), (21, [0] * 18 + [18] * 3), (40, None)]:
+        ch = _row_chunks(B, al)
+        assert ch[0][0] == 0 and ch[-1][1] == B and all(a[1] == b[0] for a, b in zip(ch, ch[1:])) and all(h - l <= 16 for l, h in ch)
