@@ -366,14 +366,40 @@ class GRPOStepRunner(_DataParallelStep):
 
 
 # =============================================================================================== SFT
+def cosine_schedule_with_warmup(base_lr: float, total_steps: int, warmup_ratio: float = 0.1) -> Callable[[int], float]:
+    """train_dna_qwen.py:393-411: `get_cosine_schedule_with_warmup(optimizer, int(0.1 * total_steps), total_steps)` stepped once per
+    optimiser step — the rate of optimiser step `i` (0-based) is base_lr x lambda(i), lambda as in transformers/optimization.py
+    (`_get_cosine_schedule_with_warmup_lr_lambda`, half a cosine period): linear from 0 over the warm-up steps, then
+    0.5 (1 + cos(pi progress)) down to 0 at `total_steps`.  tests/test_sft_runner.py holds it equal to the installed scheduler."""
+    import math
+    total = max(1, int(total_steps))
+    warm = int(warmup_ratio * total)
+
+    def rate(i: int) -> float:
+        if i < warm:
+            return base_lr * float(i) / float(max(1, warm))
+        prog = float(i - warm) / float(max(1, total - warm))
+        return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+    return rate
+
+
 class SFTStepRunner(_DataParallelStep):
-    """train_dna_qwen.py:179-213 + :393-397: forward (loss + full-row logits, `outputs.logits` being part of the model
-    contract), backward, DDP-mean of the gradients, AdamW.  One call = one optimiser step over one local batch."""
+    """train_dna_qwen.py:179-213 + :393-411 + the trainer settings of :985-1005: forward (loss + full-row logits, `outputs.logits` being
+    part of the model contract), backward, DDP-mean of the gradients, clip at 1.0, AdamW.  One call = one micro-batch; the optimiser
+    runs when the accumulation cycle closes (`accumulate_grad_batches`: the loss of a micro-batch is divided by the cycle length,
+    the data-parallel sum is taken once, from inside the last backward of the cycle).  `lr_schedule` (optimiser step -> rate;
+    `cosine_schedule_with_warmup` is the reference's) replaces the constant `learning_rate` when set."""
 
     def __init__(self, model, learning_rate: float = 1e-4, weight_decay: float = 0.01, max_grad_norm: float = 1.0,
-                 n_buckets: int = 4, return_logits: bool = True):
+                 n_buckets: int = 4, return_logits: bool = True, gradient_accumulation_steps: int = 1,
+                 lr_schedule: Optional[Callable[[int], float]] = None):
         super().__init__(model, n_buckets)
         self.lr, self.wd, self.max_grad_norm, self.return_logits = learning_rate, weight_decay, max_grad_norm, return_logits
+        self.ga = max(1, int(gradient_accumulation_steps))
+        self.lr_schedule = lr_schedule
+        self.global_step = 0                # optimiser steps taken
+        self._micro = 0                     # micro-batches seen
+        self.last_lr = learning_rate
         if hasattr(model.text_model, "set_dropout_seed"):
             model.text_model.set_dropout_seed(23 * 1000003 + self.rank)
 
@@ -384,16 +410,26 @@ class SFTStepRunner(_DataParallelStep):
         if timing:
             self.timers.clear()
         mark("start")
-        m.arena.zero_grad()
-        self.begin_backward()
+        slot = self._micro % self.ga
+        self._micro += 1
+        if slot == 0:
+            m.arena.zero_grad()
+        if slot == self.ga - 1:
+            self.begin_backward()
         out = m(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], dna_tokenized=batch["dna_tokenized"],
                 batch_idx_map=batch["batch_idx_map"], labels=batch["labels"], return_logits=self.return_logits)
         mark("forward")
-        out.loss.backward()
+        (out.loss / self.ga if self.ga > 1 else out.loss).backward()
         mark("backward")
-        scale = self.reduce_gradients()
-        m.arena.adamw_step(self.lr, (0.9, 0.999), 1e-8, self.wd, max_grad_norm=self.max_grad_norm, grad_scale=scale)
+        res = {"loss_t": out.loss.detach()}
+        if slot == self.ga - 1:
+            scale = self.reduce_gradients()
+            lr = self.lr if self.lr_schedule is None else float(self.lr_schedule(self.global_step))
+            self.last_lr = lr
+            m.arena.adamw_step(lr, (0.9, 0.999), 1e-8, self.wd, max_grad_norm=self.max_grad_norm, grad_scale=scale)
+            self.global_step += 1
+            res["stepped"] = True
         mark("optimizer")
         if timing:
             self._close_marks(marks)
-        return {"loss_t": out.loss.detach()}
+        return res
