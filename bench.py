@@ -500,6 +500,8 @@ def main():
     ap.add_argument("--no-overlap-ref", action="store_true", help="reference-policy pass on the main stream instead of beside the policy forward")
     ap.add_argument("--no-shared-policy", action="store_true",
                     help="policy forward / backward over every row's full prompt (independent LoRA-dropout masks per copy, as the reference draws them)")
+    ap.add_argument("--no-w4-gemm", action="store_true",
+                    help="A/B on one box: the per-shape GEMM choice without the four-wave large-tile kernel (bra_gemm_set_variant(-2))")
     ap.add_argument("--round3-kernels", action="store_true",
                     help="A/B on one box: round 3's kernel choices (256-row LDS-DMA tiles only, block-index-fastest attention grids, "
                          "full-scan sampler + advance_counters launch); a secondary measurement, never the headline")
@@ -546,8 +548,12 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
 
     from bioreason_amd import ops
+    if args.no_w4_gemm:
+        from bioreason_amd._lib import get_lib
+        get_lib().call("bra_gemm_set_variant", -2)
     if args.round3_kernels:
         from bioreason_amd._lib import get_lib
+        get_lib().call("bra_gemm_set_variant", -2)
         get_lib().call("bra_gemm_set_glds_rows", 256)
         get_lib().call("bra_attn_set_block_order", 1)
         os.environ["BRA_SAMPLE_TILES"] = "0"
@@ -696,8 +702,9 @@ def main():
                          "frac": prof["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "flops_per_launch": prof["flops_per_launch"], "algorithmic_bytes_per_launch": prof["bytes_per_launch"],
                          "kernel": "gemm_ring_kernel<...> (256x256 LDS-ring MFMA tiles) + gemm_glds_kernel<..., MI> (LDS-DMA tiles of "
-                                   "256 / 192 / 128 rows x 128 columns, height chosen per call so that the one-prompt shapes M = 2180 / "
-                                   "2048 fill the 256 CUs; row-split remainders) — every projection / "
+                                   "256 / 192 / 128 rows x 128 columns) + gemm_w4_kernel<..., WM, WN> (four waves with 80 x 128 ... 64 x 64 per-wave "
+                                   "tiles, late round 4) — one of them per call by a cost model over tiles, rounds of 256 CUs and the "
+                                   "kernels' sustained rates; row-split remainders) — every projection / "
                                    "lm_head GEMM of the prefill, ref, policy forward and backward passes that fills the chip; "
                                    "one launch = one API call (bra_gemm_bf16_nt)",
                          "launches": prof["launches"], "avg_launch_ms": prof["avg_launch_ms"],
@@ -720,6 +727,8 @@ def main():
                         "event pairs); `achieved` above is measured inside the timed steps, where three chains share the chip"}
         if dims.dry:
             line["dryrun"] = True
+        if args.no_w4_gemm:
+            line["ab_note"] = "A/B run without the four-wave GEMM kernel (--no-w4-gemm): not the shipped configuration"
         if args.round3_kernels:
             line["ab_note"] = "A/B run with round 3's kernel choices (--round3-kernels): not the shipped configuration"
 

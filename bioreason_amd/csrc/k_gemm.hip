@@ -670,6 +670,160 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------
+// FOUR waves with LARGE per-wave tiles (late round 4; opt-in: bra_gemm_set_variant(11..14)).  What the tuned library runs on the
+// one-prompt shapes (profiles/r4_l_hipblaslt_kernels.txt): one wave per SIMD with the whole register file, a 16 WM x 16 WN tile per
+// wave (2 x 2 waves: macro tile 32 WM x 32 WN), i.e. (WM + WN) fragment reads per WM x WN MFMAs — 0.33 for 5 x 8 against 0.5 / 0.75 of
+// the eight-wave kernels above — and macro tiles of 160 rows for M = 2180 (14 x 16 = 224 workgroups on 256 CUs).
+// Staging as in gemm_glds_kernel: LDS-DMA pieces of 8 rows x 128 B, XOR swizzle on the source side, the stage image is the
+// (BM + BN) rows of A then B; every wave issues WM + WN pieces per K-tile; counted waits keep NS - 2 whole tiles in flight.
+// K loop = the skewed form: the fragments of the second half K-step are requested before the MFMAs of the first, the barrier sits
+// between the halves.  Same K order per output element as every other variant (bit-identical results).
+// scheduling request for one MFMA cluster of NM instructions with ND LDS-DMA pieces and NR fragment reads issued in its gaps:
+// {1 MFMA, 1 DMA piece + its pointer update} x ND, {1 MFMA, 1 fragment read} x NR, the remaining MFMAs
+template <int ND, int NR, int NM>
+__device__ __forceinline__ void sched_pipe() {
+#ifndef BRA_EMU
+    static_assert(ND + NR <= NM, "one memory instruction per MFMA gap");
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);      // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);     // VMEM read (the LDS-DMA piece)
+        __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);      // VALU (64-bit pointer += BK)
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read
+    }
+    if constexpr (NM - ND - NR > 0) __builtin_amdgcn_sched_group_barrier(0x8, NM - ND - NR, 0);
+#endif
+}
+
+template <int EPI, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_w4_kernel(GemmArgs g) {
+    static_assert(WN % 4 == 0, "the wave epilogue works on 64-column groups");
+    constexpr int BM = 32 * WM, BN = 32 * WN, BK = 64;
+    constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
+    constexpr int NS = (160 * 1024) / STAGE >= 4 ? 4 : 3, LOOK = NS - 1;
+    constexpr int NDMA = WM + WN;          // 1-KiB pieces per wave per K-tile: (BM + BN) / 8 rows-of-8 over 4 waves
+    BRA_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = (int)xcd_remap(blockIdx.x, (unsigned)ntiles);
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int gid = bid / per_group;
+    const int first_m = gid * GROUP;
+    const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int tile_m = first_m + (bid % per_group) % gsize;
+    const int tile_n = (bid % per_group) / gsize;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int nk1 = g.K / BK, nk2 = g.K2 / BK;
+    const int nt = nk1 + nk2;
+
+    // piece j of this wave = rows 8 (wave NDMA + j) .. + 7 of the stage image; running source pointers (+ BK elements per K-tile),
+    // rebuilt once where the stream crosses from (A, B) to the LoRA pair (A2, B2)
+    const int prow = lane >> 3, lchunk = ((lane & 7) ^ (lane >> 3)) * 8;
+    const bf16_t* src[NDMA];
+    auto src_init = [&](bool main) {
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) {
+            const int r = (wave * NDMA + j) * 8 + prow;              // row of the stage image (a piece never straddles A / B: BM % 8 == 0)
+            if (r < BM) { int m = m0 + r; m = m < g.M ? m : g.M - 1; src[j] = (main ? g.A : g.A2) + (long)m * (main ? g.lda : g.lda2) + lchunk; }
+            else { int n = n0 + r - BM; n = n < g.N ? n : g.N - 1; src[j] = (main ? g.B : g.B2) + (long)n * (main ? g.ldb : g.ldb2) + lchunk; }
+        }
+    };
+    src_init(nk1 > 0);
+    auto issue = [&](int kt, int stage) {
+        if (kt == nk1 && kt > 0) src_init(false);                     // (wave-uniform, once)
+        char* dst = smem + stage * STAGE + wave * (NDMA * 1024);
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) { glds16(src[j], dst + j * 1024); src[j] += BK; }
+    };
+    auto wait_tiles = [&](int fly) {
+        if (fly >= 2 && LOOK >= 3) wait_vmcnt<2 * NDMA>();
+        else if (fly >= 1) wait_vmcnt<NDMA>();
+        else wait_vmcnt<0>();
+    };
+
+    f32x4 acc[WN][WM];             // acc[ni][mi]: D[n = 16 ni + 4 (lane >> 4) + r][m = 16 mi + (lane & 15)]
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+#pragma unroll
+        for (int j = 0; j < WM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    auto read_frags = [&](int stg, int kk, u32x4 (&fa)[WM], u32x4 (&fb)[WN]) {
+        const char* sa = smem + stg * STAGE;
+        const char* sb = sa + A_BYTES;
+        const int c = kk * 4 + fq;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int rowa = wm * (16 * WM) + i * 16 + fr;
+            fa[i] = ld16(sa + rowa * 128 + swz_chunk<64>(rowa, c) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < WN; ++i) {
+            const int rowb = wn * (16 * WN) + i * 16 + fr;
+            fb[i] = ld16(sb + rowb * 128 + swz_chunk<64>(rowb, c) * 16);
+        }
+    };
+    auto mma = [&](const u32x4 (&fa)[WM], const u32x4 (&fb)[WN]) {
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) acc[ni][mi] = mfma_16x16x32(fb[ni], fa[mi], acc[ni][mi]);
+    };
+
+#pragma unroll
+    for (int j = 0; j < LOOK; ++j)
+        if (j < nt) issue(j, j);
+    wait_tiles((nt < LOOK ? nt : LOOK) - 1);
+    raw_barrier();
+    u32x4 fa0[WM], fb0[WN], fa1[WM], fb1[WN];
+    read_frags(0, 0, fa0, fb0);
+    int stage = 0;
+    // One K-tile.  With one wave per SIMD nothing else covers the issue slots of the DMA pieces and fragment reads, so they are placed
+    // INSIDE the MFMA clusters (sched_group_barrier: one memory instruction per MFMA gap) instead of between them; the steady-state
+    // body has no branch between its first DMA piece and its last MFMA (the tail iterations, which issue nothing, are a second loop).
+    auto body = [&](int t, auto ISSUE) {
+        constexpr bool issuing = decltype(ISSUE)::value;
+        int s2 = stage + LOOK; s2 = s2 >= NS ? s2 - NS : s2;
+        const int s1 = stage + 1 == NS ? 0 : stage + 1;
+        if (issuing && t + LOOK == nk1 && nk1 > 0) src_init(false);   // (wave-uniform, once: the stream crosses to the LoRA pair)
+        sched_fence();
+        if (issuing) {
+            char* dst = smem + s2 * STAGE + wave * (NDMA * 1024);     // slot of K-tile t - 1: every wave is past the barrier behind its last read
+#pragma unroll
+            for (int j = 0; j < NDMA; ++j) { glds16(src[j], dst + j * 1024); src[j] += BK; }
+        }
+        read_frags(stage, 1, fa1, fb1);
+        mma(fa0, fb0);
+        sched_pipe<issuing ? NDMA : 0, NDMA, WM * WN>();
+        sched_fence();
+        if (issuing) wait_vmcnt<(LOOK - 1) * NDMA>();                 // K-tile t + 1 has landed, LOOK - 1 younger ones stay in flight
+        else { const int left = nt - 2 - t; wait_tiles(left < LOOK - 1 ? left : LOOK - 1); }
+        raw_barrier();
+        sched_fence();
+        if (t + 1 < nt) read_frags(s1, 0, fa0, fb0);                  // (uniform; false only in the very last iteration)
+        mma(fa1, fb1);
+        sched_pipe<0, NDMA, WM * WN>();
+        sched_fence();
+        stage = s1;
+    };
+    int t = 0;
+    for (; t + LOOK < nt; ++t) body(t, std::true_type{});
+    for (; t < nt; ++t) body(t, std::false_type{});
+#pragma unroll
+    for (int hcol = 0; hcol < WN / 4; ++hcol)
+        gemm_epilogue_w<EPI, WM>(g, *reinterpret_cast<f32x4 (*)[4][WM]>(&acc[4 * hcol]), m0 + wm * (16 * WM), n0 + wn * (16 * WN) + 64 * hcol, lane);
+}
+
+// ---------------------------------------------------------------------------
 // 256 x 256 output tile, 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 8 x 4 fragments of v_mfma_f32_16x16x32_bf16
 // (128 accumulator registers), BK = 64.  Against the 256 x 128 kernel above: per-wave tile 128 x 64 instead of
 // 64 x 64 (24 instead of 32 fragment reads per 64 MFMAs, half the L2 -> LDS bytes per flop), and a PHASED K loop in
@@ -969,6 +1123,7 @@ template <typename T> struct knob_t {
 };
 #endif
 static knob_t<int> g_forced_variant(-1);
+static knob_t<int> g_forced_w4(0);             // 1..4: gemm_w4_kernel at 160x256 / 128x256 / 160x128 / 128x128 (bra_gemm_set_variant(11..14))
 static knob_t<int> ring_min_fill_pct(75);
 static knob_t<int> ring_two_phase(1);
 static knob_t<int> ring_row_split(1);
@@ -1053,6 +1208,56 @@ static int launch_glds(const GemmArgs& g, bra_stream_t stream) {
     return launch_glds_mi<EPI, 4>(g, stream, skew);
 }
 
+// Which kernel for this call?  A launch takes rounds x (tile flops / sustained rate of the kernel on one CU + a fixed part: prologue
+// latency + epilogue), rounds = ceil(tiles / 256) — fitted on tools/gemm_variants.py GV_SMALLM=1 (profiles/r4_n_gemm_variants_w4.txt:
+// predicted / measured within 8 %, the argmin is the measured-fastest variant on 19 of the 20 one-prompt shapes).  Rates in TFLOP/s
+// per CU: 256 x 256 ring 5.9; four-wave tiles 4.5; LDS-DMA tiles 4.27 / 4.56 / 3.75 at 256 / 192 / 128 rows.  Returns the four-wave
+// configuration (1..4) when one of them is the argmin, else 0 = the ring / LDS-DMA choice of pick_variant() stands.
+static knob_t<int> g_w4_auto(1);
+static int pick_w4(const GemmArgs& g) {
+    { const int f = g_forced_w4; if (f) return f; }
+    if (!g_w4_auto || g_forced_variant >= 0 || g_forced_glds_rows) return 0;
+    if (g.K % 64 || g.K2 % 64 || g.split_k > 1 || g.M < 128 || g.N < 128 || g.K + g.K2 < 256) return 0;
+    // only where 256 x 256 tiles cannot fill more than one round of the chip (the one-prompt shapes the model was fitted on): with
+    // several rounds the ring kernel's row split covers a partial last round better than ceil() says — SFT's M = 17 440 shapes measured
+    // 6 % slower when the model was allowed to move them (254.1 vs 238.7 ms per step)
+    if ((long)((g.M + 255) / 256) * ((g.N + 255) / 256) > 256) return 0;
+    struct Cand { int bm, bn; double rate; int w4; };
+    static const Cand cands[8] = {{256, 256, 5.9, 0}, {256, 128, 4.27, 0}, {192, 128, 4.56, 0}, {128, 128, 3.75, 0},
+                                  {160, 256, 4.5, 1}, {128, 256, 4.5, 2}, {160, 128, 4.5, 3}, {128, 128, 4.5, 4}};
+    const double kk = 2.0e-6 * (double)(g.K + g.K2);
+    int best = 0;
+    double best_t = 1e30;
+    for (const Cand& c : cands) {
+        const long tiles = (long)((g.M + c.bm - 1) / c.bm) * ((g.N + c.bn - 1) / c.bn);
+        const double t = (double)((tiles + 255) / 256) * (kk * c.bm * c.bn / c.rate + 3.5);
+        if (t < best_t) { best_t = t; best = c.w4; }
+    }
+    return best;
+}
+
+template <int EPI, int WM, int WN>
+static int launch_w4_t(const GemmArgs& g, bra_stream_t stream) {
+    constexpr int BM = 32 * WM, BN = 32 * WN, STAGE = (BM + BN) * 128, NS = (160 * 1024) / STAGE >= 4 ? 4 : 3;
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    const size_t smem = (size_t)NS * STAGE;
+    BRA_ALLOW_SMEM((gemm_w4_kernel<EPI, WM, WN>), smem);
+    BRA_LAUNCH((gemm_w4_kernel<EPI, WM, WN>), dim3(tiles), dim3(256), smem, stream, g);
+    return BRA_LAUNCH_STATUS();
+}
+template <int EPI>
+static int launch_w4(const GemmArgs& g, bra_stream_t stream, int cfg) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_F32) {
+        switch (cfg) {
+            case 1: return launch_w4_t<EPI, 5, 8>(g, stream);
+            case 2: return launch_w4_t<EPI, 4, 8>(g, stream);
+            case 3: return launch_w4_t<EPI, 5, 4>(g, stream);
+            default: return launch_w4_t<EPI, 4, 4>(g, stream);
+        }
+    }
+    return BRA_ERR_UNSUPPORTED;
+}
+
 template <int EPI>
 static int launch_ring(const GemmArgs& g, bra_stream_t stream) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
@@ -1069,6 +1274,7 @@ static int launch_ring(const GemmArgs& g, bra_stream_t stream) {
 
 template <int BK, int EPI>
 static int launch_gemm(const GemmArgs& g, bra_stream_t stream) {
+    if (BK == 64 && (EPI == EPI_BF16 || EPI == EPI_F32)) { const int w4 = pick_w4(g); if (w4) return launch_w4<EPI>(g, stream, w4); }
     if (BK == 64 && EPI != EPI_ATOMIC && pick_variant(g) == 6) return launch_ring<EPI>(g, stream);
     if (BK == 64 && pick_variant(g) >= 4) return launch_glds<EPI>(g, stream);
     switch (pick_variant(g)) {
@@ -1087,7 +1293,7 @@ static int launch_gemm(const GemmArgs& g, bra_stream_t stream) {
 // Returns the rows of the ring part, or 0 (no split).  Rows are independent in every epilogue this is applied to.
 static int ring_split_rows(const GemmArgs& g) {
     if (g_forced_variant >= 0 || !ring_row_split || g.K % 64 || g.K2 % 64 || g.split_k > 1) return 0;
-    if (pick_variant(g) != 6) return 0;
+    if (pick_variant(g) != 6 || pick_w4(g)) return 0;
     const long tm = (g.M + 255) / 256, tn = (g.N + 255) / 256, t = tm * tn;
     const long R = t / 256, rem = t - R * 256;
     if (R < 1 || rem == 0 || 2 * rem >= 256) return 0;
@@ -1139,6 +1345,10 @@ using namespace bra;
 
 extern "C" int bra_gemm_set_variant(int v) {
     bra::g_forced_glds_rows = 0;
+    bra::g_forced_w4 = 0;
+    bra::g_w4_auto = v == -2 ? 0 : 1;                                                      // -2: automatic choice WITHOUT the four-wave kernel (A/B)
+    if (v == -2) v = -1;
+    if (v >= 11 && v <= 14) { bra::g_forced_w4 = v - 10; v = 5; }                         // four waves, large per-wave tiles (opt-in)
     if (v == 9 || v == 10) { bra::g_forced_glds_rows = v == 9 ? 192 : 128; v = 5; }      // the LDS-DMA kernel at 192 / 128-row tiles
     bra::g_forced_variant = v;
     if (v == 6) bra::ring_two_phase = 0;                 // 6 = four-phase ring, 7 = two-phase ring (A/B measurements)

@@ -90,7 +90,7 @@ class GemmProfile:
 
     def wants(self, M: int, N: int, K: int, K2: int) -> bool:
         """dominant_only: exactly the launches k_gemm.hip's pick_variant() sends to the LDS-DMA MFMA kernels (gemm_ring_kernel
-        256x256 / gemm_glds_kernel 256 | 192 | 128 x 128, MFMA-bound); otherwise every launch with M >= min_m (that also counts the N = 32
+        256x256 / gemm_glds_kernel 256 | 192 | 128 x 128 / — late round 4, the same calls — gemm_w4_kernel, MFMA-bound); otherwise every launch with M >= min_m (that also counts the N = 32
         LoRA projections, which are HBM-bound reads of the activations)"""
         if not self.dominant_only:
             return M >= self.min_m

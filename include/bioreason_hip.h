@@ -46,8 +46,10 @@ int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, const voi
 
 /* tuning knob for A/B measurements: pins the tile variant of bra_gemm_* (0-3: register-staged 128/256-row tiles x prefetch
  * depth, 4/5: 256 x 128 LDS-DMA kernel without / with skewed fragment reads, 6 / 7: 256 x 256 ring kernel with four / two phases
- * per K-tile); v < 0 restores
- * the built-in per-shape choice.  Process-wide: meant for benchmarks and tests, not for concurrent callers. */
+ * per K-tile, 9 / 10: the LDS-DMA kernel at 192 / 128-row tiles, 11 - 14: the four-wave kernel with 80 x 128 / 64 x 128 / 80 x 64 /
+ * 64 x 64 per-wave tiles = macro tiles 160 x 256 / 128 x 256 / 160 x 128 / 128 x 128); v = -1 restores the built-in per-shape
+ * choice (a cost model over all of them), v = -2 the same choice WITHOUT the four-wave kernel (rounds 1 - 4a, for A/B runs).
+ * Process-wide: meant for benchmarks and tests, not for concurrent callers. */
 int bra_gemm_set_variant(int v);
 /* minimum fill (percent of 256 CUs busy, averaged over the rounds of 256 x 256 tiles) at which the per-shape choice takes the
  * ring kernel (default 75) */

@@ -856,7 +856,7 @@ def test_lmhead_lse_at_full_vocab(hip_device):
     assert rel(logp, ref_lp) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [0, 5, 7, 9, 10])
+@pytest.mark.parametrize("variant", [0, 5, 7, 9, 10, 11, 12, 13, 14])
 def test_gemm_bf16_epilogue_interior_and_edge_waves(backend, variant):
     """k_gemm.hip epi_bf16_interior: a wave whose fragments all lie inside the matrix takes the batched epilogue (one base
     pointer per operand, every residual word requested up front), the others the generic one: every bias / residual combination
@@ -885,9 +885,10 @@ def test_gemm_bf16_epilogue_interior_and_edge_waves(backend, variant):
         get_lib().call("bra_gemm_set_variant", -1)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 9, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14])
 def test_gemm_tile_variants(backend, variant):
     """every tile variant (128/256-row tiles x register prefetch depth 1/2; 5 / 9 / 10: the LDS-DMA kernel at 256 / 192 / 128-row tiles;
+    11 - 14: four waves with 80 x 128 / 64 x 128 / 80 x 64 / 64 x 64 per-wave tiles (opt-in);
     6 / 7: the 256 x 256 ring) against the fp32 statement"""
     from bioreason_amd._lib import get_lib
     get_lib().call("bra_gemm_set_variant", variant)

@@ -14,7 +14,7 @@ P1 = 2180
 if os.environ.get("GV_SMALLM") == "1":
     # the GEMMs of the shared-prompt GRPO step (round 3+): prompt chain M = 2180, completion chain M = 8 x 256 = 2048; forward
     # projections and the input-gradient GEMMs (K = the forward's N); encoder rows M = 2052.  Variants: 0 = 128x128 register-staged,
-    # 5 / 9 / 10 = LDS-DMA kernel at 256 / 192 / 128-row tiles, 7 = 256x256 ring
+    # 5 / 9 / 10 = LDS-DMA kernel at 256 / 192 / 128-row tiles, 7 = 256x256 ring, 11 - 14 = four waves, macro tile 160x256 / 128x256 / 160x128 / 128x128
     shapes = []
     for tag, M in (("p", 2180), ("c", 2048)):
         shapes += [(tag + "_qkv", M, 4096, 2048, 128), (tag + "_o", M, 2048, 2048, 64), (tag + "_gate_up", M, 12288, 2048, 64),
@@ -41,11 +41,11 @@ for name, M, N, K, K2 in shapes:
     res = {}
     if os.environ.get("GV_CHECK") == "1":            # variant 6 against variant 5 on the same operands (both fp32-accumulated)
         get_lib().call("bra_gemm_set_variant", 5); c5 = ops.gemm_nt(a, b, a2=a2, b2=b2).float()
-        for vv in ((9, 10, 0) if os.environ.get("GV_SMALLM") == "1" else (7,)):
+        for vv in ((9, 10, 0, 11, 12, 13, 14) if os.environ.get("GV_SMALLM") == "1" else (7,)):
             get_lib().call("bra_gemm_set_variant", vv); c6 = ops.gemm_nt(a, b, a2=a2, b2=b2).float()
             print(name, "variant", vv, "max |v - v5| / max|v5| =", float((c6 - c5).abs().max() / c5.abs().max()), "mismatching elements", int((c6 != c5).sum()), flush=True)
         del c5, c6
-    for v in ((0, 5, 9, 10, 7) if os.environ.get('GV_SMALLM') == '1' else ((5, 6, 7) if os.environ.get('GV_FAST') == '1' else (0, 4, 5, 6, 7))):
+    for v in ((5, 9, 10, 7, 11, 12, 13, 14, -2, -1) if os.environ.get('GV_SMALLM') == '1' else ((5, 6, 7) if os.environ.get('GV_FAST') == '1' else (0, 4, 5, 6, 7))):
         get_lib().call("bra_gemm_set_variant", v)
         ms = timeit(lambda: ops.gemm_nt(a, b, a2=a2, b2=b2, out=c, res=rs))
         res[v] = round(2.0 * M * N * (K + K2) / ms / 1e9)

@@ -16,7 +16,7 @@ for f in ("k_gemm.hip", "bra_device.h"):
 res = {"kernel_source_sha": h.hexdigest()[:16], "command": "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary (the timed configuration; GRPO steps traced: see steps_in_trace)",
        "fetch_correction": 2.0, "steps_in_trace": NSTEPS, "kernels": {}}
 tot_b, tot_n = 0.0, 0
-for key in ("gemm_ring_kernel<0", "gemm_glds_kernel<0"):
+for key in ("gemm_ring_kernel<0", "gemm_glds_kernel<0", "gemm_w4_kernel<0"):
     # (round 4: the LDS-DMA kernel has one instantiation per tile height — every kernel name that matches the key is summed)
     f = {r["Kernel_Name"]: r for r in pick(rows("FETCH_SIZE"), "FETCH_SIZE", key)}
     w = {r["Kernel_Name"]: r for r in pick(rows("WRITE_SIZE"), "WRITE_SIZE", key)}
@@ -58,7 +58,7 @@ if dec_b > 0:
     res["decode_traffic_by_kernel_in_trace"] = dec_k
     res["decode_traffic_bytes_per_token_step"] = dec_b / (NSTEPS * 255.0)
 sq = rows("SQ_BUSY_CYCLES")
-for key in ("gemm_ring_kernel<0", "gemm_glds_kernel<0", "attn_fwd_kernel<128", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel<128", "dec_gemm2_kernel<0, 2, 1", "dec_attn_items_kernel", "dec_attn_merge_kernel"):
+for key in ("gemm_ring_kernel<0", "gemm_glds_kernel<0", "gemm_w4_kernel<0", "attn_fwd_kernel<128", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel<128", "dec_gemm2_kernel<0, 2, 1", "dec_attn_items_kernel", "dec_attn_merge_kernel"):
     busy, mfma = pick(sq, "SQ_BUSY_CYCLES", key), pick(sq, "SQ_VALU_MFMA_BUSY_CYCLES", key)
     if busy and mfma:
         # SQ_BUSY_CYCLES is reported per shader engine (32 SEs), SQ_VALU_MFMA_BUSY_CYCLES summed over the 1024 SIMDs; every
