@@ -500,7 +500,11 @@ class Qwen3ForCausalLM(nn.Module):
             tgt = shift[valid].to(torch.int32)
         hid = self.hidden_states(inputs_embeds, attention_mask, position_ids)
         loss = None
-        if labels is not None:
+        if labels is not None and rows.numel() == 0:
+            # every label is -100 (e.g. the assistant span fell to truncation): HF's mean over zero positions is NaN
+            # (TF:loss/loss_utils.py:32-46) and so is this loss; its backward sends zeros (an all-ignored batch teaches nothing)
+            loss = _NanLossFn.apply(hid)
+        elif labels is not None:
             hsel = _GatherRowsFn.apply(hid, rows)
             logp = _LogProbFn.apply(hsel, self, tgt)
             loss = _neg_mean(logp)
@@ -526,6 +530,20 @@ class _GatherRowsFn(torch.autograd.Function):
     def backward(ctx, dy):
         (rows,) = ctx.saved_tensors
         return ops.scatter_rows(rows, dy.contiguous(), ctx.n), None
+
+
+class _NanLossFn(torch.autograd.Function):
+    """the loss of a batch without a single supervised position: NaN forward, zero gradient"""
+
+    @staticmethod
+    def forward(ctx, hid):
+        ctx.meta = (hid.shape, hid.dtype, hid.device)
+        return torch.full((), float("nan"), dtype=torch.float32, device=hid.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dt, dev = ctx.meta
+        return torch.zeros(shape, dtype=dt, device=dev)
 
 
 class _NegMeanFn(torch.autograd.Function):

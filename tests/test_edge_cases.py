@@ -197,3 +197,32 @@ def test_dna_embedding_cache_is_exact(backend):
     m(**b)
     g2 = m(input_ids=ids, attention_mask=b["attention_mask"], dna_tokenized=sub, batch_idx_map=[0] * len(keep)).logits
     assert torch.equal(g2.cpu(), w2.cpu())
+
+
+def test_batch_without_a_supervised_position(backend):
+    """every label -100 (the assistant span fell to truncation, kegg.py:252-327 + max_length_text): HF's CE mean over zero
+    positions is NaN (TF:loss/loss_utils.py:32-46) — so is this loss, and its backward runs (zero gradients) instead of raising"""
+    fix = _fix("tiny_b")
+    ora = rebuild(fix, True)
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    lab = torch.full_like(fix["batch"]["labels"], -100)
+    with torch.no_grad():
+        want = ora(input_ids=fix["batch"]["input_ids"], attention_mask=fix["batch"]["attention_mask"], labels=lab,
+                   dna_tokenized=fix["batch"]["dna_tokenized"], batch_idx_map=fix["batch"]["batch_idx_map"])
+    assert torch.isnan(want.loss)
+    m.train()
+    m.arena.zero_grad()
+    out = m(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=lab.to(backend), dna_tokenized=b["dna_tokenized"],
+            batch_idx_map=b["batch_idx_map"])
+    assert torch.isnan(out.loss) and out.logits.shape == want.logits.shape
+    out.loss.backward()
+    assert float(m.arena.grads.abs().max()) == 0.0
+    # one supervised position is an ordinary batch again
+    lab[0, -1] = fix["batch"]["input_ids"][0, -1]
+    with torch.no_grad():
+        want = ora(input_ids=fix["batch"]["input_ids"], attention_mask=fix["batch"]["attention_mask"], labels=lab,
+                   dna_tokenized=fix["batch"]["dna_tokenized"], batch_idx_map=fix["batch"]["batch_idx_map"])
+    out = m(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=lab.to(backend), dna_tokenized=b["dna_tokenized"],
+            batch_idx_map=b["batch_idx_map"])
+    assert abs(out.loss.item() - want.loss.item()) < 3e-2 * max(1.0, abs(want.loss.item()))
