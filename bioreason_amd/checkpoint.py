@@ -65,40 +65,87 @@ def _tokenizer(path: str):
         return None                                   # weights-only directory: the caller tokenises elsewhere
 
 
-def load_pretrained_pair(text_model_name, dna_model_name, cache_dir, device):
-    """-> (text_model, dna_model, (text_tokenizer, dna_tokenizer, processor)) from two local directories"""
+def _require_dir(n):
+    if not (isinstance(n, str) and os.path.isdir(n)):
+        raise RuntimeError(
+            f"bioreason_amd: '{n}' is not a local checkpoint directory and the HF Hub is unreachable here. "
+            "Pass config objects (bioreason_amd.configs) for random-init models, or a local directory with "
+            "config.json + *.safetensors.")
+
+
+def load_pretrained_text(text_model_name, cache_dir, device):
+    """-> (Qwen3ForCausalLM with the directory's weights, its tokenizer prepared as dna_llm.py:67-73 does, or None)"""
     from . import configs
-    from .modeling import NTEncoderForMaskedLM, Qwen3ForCausalLM
-    for n in (text_model_name, dna_model_name):
-        if not (isinstance(n, str) and os.path.isdir(n)):
-            raise RuntimeError(
-                f"bioreason_amd: '{n}' is not a local checkpoint directory and the HF Hub is unreachable here. "
-                "Pass config objects (bioreason_amd.configs) for random-init models, or a local directory with "
-                "config.json + *.safetensors.")
-    tc, dc = _load_config(text_model_name), _load_config(dna_model_name)
+    from .modeling import Qwen3ForCausalLM
+    _require_dir(text_model_name)
+    tc = _load_config(text_model_name)
     tkeys = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads",
              "head_dim", "rope_theta", "max_position_embeddings", "rms_norm_eps")
-    dkeys = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "max_position_embeddings")
     text = Qwen3ForCausalLM(configs.qwen3_config(**{k: tc[k] for k in tkeys if k in tc}), device=device)
-    dna = NTEncoderForMaskedLM(configs.nt_v2_config(**{k: dc[k] for k in dkeys if k in dc}), device=device)
     sd = read_weight_dir(text_model_name)
     missing, unexpected = text.load_state_dict(sd, strict=False)
     missing = [k for k in missing if k != "lm_head.weight"]           # tied: absent from HF Qwen3 checkpoints
     if missing:
         raise RuntimeError(f"bioreason_amd: '{text_model_name}' lacks {len(missing)} tensors, e.g. {missing[:3]}")
     text.tie_weights()
-    sd = read_weight_dir(dna_model_name)
-    # the hub NT-v2 names equal the installed ESM's except for the gated FFN, which this package names as the oracle does
-    missing, unexpected = dna.load_state_dict(sd, strict=False)
-    if missing:
-        raise RuntimeError(f"bioreason_amd: '{dna_model_name}' lacks {len(missing)} tensors, e.g. {missing[:3]} "
-                           "(NT-v2 key names could not be verified offline: SURVEY §8c)")
-    tt, dt = _tokenizer(text_model_name), _tokenizer(dna_model_name)
+    tt = _tokenizer(text_model_name)
     if tt is not None:                                                # dna_llm.py:68-73
         from .chat_template import CHAT_TEMPLATE
         tt.pad_token = tt.eos_token
         tt.chat_template = CHAT_TEMPLATE                              # dna_llm.py:69: {"type": "dna"} items -> placeholders
         tt.add_special_tokens({"additional_special_tokens": NEW_TOKENS})
+    return text, tt
+
+
+def check_nt_v2_key_shapes(sd: Dict[str, torch.Tensor], hidden: int, intermediate: int, n_layers: int, where: str = "") -> None:
+    """The NT-v2 feed-forward of this package is RECALLED from the public hub file (gated SwiGLU without bias: one
+    `intermediate.dense.weight` of shape [2F, H] whose halves are gate | up, `output.dense.weight` [H, F]; SURVEY §8c asks for
+    exactly this check once weights exist).  A checkpoint whose tensors say otherwise must fail HERE, loudly, not run as a
+    different network: plain ESM has [F, H] + biases, which `load_state_dict(strict=False)` would otherwise half-accept."""
+    F, H = int(intermediate), int(hidden)
+    problems = []
+    for layer in range(n_layers):
+        base = f"esm.encoder.layer.{layer}."
+        for key, want in ((base + "intermediate.dense.weight", (2 * F, H)), (base + "output.dense.weight", (H, F))):
+            t = sd.get(key)
+            if t is None:
+                problems.append(f"{key}: missing")
+            elif tuple(t.shape) != want:
+                problems.append(f"{key}: {tuple(t.shape)} instead of {want}")
+        for key in (base + "intermediate.dense.bias", base + "output.dense.bias"):
+            if key in sd:
+                problems.append(f"{key}: present, but the gated FFN of NT-v2 has no bias (config add_bias_fnn=false)")
+    if problems:
+        raise RuntimeError(f"bioreason_amd: '{where}' is not an NT-v2 checkpoint as this package models it "
+                           f"({len(problems)} feed-forward tensors disagree, e.g. {problems[:3]}); the encoder's gated FFN was "
+                           "restated from the public hub code without a checkpoint to verify against (SURVEY §8c)")
+
+
+def load_pretrained_dna(dna_model_name, cache_dir, device):
+    """-> (NTEncoderForMaskedLM with the directory's weights, its tokenizer or None)"""
+    from . import configs
+    from .modeling import NTEncoderForMaskedLM
+    _require_dir(dna_model_name)
+    dc = _load_config(dna_model_name)
+    dkeys = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "max_position_embeddings")
+    cfg = configs.nt_v2_config(**{k: dc[k] for k in dkeys if k in dc})
+    dna = NTEncoderForMaskedLM(cfg, device=device)
+    sd = read_weight_dir(dna_model_name)
+    check_nt_v2_key_shapes(sd, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, dna_model_name)
+    # the hub NT-v2 names equal the installed ESM's except for the gated FFN, which this package names as the oracle does
+    missing, unexpected = dna.load_state_dict(sd, strict=False)
+    if missing:
+        raise RuntimeError(f"bioreason_amd: '{dna_model_name}' lacks {len(missing)} tensors, e.g. {missing[:3]} "
+                           "(NT-v2 key names could not be verified offline: SURVEY §8c)")
+    return dna, _tokenizer(dna_model_name)
+
+
+def load_pretrained_pair(text_model_name, dna_model_name, cache_dir, device):
+    """-> (text_model, dna_model, (text_tokenizer, dna_tokenizer, processor)) from two local directories"""
+    for n in (text_model_name, dna_model_name):
+        _require_dir(n)
+    text, tt = load_pretrained_text(text_model_name, cache_dir, device)
+    dna, dt = load_pretrained_dna(dna_model_name, cache_dir, device)
     processor = None
     if tt is not None and dt is not None:                             # dna_llm.py:100: DLProcessor(tokenizer, dna_tokenizer)
         from .processing import DLProcessor

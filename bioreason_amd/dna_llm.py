@@ -126,13 +126,42 @@ class DNALLMModel(nn.Module):
         dna_token_id: Optional[int] = None,
     ):
         super().__init__()
-        if dna_is_evo2:
-            raise NotImplementedError("Evo2 encoder: SURVEY §8f N3 (no oracle offline); NT-v2 path only")
         self.text_model_finetune, self.dna_model_finetune = text_model_finetune, dna_model_finetune
         self.max_length_dna, self.max_length_text = max_length_dna, max_length_text
         self.dna_is_evo2, self.dna_embedding_layer = dna_is_evo2, dna_embedding_layer
         dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        if isinstance(text_model_name, str) or isinstance(dna_model_name, str):
+        if dna_is_evo2:
+            # dna_llm.py:85-90.  The StripedHyena-2 network itself is NOT built here (`evo2` / `vortex` are absent and
+            # unpinned — no oracle, so no kernels); what IS here is everything around it: the tokenizer, the batched call through
+            # Evo2's own interface `model(input_ids, return_embeddings=True, layer_names=[layer]) -> (_, {layer: [n, S, H]})`, and the
+            # valid-row quirk of left-padded batches.  `dna_model_name` is either a checkpoint name (needs the `evo2` package) or any
+            # object with that call interface + `.tokenizer` + `.model.config.hidden_size` (tests inject one).
+            from .evo2_tokenizer import Evo2Tokenizer
+            if isinstance(dna_model_name, str):
+                try:
+                    from evo2 import Evo2
+                except ImportError as e:
+                    raise ImportError("dna_is_evo2=True with a checkpoint name needs the `evo2` package (not installed: SURVEY §8c); "
+                                      "pass an encoder object with Evo2's call interface instead") from e
+                encoder = Evo2(dna_model_name)
+            else:
+                encoder = dna_model_name
+            if isinstance(text_model_name, str):
+                from .checkpoint import load_pretrained_text
+                self.text_model, self.text_tokenizer = load_pretrained_text(text_model_name, cache_dir, dev)
+            else:
+                self.text_model, self.text_tokenizer = Qwen3ForCausalLM(text_model_name, device=dev), None
+            self.dna_model = encoder
+            self.dna_tokenizer = Evo2Tokenizer(getattr(encoder, "tokenizer", None))
+            self.evo2_batched = bool(getattr(encoder, "supports_batch", True))
+            self.processor = None
+            if self.text_tokenizer is not None:
+                from .processing import DLProcessor
+                self.processor = DLProcessor(tokenizer=self.text_tokenizer, dna_tokenizer=self.dna_tokenizer)
+                self.dna_token_id = self.text_tokenizer.convert_tokens_to_ids("<|dna_pad|>")
+            else:
+                self.dna_token_id = dna_token_id if dna_token_id is not None else 151670
+        elif isinstance(text_model_name, str) or isinstance(dna_model_name, str):
             from .checkpoint import load_pretrained_pair
             self.text_model, self.dna_model, toks = load_pretrained_pair(text_model_name, dna_model_name, cache_dir, dev)
             self.text_tokenizer, self.dna_tokenizer, self.processor = toks
@@ -145,7 +174,8 @@ class DNALLMModel(nn.Module):
             self.dna_model = NTEncoderForMaskedLM(dna_model_name, device=dev)
             self.text_tokenizer = self.dna_tokenizer = self.processor = None
             self.dna_token_id = dna_token_id if dna_token_id is not None else 151670   # Qwen3 id of the 2nd added token
-        self.text_config, self.dna_config = self.text_model.config, self.dna_model.config
+        self.text_config = self.text_model.config
+        self.dna_config = self.dna_model.model.config if dna_is_evo2 else self.dna_model.config          # dna_llm.py:83,88
         self.config = self.text_config
         self.text_hidden_size, self.dna_hidden_size = self.text_config.hidden_size, self.dna_config.hidden_size
         self.arena = TrainableArena(dev)
@@ -153,8 +183,9 @@ class DNALLMModel(nn.Module):
         self.arena.commit()
         self.dna_projection.reset_parameters()
         self.text_model.arena = self.arena
-        for p in self.dna_model.parameters():   # frozen at run time whatever dna_model_finetune says (dna_llm.py:121)
-            p.requires_grad_(False)
+        if hasattr(self.dna_model, "parameters"):
+            for p in self.dna_model.parameters():   # frozen at run time whatever dna_model_finetune says (dna_llm.py:121)
+                p.requires_grad_(False)
         self.warnings_issued: Dict[str, bool] = {}
         self.check_counts = True
 
@@ -187,6 +218,30 @@ class DNALLMModel(nn.Module):
         self._dna_cache = None
 
     @torch.no_grad()
+    def _run_encoder(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """frozen encoder over token rows [m, Sd] -> hidden rows [m, Sd, H_dna] (bf16).  NT-v2: `hidden_states[-1]` of the HIP
+        encoder (dna_llm.py:150-156).  Evo2 (dna_llm.py:123-146): the named layer's embeddings through Evo2's own call interface —
+        ONE call over the whole batch instead of the reference's call per sequence (the rows of a batch are independent in the
+        encoder, and the reference's per-sequence slices carry their left padding with them, so the rows are the same ones);
+        `evo2_batched=False` (or an encoder with `supports_batch = False`) restores the call per sequence."""
+        if not self.dna_is_evo2:
+            return self.dna_model(input_ids=ids, attention_mask=mask).hidden_states[-1]
+        layer = self.dna_embedding_layer
+        if layer is None:
+            raise ValueError("dna_is_evo2=True needs dna_embedding_layer (dna_llm.py:123: the HF call of the other branch does not "
+                             "exist on an Evo2 model)")
+        if self.evo2_batched:
+            _, emb = self.dna_model(ids, return_embeddings=True, layer_names=[layer])
+            h = emb[layer]
+        else:
+            rows = []
+            for i in range(ids.shape[0]):
+                _, emb = self.dna_model(ids[i:i + 1], return_embeddings=True, layer_names=[layer])
+                rows.append(emb[layer].squeeze(0))
+            h = torch.stack(rows)
+        return h.to(device=self.dna_projection.weight.device, dtype=BF16).contiguous()
+
+    @torch.no_grad()
     def encode_dna(self, dna_tokenized: Dict[str, torch.Tensor], dna_alias: Optional[List[int]] = None) -> torch.Tensor:
         """frozen encoder forward -> hidden_states[-1] as rows [n_seq * Sd, H_dna]; with `dna_alias` only the
         representative sequences are encoded and the rows are expanded."""
@@ -206,7 +261,7 @@ class DNALLMModel(nn.Module):
             self.dna_cache_hits += n - len(todo)
             if todo:
                 sel = torch.tensor(todo, device=ids.device)
-                enc = self.dna_model(input_ids=ids[sel], attention_mask=mask[sel]).hidden_states[-1]      # [m, Sd, H]
+                enc = self._run_encoder(ids[sel], mask[sel])                                             # [m, Sd, H]
                 for i, r in enumerate(todo):
                     cache[keys[r]] = enc[i].clone()
             out = []
@@ -217,11 +272,11 @@ class DNALLMModel(nn.Module):
                 cache.popitem(last=False)
             return torch.stack(out, 0).reshape(n * Sd, -1)
         if dna_alias is None:
-            return self.dna_model(input_ids=ids, attention_mask=mask).hidden_states[-1].reshape(n * Sd, -1)
+            return self._run_encoder(ids, mask).reshape(n * Sd, -1)
         reps = sorted(set(dna_alias))
         where = {r: i for i, r in enumerate(reps)}
         sel = torch.tensor(reps, device=ids.device)
-        enc = self.dna_model(input_ids=ids[sel], attention_mask=mask[sel]).hidden_states[-1].reshape(len(reps) * Sd, -1)
+        enc = self._run_encoder(ids[sel], mask[sel]).reshape(len(reps) * Sd, -1)
         rows = torch.tensor([where[a] for a in dna_alias], dtype=torch.int32, device=ids.device)
         rows = (rows[:, None] * Sd + torch.arange(Sd, dtype=torch.int32, device=ids.device)[None, :]).reshape(-1)
         return ops.gather_rows(rows.contiguous(), enc)
@@ -229,6 +284,8 @@ class DNALLMModel(nn.Module):
     def process_dna_embeddings(self, dna_tokenized: Dict[str, torch.Tensor], batch_idx_map: List[int], batch_size: int) -> List[torch.Tensor]:
         """Reference-shaped output (dna_llm.py:103-179): per batch item, the projected rows of its sequences
         (first `attention_mask.sum()` rows of each) concatenated."""
+        if len(dna_tokenized["input_ids"]) == 0:                                    # dna_llm.py:145-146
+            return [torch.zeros((0, self.text_hidden_size)) for _ in range(batch_size)]
         enc = self.encode_dna(dna_tokenized)
         n, Sd = dna_tokenized["input_ids"].shape
         proj = self.dna_projection(enc).view(n, Sd, -1)

@@ -163,3 +163,31 @@ def test_load_pretrained_pair_from_local_directories(emu, tmp_path):
     assert torch.equal(_logits(m, fix["batch"], emu), _logits(src, fix["batch"], emu))
     with pytest.raises(RuntimeError, match="not a local checkpoint directory"):
         C.load_pretrained_pair("Qwen/Qwen3-1.7B", str(tmp_path / "dna"), None, emu)
+
+
+def test_nt_v2_checkpoint_with_a_plain_esm_ffn_fails_loudly(emu, tmp_path):
+    """VERDICT r4 #5 / SURVEY §8c: the encoder's gated FFN is recalled from the hub file — a checkpoint whose
+    `intermediate.dense.weight` is not [2F, H] (plain ESM: [F, H] + biases) must be refused, not half-loaded"""
+    from safetensors.torch import save_file
+    fix = _fix("tiny_b")
+    src = build(fix, emu, False)
+    cfg = src.dna_model.config
+    H, F, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    good = {k: v.cpu().clone().contiguous() for k, v in src.dna_model.state_dict().items()}
+    C.check_nt_v2_key_shapes(good, H, F, L, "good")                               # the package's own layout passes
+    assert tuple(good["esm.encoder.layer.0.intermediate.dense.weight"].shape) == (2 * F, H)
+    bad = dict(good)
+    bad["esm.encoder.layer.0.intermediate.dense.weight"] = torch.zeros(F, H)      # ungated ESM
+    bad["esm.encoder.layer.0.intermediate.dense.bias"] = torch.zeros(F)
+    with pytest.raises(RuntimeError, match="not an NT-v2 checkpoint"):
+        C.check_nt_v2_key_shapes(bad, H, F, L, "bad")
+    os.makedirs(tmp_path / "dna")
+    save_file(bad, str(tmp_path / "dna" / "model.safetensors"))
+    with open(tmp_path / "dna" / "config.json", "w") as fh:
+        json.dump({k: v for k, v in vars(cfg).items() if isinstance(v, (int, float, str, bool, type(None)))}, fh)
+    with pytest.raises(RuntimeError, match="feed-forward tensors disagree"):
+        C.load_pretrained_dna(str(tmp_path / "dna"), None, emu)
+    missing = {k: v for k, v in good.items() if "layer.1.output.dense.weight" not in k}
+    if L > 1:
+        with pytest.raises(RuntimeError, match="missing"):
+            C.check_nt_v2_key_shapes(missing, H, F, L, "missing")
