@@ -307,6 +307,148 @@ def cpu_baseline(mode: str = "grpo"):
     return res
 
 
+def gpu_baseline_hf():
+    """SURVEY §8(d) last row / VERDICT r4 #4: the SAME oracle (the reference's glue around the installed transformers Qwen3 / ESM
+    modules + the restated PEFT LoRA layer) on THIS MI355X through stock PyTorch-ROCm eager kernels (bf16, sdpa) — what the reference
+    itself executes on a GPU box, and the only same-node denominator for "matching or beating".  Informational: its own sub-object,
+    its own process, after the timed region of the HIP path.
+
+    GRPO (cfg-3): the reference's full step for 1 prompt x G = 8 — `generate` over [8, P] rows (HF `_sample`, T 0.6 / top-k 20 /
+    top-p 0.95, 256 new tokens, EOS suppressed as in the headline), reference log-probs with the adapters off over [8, P + C]
+    (`_get_per_token_logps`: full-row lm_head logits + per-row log-softmax), policy forward / backward in train mode (LoRA dropout
+    0.05, a mask per row as PEFT draws them) + `compute_loss`, AdamW over the adapters and the projection (torch.optim.AdamW, foreach).
+    The DNA encoder runs inside each of the three passes, as the reference runs it.  1 warm-up step + `BENCH_HF_STEPS` (2) timed.
+    SFT (cfg-2): forward (full-row logits + CE) / backward / AdamW over B = 8 distinct samples, 1 + 3 steps."""
+    import torch
+    from oracle import dna_llm_oracle as O
+    from oracle import grpo_math as GM
+    from bioreason_amd.synth import synth_prompt_batch
+    dev = torch.device(os.environ.get("BENCH_HF_DEVICE", "cuda:0"))       # ("cpu" + BENCH_CPU_TINY=1: the code-path test of tests/)
+    on_gpu = dev.type == "cuda"
+    if on_gpu:
+        torch.cuda.set_device(dev)
+
+    def sync():
+        if on_gpu:
+            sync()
+
+    tc = dict(vocab_size=151936, hidden_size=2048, intermediate_size=6144, num_hidden_layers=28, num_attention_heads=16,
+              num_key_value_heads=8, head_dim=128, rope_theta=1e6, max_position_embeddings=40960)
+    dc = dict(vocab_size=4107, hidden_size=1024, intermediate_size=4096, num_hidden_layers=29, num_attention_heads=16,
+              max_position_embeddings=2050)
+    tiny = os.environ.get("BENCH_CPU_TINY") == "1"
+    if tiny:
+        tc.update(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=16)
+        dc.update(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2)
+    from transformers.initialization import no_init_weights
+    t0 = time.time()
+    with no_init_weights():
+        text = O.make_qwen3(tc, "sdpa").to(torch.bfloat16)
+        dna = O.make_nt_v2(dc, "sdpa").to(torch.bfloat16)
+    text, dna = text.to(dev), dna.to(dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    for mdl in (text, dna):
+        for p in mdl.parameters():
+            p.data.uniform_(-0.03, 0.03, generator=g) if p.dim() >= 2 else p.data.fill_(1.0)
+    O.apply_lora(text, r=32, alpha=64.0, dropout=LORA_DROPOUT)
+    text = text.to(dev)
+    for n, p in text.named_parameters():
+        if "lora_" in n:
+            p.data = p.data.to(torch.bfloat16)
+    model = O.OracleDNALLM(text, dna, 151670).to(dev).to(torch.bfloat16)
+    for p in dna.parameters():
+        p.requires_grad_(False)
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(trainable, lr=1e-5, weight_decay=0.0)
+    build_s = time.time() - t0
+
+    def to_dev(b):
+        return ({"input_ids": b["input_ids"].to(dev), "attention_mask": b["attention_mask"].to(dev)},
+                {"dna_tokenized": {k: v.to(dev) for k, v in b["dna_tokenized"].items()}, "batch_idx_map": list(b["batch_idx_map"])})
+
+    def timed(fn, warm, n):
+        for _ in range(warm):
+            fn()
+        sync()
+        t = time.time()
+        for _ in range(n):
+            fn()
+        sync()
+        return (time.time() - t) / n
+
+    out = {"unit": "samples/s", "kind": "reference glue + installed transformers %s on stock PyTorch-ROCm %s eager kernels, bf16, sdpa, "
+                                        "same MI355X" % (__import__("transformers").__version__, torch.__version__),
+           "device": torch.cuda.get_device_name(0) if on_gpu else "cpu", "model_build_s": round(build_s, 1)}
+    # ---- GRPO, cfg-3
+    b = synth_prompt_batch(B=G, n_unique=1, Sd=SD, text_len=TEXT_LEN, n_dna=NDNA, seed=42)
+    io, mm = to_dev(b)
+    gen_kw = dict(do_sample=True, temperature=0.6, top_k=20, top_p=0.95, pad_token_id=0, max_new_tokens=C, min_new_tokens=C)
+    phases = {}
+
+    def grpo_step():
+        t_a = time.time()
+        model.eval()                                            # (HF Trainer would leave train mode on; dropout-free rollouts = the headline's)
+        with torch.no_grad():
+            comp = model.generate(**io, **mm, **gen_kw)
+        comp = comp[:, -C:]
+        ids = torch.cat([io["input_ids"], comp], 1)
+        mask = torch.ones_like(ids)
+        sync(); t_b = time.time()
+        O.set_adapters(text, False)
+        with torch.no_grad():
+            ref_lp = GM.per_token_logps(model, ids, mask, **mm)[:, -C:]
+        O.set_adapters(text, True)
+        sync(); t_c = time.time()
+        model.train()
+        opt.zero_grad(set_to_none=True)
+        lp = GM.per_token_logps(model, ids, mask, **mm)[:, -C:]
+        adv = torch.linspace(-1.0, 1.0, G, device=dev)
+        loss, _, _ = GM.grpo_loss(lp.float(), None, ref_lp.float(), adv, torch.ones(G, C, device=dev), 0.2, 0.2, 0.04)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(trainable, 1.0)
+        opt.step()
+        sync(); t_d = time.time()
+        phases.update(rollout=t_b - t_a, ref_logps=t_c - t_b, policy_fwd_bwd_opt=t_d - t_c)
+
+    n_steps = int(os.environ.get("BENCH_HF_STEPS", "2"))
+    try:
+        t_step = timed(grpo_step, 1, n_steps)
+        out.update(value=G / t_step, ms_per_step=1000.0 * t_step, steps=n_steps, warmup=1,
+                   phases_ms={k: round(1000.0 * v, 1) for k, v in phases.items()},
+                   ms_per_token_step=round(1000.0 * phases["rollout"] / C, 2),
+                   workload="the reference's GRPO step, cfg-3: 1 prompt x G=8 rows of P=%d, 256 sampled tokens (HF generate), reference "
+                            "log-probs, policy forward/backward over [8, P+C] rows with full-row lm_head logits (grpo_trainer.py:510-520), "
+                            "LoRA r=32 dropout %g, AdamW; DNA encoder inside each pass" % (b["input_ids"].shape[1], LORA_DROPOUT))
+    except Exception as e:
+        out.update(value=None, error="%s: %s" % (type(e).__name__, str(e)[:300]))
+    out["hbm_peak_gib_grpo"] = round(torch.cuda.max_memory_allocated(dev) / 2.0 ** 30, 1) if on_gpu else None
+    # ---- SFT, cfg-2
+    try:
+        bs = synth_prompt_batch(B=8, n_unique=8, Sd=SD, text_len=TEXT_LEN, n_dna=NDNA, seed=23)
+        ios, mms = to_dev(bs)
+        labels = torch.full_like(ios["input_ids"], -100)
+        labels[:, -SFT_LABEL_TAIL:] = ios["input_ids"][:, -SFT_LABEL_TAIL:]
+        model.train()
+
+        def sft_step():
+            opt.zero_grad(set_to_none=True)
+            o = model(**ios, labels=labels, **mms)
+            o.loss.backward()
+            torch.nn.utils.clip_grad_norm_(trainable, 1.0)
+            opt.step()
+
+        if on_gpu:
+            torch.cuda.empty_cache()
+        t_sft = timed(sft_step, 1, 3)
+        out["sft"] = {"value": 8 / t_sft, "unit": "samples/s", "ms_per_step": 1000.0 * t_sft, "steps": 3, "warmup": 1,
+                      "workload": "cfg-2 SFT step: B=8 distinct samples, P=%d, full-row logits + shifted CE, backward, AdamW (no gradient "
+                                  "checkpointing)" % bs["input_ids"].shape[1]}
+    except Exception as e:
+        out["sft"] = {"value": None, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    out["hbm_peak_gib"] = round(torch.cuda.max_memory_allocated(dev) / 2.0 ** 30, 1) if on_gpu else None
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- GPU legs
 def decode_roofline(model, rollout_profile, Cn, n_prompts, P, loop_ev=None):
     """HBM roofline of the rollout's token loop (the largest phase of the step by time; every kernel in it is a weight / KV
@@ -508,9 +650,14 @@ def main():
     ap.add_argument("--completion-len", type=int, default=None)
     ap.add_argument("--lora-dropout", type=float, default=LORA_DROPOUT, help="PEFT lora_dropout of the policy pass (reference: 0.05)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the oracle timing leg and print its JSON")
+    ap.add_argument("--no-gpu-baseline-hf", action="store_true", help="skip the `gpu_baseline_hf` leg (the oracle on this GPU through stock PyTorch-ROCm)")
+    ap.add_argument("--gpu-baseline-hf-only", action="store_true", help="internal: run the oracle-on-GPU timing leg and print its JSON")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.mode)), flush=True)
+        return
+    if args.gpu_baseline_hf_only:
+        print(json.dumps(gpu_baseline_hf()), flush=True)
         return
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)
@@ -548,6 +695,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
 
     from bioreason_amd import ops
+    if (args.no_w4_gemm or args.round3_kernels) and not dims.dry:
+        # A/B flags pin tile variants: those knobs exist only in the debug build (include/bioreason_hip_debug.h), never in the product library
+        from bioreason_amd import _lib as _bra_lib
+        _bra_lib.use_debug_library()
     if args.no_w4_gemm:
         from bioreason_amd._lib import get_lib
         get_lib().call("bra_gemm_set_variant", -2)
@@ -755,6 +906,34 @@ def main():
             if metrics_t is not None:
                 line["metrics"] = {k: float(v) for k, v in zip(runner.metric_names, metrics_t.tolist())}
         line.update(secondary)
+        # ---- what the headline's policy pass is, in the line itself: `value` runs the shared-prompt policy pass, opted into
+        # explicitly here (the library default follows the reference: full rows whenever the adapters have dropout); the same step with the
+        # reference's sampling scheme is `value_reference_semantics` (= the `unshared_policy` leg)
+        if args.mode == "grpo":
+            line["policy_pass"] = ("full rows, an independent LoRA-dropout mask per copy (the reference's scheme)" if args.no_shared_policy else
+                                   "shared prompt rows per group (explicit opt-in: GRPOConfig.share_policy_prompt=True); under lora_dropout > 0 one "
+                                   "mask stream for the shared rows — unbiased, not the reference's sampling scheme (DESIGN.md section 6)")
+            if args.no_shared_policy:
+                line["value_reference_semantics"] = value
+            elif "unshared_policy" in secondary:
+                line["value_reference_semantics"] = secondary["unshared_policy"]["value"]
+        if headline_default and world == 1 and not dims.dry and not args.no_gpu_baseline_hf:
+            try:   # the oracle on this GPU (stock PyTorch-ROCm), its own process; the HIP model of this process keeps its ~60 GB of the 288
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpu-baseline-hf-only"], capture_output=True, text=True,
+                                   timeout=float(os.environ.get("BENCH_HF_TIMEOUT", "420")))
+                hf = json.loads(r.stdout.strip().splitlines()[-1])
+                if hf.get("value"):
+                    hf["hip_over_hf"] = value / hf["value"]
+                    if "value_reference_semantics" in line:
+                        hf["hip_reference_semantics_over_hf"] = line["value_reference_semantics"] / hf["value"]
+                if hf.get("sft", {}).get("value") and "sft" in secondary:
+                    hf["sft"]["hip_over_hf"] = secondary["sft"]["value"] / hf["sft"]["value"]
+                line["gpu_baseline_hf"] = hf
+            except Exception as e:
+                line["gpu_baseline_hf"] = {"value": None, "unit": "samples/s", "error": "not measured: %s: %s" % (type(e).__name__, str(e)[:200])}
         if not args.no_cpu_baseline and world == 1 and not dims.dry:
             try:   # separate process, hard wall-clock bound: the GPU number must be reported whatever the host does
                 env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")

@@ -19,7 +19,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "bioreason_hip.h")
+_DEBUG_HEADER = os.path.join(os.path.dirname(_HERE), "include", "bioreason_hip_debug.h")
 _LIB_PATH = os.path.join(_HERE, "libbioreason_hip.so")
+_DEBUG_LIB_PATH = os.path.join(_HERE, "libbioreason_hip_debug.so")
 
 _CTYPES = {
     "int": ctypes.c_int,
@@ -64,7 +66,9 @@ class KernelError(RuntimeError):
 
 
 class KernelLibrary:
-    def __init__(self, path: str, emulated: bool = False):
+    def __init__(self, path: str, emulated: bool = False, debug: bool = False):
+        """`debug`: the library was built with -DBRA_DEBUG and also exports include/bioreason_hip_debug.h (knobs, probes, the
+        persistent decode step); the emulator build of tests/emu always is."""
         if not os.path.exists(path):
             raise RuntimeError(
                 f"bioreason_amd: kernel library {path} is missing. Build it with "
@@ -73,8 +77,11 @@ class KernelLibrary:
             )
         self.path = path
         self.emulated = emulated
+        self.debug = bool(debug or emulated)
         self._dll = ctypes.CDLL(path)
         self.protos = parse_header()
+        if self.debug:
+            self.protos.update(parse_header(_DEBUG_HEADER))
         self._fn = {}
         for name, args in self.protos.items():
             try:
@@ -134,6 +141,19 @@ def get_lib() -> KernelLibrary:
     global _lib
     if _lib is None:
         _lib = KernelLibrary(_LIB_PATH, emulated=False)
+    return _lib
+
+
+def use_debug_library() -> KernelLibrary:
+    """Opt into libbioreason_hip_debug.so (the same kernels + include/bioreason_hip_debug.h: tile-variant knobs, probes, the
+    persistent decode step) for this process: tests that pin a variant, tools/, bench.py's A/B flags.  Never the default."""
+    global _lib
+    if _lib is not None and _lib.debug:
+        return _lib
+    if not os.path.exists(_DEBUG_LIB_PATH):
+        raise RuntimeError(f"bioreason_amd: {_DEBUG_LIB_PATH} is missing; build it with `make -C bioreason_amd/csrc debug` "
+                           "(__graft_entry__.build() does)")
+    _lib = KernelLibrary(_DEBUG_LIB_PATH, emulated=False, debug=True)
     return _lib
 
 

@@ -16,12 +16,12 @@ struct DecGemm2Args {
     float* ss_out; int nss_out;         // partial sums of squares of the bf16 outputs, [8 | 16][nss_out], column = workgroup
     int M, N, K;
     int packed;                         // W is in fragment order (bra_dec_pack_weights): [tile][k-step][lane][8]
-    unsigned long long* probe;          // optional timing probe (tools/dec_overhead_probe.py): 8 stamps per probed workgroup
+    BRA_DBG_FIELD(unsigned long long* probe;)   // BRA_DEBUG only: timing probe (tools/dec_overhead_probe.py), 8 stamps per probed workgroup
     float inv_K;                        // 1 / K rounded on the host (NORM == 2: mean of squares = fma(sum, inv_K, eps))
 };
 
-// 100 MHz wall clock (s_memrealtime); the probe is compiled in but costs one uniform branch per stamp when unused
-#ifdef BRA_EMU
+// 100 MHz wall clock (s_memrealtime); compiled in only under BRA_DEBUG (one uniform branch per stamp when unused)
+#if defined(BRA_EMU) || !defined(BRA_DEBUG)
 __device__ __forceinline__ void dg2_stamp(const DecGemm2Args&, int) {}
 #else
 __device__ __forceinline__ void dg2_stamp(const DecGemm2Args& g, int slot) {

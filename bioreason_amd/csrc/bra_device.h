@@ -3,6 +3,17 @@
 // (With -DBRA_EMU the same sources are compiled for the host test executor in
 // tests/emu/; that build is test infrastructure and never ships.)
 #pragma once
+// Diagnostics (timing probes, tile-variant knobs, the persistent decode step) exist only in the -DBRA_DEBUG build
+// (libbioreason_hip_debug.so, include/bioreason_hip_debug.h); the product library carries no process-wide mutable knob and no
+// probe word in any kernel argument record.
+#ifdef BRA_DEBUG
+#define BRA_DBG_FIELD(decl) decl
+#define BRA_DBG_INIT(x) x,
+#else
+#define BRA_DBG_FIELD(decl)
+#define BRA_DBG_INIT(x)
+#endif
+
 #include <stdint.h>
 #include <stddef.h>
 

@@ -1183,7 +1183,9 @@ extern "C" int bra_attn_bwd_split(const void* q, long q_sb, long q_ss, long q_sh
                          part_dv, stream);
 }
 
+#ifdef BRA_DEBUG
 extern "C" int bra_attn_set_block_order(int legacy) { g_attn_legacy_order = legacy ? 1 : 0; return 0; }
+#endif
 
 extern "C" int bra_attn_decode_nchunk(int len) { return (len + 127) / 128; }
 

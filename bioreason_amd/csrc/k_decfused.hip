@@ -199,7 +199,7 @@ struct DecAttnArgs {
     float eps, scale;
     int chunk_off, nchunk_tot;             // slot of this call's chunks inside the partial buffers (shared-prefix split)
     const int* t_ptr;                      // optional device-side cur_len (graph replay: the launch arguments stay constant)
-    unsigned long long* probe;
+    BRA_DBG_FIELD(unsigned long long* probe;)
     const float* rope_rows;                // optional [B, hd]: cos | sin of each sequence's CURRENT position (bra_rope_rows): no pos -> table hop
 };
 
@@ -239,7 +239,11 @@ __device__ __forceinline__ void dec_attn_partial_body(const DecAttnArgs& a, cons
     const int hkv = G == GT ? hsel : hsel / GT;
     const int hq0 = G == GT ? hkv * GT : hsel;
     const int lane = lane_id();
+#ifdef BRA_DEBUG
     unsigned long long* pr = (a.probe && c == 0 && hkv == 0 && b == 0) ? a.probe + 8 : nullptr;
+#else
+    constexpr unsigned long long* pr = nullptr;
+#endif
     da_stamp(pr, 0);
     int cur_len = a.cur_len, nchunk = a.nchunk, nchunk_tot = a.nchunk_tot;
     if (a.t_ptr) { cur_len = a.t_ptr[0]; nchunk = (cur_len + 64) / 64; nchunk_tot = a.chunk_off + nchunk; }
@@ -435,7 +439,7 @@ extern "C" int bra_dec_attn_partial(const void* qkv, long ldqkv, const void* qw,
     const int G = Hq / Hkv;
     DecAttnArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, (bf16_t*)kc, (bf16_t*)vc,
                      (const uint8_t*)kmask, part_o, part_ml, B, Hq, Hkv, Smax, cur_len, (cur_len + 1 + 63) / 64, eps, scale, chunk_off,
-                     nchunk_tot > 0 ? nchunk_tot : (cur_len + 1 + 63) / 64, t_dev, nullptr, nullptr};
+                     nchunk_tot > 0 ? nchunk_tot : (cur_len + 1 + 63) / 64, t_dev, BRA_DBG_INIT(nullptr) nullptr};
     bra_stream_t st = (bra_stream_t)stream;
     dim3 grid((a.nchunk + 3) / 4, Hkv, B);
 #define BRA_DA(HD_, G_)                                                                         \
@@ -470,7 +474,7 @@ struct DecSharedArgs {
     int R, copies, Hq, Hkv, P, nchunk_tot;
     float eps, scale;
     const int* t_ptr;                     // optional device-side completion index t: nchunk_tot = ceil(P/64) + ceil((t+1)/64)
-    unsigned long long* probe;            // diagnostics (bra_debug_set_probe): 100 MHz stamps of one prompt-part and one completion-part wave
+    BRA_DBG_FIELD(unsigned long long* probe;)   // BRA_DEBUG only (bra_debug_set_probe): 100 MHz stamps of one prompt-part and one completion-part wave
     const float* rope_rows;               // optional [B, hd]: cos | sin of each sequence's current position
 };
 
@@ -480,7 +484,11 @@ __device__ __forceinline__ void dec_attn_shared_body(const DecSharedArgs& a, con
     constexpr int DS = HD / 32;           // 32-deep contraction steps over the head dim
     constexpr int DB = HD / 16;           // 16-wide output blocks over the head dim
     const int lane = lane_id();
+#ifdef BRA_DEBUG
     unsigned long long* pr = (a.probe && c == 0 && hkv == 0 && r == 0) ? a.probe : nullptr;
+#else
+    constexpr unsigned long long* pr = nullptr;
+#endif
     da_stamp(pr, 0);
     const int fr = lane & 15, fq = lane >> 4;
     const int s0 = c * 64;
@@ -647,7 +655,7 @@ extern "C" int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, 
     if (vt_sd < ((P + 63) / 64) * 64 || vt_sd % 4 || kp_ss % 8) return BRA_ERR_ARG;
     DecSharedArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, cosT, sinT, pos, (const bf16_t*)kp, kp_sr, kp_sh, kp_ss,
                        (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask, part_o, part_ml, R, copies, Hq, Hkv, P,
-                       nchunk_tot, eps, scale, t_dev, nullptr, nullptr};
+                       nchunk_tot, eps, scale, t_dev, BRA_DBG_INIT(nullptr) nullptr};
     bra_stream_t st = (bra_stream_t)stream;
     dim3 grid((P + 63) / 64, Hkv, R);
 #define BRA_DS(HD_, G_)                                                                         \
@@ -660,12 +668,14 @@ extern "C" int bra_dec_attn_shared(const void* qkv, long ldqkv, const void* qw, 
     return BRA_ERR_UNSUPPORTED;
 }
 
+#ifdef BRA_DEBUG
 #ifdef BRA_EMU
 static unsigned long long* g_debug_probe = nullptr;
 #else
-static std::atomic<unsigned long long*> g_debug_probe{nullptr};        // diagnostics knob (include/bioreason_hip.h)
+static std::atomic<unsigned long long*> g_debug_probe{nullptr};        // diagnostics knob (include/bioreason_hip_debug.h)
 #endif
 extern "C" int bra_debug_set_probe(void* p) { g_debug_probe = (unsigned long long*)p; return 0; }
+#endif
 
 extern "C" int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, const void* kw, const float* cosT,
                                  const float* sinT, const int* pos, const void* kp, long kp_sr, long kp_sh, long kp_ss,
@@ -680,9 +690,9 @@ extern "C" int bra_dec_attn_both(const void* qkv, long ldqkv, const void* qw, co
     const int npc = (P + 63) / 64, ncc = (t + 64) / 64, ntot = npc + ncc;
     DecSharedArgs s = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, cosT, sinT, pos, (const bf16_t*)kp, kp_sr, kp_sh, kp_ss,
                        (const bf16_t*)vtp, vt_sr, vt_sh, vt_sd, (const uint8_t*)pmask, part_o, part_ml, R, copies, Hq, Hkv, P,
-                       ntot, eps, scale, t_dev, (unsigned long long*)g_debug_probe, rope_rows};
+                       ntot, eps, scale, t_dev, BRA_DBG_INIT((unsigned long long*)g_debug_probe) rope_rows};
     DecAttnArgs a = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)qw, (const bf16_t*)kw, cosT, sinT, pos, (bf16_t*)kc,
-                     (bf16_t*)vc, nullptr, part_o, part_ml, B, Hq, Hkv, C, t, ncc, eps, scale, npc, ntot, t_dev, (unsigned long long*)g_debug_probe, rope_rows};
+                     (bf16_t*)vc, nullptr, part_o, part_ml, B, Hq, Hkv, C, t, ncc, eps, scale, npc, ntot, t_dev, BRA_DBG_INIT((unsigned long long*)g_debug_probe) rope_rows};
     bra_stream_t st = (bra_stream_t)stream;
     const dim3 grid(npc * Hkv * R + ncc * Hq * B);
 #define BRA_DB(HD_, G_)                                                                         \

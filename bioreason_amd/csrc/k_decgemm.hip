@@ -334,8 +334,9 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     //  projection runs 16 waves to keep the single register round)
     const int nw = (WIDE && nsteps >= 128) ? 16 : (nsteps >= 64 ? 8 : 4);
     const int spw = (nsteps + nw - 1) / nw;
-    const int nl = (spw >= 12 && spw % 12 == 0) ? 12 : (spw == 10 ? 10 : (spw > 4 ? 8 : 4));     // (10: K = 2560, Qwen3-4B's hidden size)
-    if (nl == 10 && nw != 8) return BRA_ERR_UNSUPPORTED;                                         // (only the 8-wave form is instantiated)
+    // (10: K = 2560, Qwen3-4B's hidden size — instantiated for the 8-wave form only; 4- and 16-wave shapes with ten steps per wave
+    //  take nl = 8 in the generic multi-round loop, as before that form existed)
+    const int nl = (spw >= 12 && spw % 12 == 0) ? 12 : ((spw == 10 && nw == 8) ? 10 : (spw > 4 ? 8 : 4));
     if (NORM == 2 && (nsteps + nw * nl - 1) / (nw * nl) != 1) return BRA_ERR_UNSUPPORTED;     // folded norm: single-round path only
     const int ntiles = MODE ? g.N / 8 : (g.N + 15) / 16;
     // one workgroup of 8 waves (two of 4) per CU, looping over the tiles; the 16-wave form takes one tile per workgroup
@@ -346,7 +347,12 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     // fast form: see the kernel; everything it assumes is checked here
     const bool fits32 = g.ldx < (1 << 24) && g.ldres < (1 << 24) && 16 * g.ldx < (1L << 30) && 16 * g.ldres + g.N < (1L << 30) &&
                         16L * g.nss_in < (1L << 24);
-    const bool fast = NORM != 1 && (g.packed & 1) && nsteps == nw * nl && !g.probe && fits32;
+#ifdef BRA_DEBUG
+    const bool probed = g.probe != nullptr;          // the fast form carries no stamps
+#else
+    const bool probed = false;
+#endif
+    const bool fast = NORM != 1 && (g.packed & 1) && nsteps == nw * nl && !probed && fits32;
     (void)fast;
 #define BRA_DG2(NW_, NL_)                                                                                                      \
     do {                                                                                                                       \
@@ -372,20 +378,37 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
 
 using namespace bra;
 
-extern "C" int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
-                                   const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
-                                   int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* probe, void* stream);
+static int dec_gemm2_any(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
+                        const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
+                        int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* probe, void* stream);
 
 extern "C" int bra_dec_gemm2(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
                              const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
                              int nss_out, int M, int N, int K, int act, int out_f32, void* stream) {
-    return bra_dec_gemm2_probe(x, ldx, ss_in, nss_in, norm_w, eps, W, ldw, res, ldres, out, ldo, ss_out, nss_out, M, N, K, act, out_f32,
-                               0, nullptr, stream);
+    return dec_gemm2_any(x, ldx, ss_in, nss_in, norm_w, eps, W, ldw, res, ldres, out, ldo, ss_out, nss_out, M, N, K, act, out_f32,
+                         0, nullptr, stream);
 }
 
+extern "C" int bra_dec_gemm2_packed(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
+                                    const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
+                                    int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* stream) {
+    return dec_gemm2_any(x, ldx, ss_in, nss_in, norm_w, eps, W, ldw, res, ldres, out, ldo, ss_out, nss_out, M, N, K, act, out_f32,
+                         packed, nullptr, stream);
+}
+
+#ifdef BRA_DEBUG
 extern "C" int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
                                    const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
                                    int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* probe, void* stream) {
+    return dec_gemm2_any(x, ldx, ss_in, nss_in, norm_w, eps, W, ldw, res, ldres, out, ldo, ss_out, nss_out, M, N, K, act, out_f32,
+                         packed, probe, stream);
+}
+#endif
+
+static int dec_gemm2_any(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
+                        const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
+                        int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* probe, void* stream) {
+    (void)probe;
     if (M <= 0 || M > 16 || N <= 0 || K <= 0 || K % 32 || ldx % 8 || ldw % 8 || !x || !W || !out) return BRA_ERR_ARG;
     if (act && (N % 16 || out_f32 || res || ss_out)) return BRA_ERR_ARG;
     if (out_f32 && res) return BRA_ERR_ARG;            // (out_f32 with ss_out: per-tile maxima of the logits, 16-column tiles)
@@ -397,7 +420,7 @@ extern "C" int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, 
     const bool diag = !wide && !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256 && N / 8 <= 256;
     if (ss_out && nss_out < (diag ? N / 8 : (N + 15) / 16)) return BRA_ERR_ARG;
     DecGemm2Args g = {(const bf16_t*)x, ldx, ss_in, nss_in, (const bf16_t*)norm_w, eps, (const bf16_t*)W, ldw,
-                      (const bf16_t*)res, ldres, out, ldo, ss_out, nss_out, M, N, K, packed, (unsigned long long*)probe, 1.f / (float)K};
+                      (const bf16_t*)res, ldres, out, ldo, ss_out, nss_out, M, N, K, packed, BRA_DBG_INIT((unsigned long long*)probe) 1.f / (float)K};
     if (packed && (N % (diag ? 8 : 16) || K % (diag ? 64 : 32))) return BRA_ERR_ARG;
     bra_stream_t st = (bra_stream_t)stream;
     if ((packed & 2) && !(packed & 1)) return BRA_ERR_ARG;

@@ -5,6 +5,9 @@
 #include "bra_device.h"
 #include "bra_api_internal.h"
 #include "../../include/bioreason_hip.h"
+#ifdef BRA_DEBUG
+#include "../../include/bioreason_hip_debug.h"
+#endif
 
 namespace {
 
@@ -89,7 +92,7 @@ static int sg_begin(const StepGemms& s, const void* x) {
 }
 static int sg_qkv(const StepGemms& s, const Layer& l, const void* x, void* qkv) {
     const int pk = l.flags & 3;
-    if (s.v2) return bra_dec_gemm2_probe(x, s.H, s.ssx, s.nss, l.ln1, s.eps, l.Wqkv, s.H, nullptr, 0, qkv, s.Nqkv, nullptr, 0, s.B, s.Nqkv, s.H, 0, 0, pk, nullptr, s.stream);
+    if (s.v2) return bra_dec_gemm2_packed(x, s.H, s.ssx, s.nss, l.ln1, s.eps, l.Wqkv, s.H, nullptr, 0, qkv, s.Nqkv, nullptr, 0, s.B, s.Nqkv, s.H, 0, 0, pk, s.stream);
     if (pk) return BRA_ERR_UNSUPPORTED;
     return bra_dec_gemm(x, s.H, l.ln1, s.eps, l.Wqkv, s.H, nullptr, 0, qkv, s.Nqkv, s.B, s.Nqkv, s.H, 0, 0, s.stream);
 }
@@ -98,9 +101,9 @@ static int sg_tail(const StepGemms& s, const Layer& l, const void* o, void* x, v
     int rc;
     const int pk = l.flags & 1;
     if (s.v2) {
-        if ((rc = bra_dec_gemm2_probe(o, s.Nq, nullptr, 0, nullptr, 0.f, l.Wo, s.Nq, x, s.H, h, s.H, s.ssh, s.nss, s.B, s.H, s.Nq, 0, 0, pk, nullptr, s.stream))) return rc;
-        if ((rc = bra_dec_gemm2_probe(h, s.H, s.ssh, s.nss, l.ln2, s.eps, l.Wgu, s.H, nullptr, 0, act, s.F, nullptr, 0, s.B, 2 * s.F, s.H, 1, 0, l.flags & 3, nullptr, s.stream))) return rc;
-        return bra_dec_gemm2_probe(act, s.F, nullptr, 0, nullptr, 0.f, l.Wd, s.F, h, s.H, x, s.H, s.ssx, s.nss, s.B, s.H, s.F, 0, 0, pk, nullptr, s.stream);
+        if ((rc = bra_dec_gemm2_packed(o, s.Nq, nullptr, 0, nullptr, 0.f, l.Wo, s.Nq, x, s.H, h, s.H, s.ssh, s.nss, s.B, s.H, s.Nq, 0, 0, pk, s.stream))) return rc;
+        if ((rc = bra_dec_gemm2_packed(h, s.H, s.ssh, s.nss, l.ln2, s.eps, l.Wgu, s.H, nullptr, 0, act, s.F, nullptr, 0, s.B, 2 * s.F, s.H, 1, 0, l.flags & 3, s.stream))) return rc;
+        return bra_dec_gemm2_packed(act, s.F, nullptr, 0, nullptr, 0.f, l.Wd, s.F, h, s.H, x, s.H, s.ssx, s.nss, s.B, s.H, s.F, 0, 0, pk, s.stream);
     }
     if (pk) return BRA_ERR_UNSUPPORTED;
     if ((rc = bra_dec_gemm(o, s.Nq, nullptr, 0.f, l.Wo, s.Nq, x, s.H, h, s.H, s.B, s.H, s.Nq, 0, 0, s.stream))) return rc;
@@ -113,7 +116,7 @@ static int sg_head(const StepGemms& s, const void* x, const void* norm_w, const 
                    float* tmax) {
     const int nt = (s.V + 15) / 16;
     if (s.v2 && Epacked)
-        return bra_dec_gemm2_probe(x, s.H, s.ssx, s.nss, norm_w, s.eps, Epacked, s.H, nullptr, 0, logits, s.V, tmax, tmax ? nt : 0, s.B, s.V, s.H, 0, 1, folded ? 3 : 1, nullptr, s.stream);
+        return bra_dec_gemm2_packed(x, s.H, s.ssx, s.nss, norm_w, s.eps, Epacked, s.H, nullptr, 0, logits, s.V, tmax, tmax ? nt : 0, s.B, s.V, s.H, 0, 1, folded ? 3 : 1, s.stream);
     if (s.v2) return bra_dec_gemm2(x, s.H, s.ssx, s.nss, norm_w, s.eps, E, s.H, nullptr, 0, logits, s.V, tmax, tmax ? nt : 0, s.B, s.V, s.H, 0, 1, s.stream);
     int rc = bra_dec_gemm(x, s.H, norm_w, s.eps, E, s.H, nullptr, 0, logits, s.V, s.B, s.V, s.H, 0, 1, s.stream);
     if (rc || !tmax) return rc;
@@ -219,6 +222,7 @@ extern "C" int bra_qwen_decode_step_one(const void* layers_host, int L, int R, i
     return 0;
 }
 
+#ifdef BRA_DEBUG      // the persistent decode step is an opt-in experiment: libbioreason_hip_debug.so only
 // bra_qwen_decode_step_one with the layer loop as ONE persistent launch (k_persist.hip: bra_qwen_layers_persist) — embed +
 // statistics (unless the sampler left them), one launch for all decoder layers, lm_head: 2-3 launches per token instead of ~170.
 // `layers_host` as above (its record 0 supplies the packed lm_head); `layers_dev` the device table of the persistent kernel.
@@ -261,11 +265,11 @@ extern "C" int bra_qwen_decode_step_persist(const void* layers_host, const void*
                                               t_dev, stream));
             else CK(win(1, 3));
             const int pk = l.flags & 1;
-            if (mask & 4) CK(bra_dec_gemm2_probe(o, sg.Nq, nullptr, 0, nullptr, 0.f, l.Wo, sg.Nq, x, sg.H, h, sg.H, sg.ssh, sg.nss, sg.B, sg.H, sg.Nq, 0, 0, pk, nullptr, stream));
+            if (mask & 4) CK(bra_dec_gemm2_packed(o, sg.Nq, nullptr, 0, nullptr, 0.f, l.Wo, sg.Nq, x, sg.H, h, sg.H, sg.ssh, sg.nss, sg.B, sg.H, sg.Nq, 0, 0, pk, stream));
             else CK(win(3, 4));
-            if (mask & 8) CK(bra_dec_gemm2_probe(h, sg.H, sg.ssh, sg.nss, l.ln2, sg.eps, l.Wgu, sg.H, nullptr, 0, act, sg.F, nullptr, 0, sg.B, 2 * sg.F, sg.H, 1, 0, l.flags & 3, nullptr, stream));
+            if (mask & 8) CK(bra_dec_gemm2_packed(h, sg.H, sg.ssh, sg.nss, l.ln2, sg.eps, l.Wgu, sg.H, nullptr, 0, act, sg.F, nullptr, 0, sg.B, 2 * sg.F, sg.H, 1, 0, l.flags & 3, stream));
             else CK(win(4, 5));
-            if (mask & 16) CK(bra_dec_gemm2_probe(act, sg.F, nullptr, 0, nullptr, 0.f, l.Wd, sg.F, h, sg.H, x, sg.H, sg.ssx, sg.nss, sg.B, sg.H, sg.F, 0, 0, pk, nullptr, stream));
+            if (mask & 16) CK(bra_dec_gemm2_packed(act, sg.F, nullptr, 0, nullptr, 0.f, l.Wd, sg.F, h, sg.H, x, sg.H, sg.ssx, sg.nss, sg.B, sg.H, sg.F, 0, 0, pk, stream));
             else CK(win(5, 6));
         }
     } else
@@ -276,3 +280,4 @@ extern "C" int bra_qwen_decode_step_persist(const void* layers_host, const void*
 #undef CK
     return 0;
 }
+#endif  // BRA_DEBUG

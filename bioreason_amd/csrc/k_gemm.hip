@@ -1343,6 +1343,8 @@ static int check_common(const GemmArgs& g) {
 
 using namespace bra;
 
+#ifdef BRA_DEBUG      // tile-variant knobs for tests and A/B measurements (include/bioreason_hip_debug.h); the product build has none:
+                      // the per-shape choice is a pure function of the call's arguments
 extern "C" int bra_gemm_set_variant(int v) {
     bra::g_forced_glds_rows = 0;
     bra::g_forced_w4 = 0;
@@ -1362,6 +1364,7 @@ extern "C" int bra_gemm_set_glds_rows(int rows) {
 }
 extern "C" int bra_gemm_set_ring_fill(int pct) { bra::ring_min_fill_pct = pct; return 0; }
 extern "C" int bra_gemm_set_row_split(int on) { bra::ring_row_split = on; return 0; }
+#endif
 
 extern "C" int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2,
                                 const void* B2, long ldb2, int K2, void* C, long ldc, int M, int N, int K,

@@ -46,7 +46,7 @@ def prefill(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, ca
     # the same order).  Measured at one prompt of 2180 rows (round 4, tools/decode_probe.py): 16.0 ms against 15.6 ms for one chain —
     # the half-height GEMMs lose what the overlap gains — so it is OPT-IN (BRA_PREFILL_CHUNKS=2), kept for wider prompts.
     two = (dev.type == "cuda" and os.environ.get("BRA_PREFILL_CHUNKS", "1") == "2" and B * S <= 4096 and S >= 1024)
-    if two or os.environ.get("BRA_PREFILL_CHUNKS_FORCE") == "2":
+    if two or (os.environ.get("BRA_PREFILL_CHUNKS_FORCE") == "2" and S >= 2):
         Sa = (S // 2 + 63) // 64 * 64 if S >= 256 else max(1, S // 2)
         posm = pos.reshape(B, S)
         ma = SeqMeta(B=B, S=Sa, pos=posm[:, :Sa].reshape(-1).contiguous(), kmask=kmask[:, :Sa].contiguous(), lora_on=model._lora_enabled,
@@ -247,6 +247,12 @@ class FusedDecodeState:
                        logits, current_stream(self.x))
 
 
+def decode_slots(P: int, C: int) -> int:
+    """partial-result slots per (sequence, q-head) of the shared-prefix decode attention: 64-key chunks of the prompt and of the
+    completion + the new key"""
+    return (P + 63) // 64 + (C + 63) // 64 + 1
+
+
 class SharedDecodeState:
     """`bra_qwen_decode_step_shared`: R prompts x `copies` sequences; prompt K / V^T are held once per prompt, each
     sequence owns only a completion cache [Hkv, C, hd]."""
@@ -267,7 +273,7 @@ class SharedDecodeState:
         # V cache [B, Hkv, hd, cp], the new key as its own partial);  "both" = bra_dec_attn_both + bra_attn_decode_merge
         # (first generation: row-layout V cache, completion keys on the VALU)
         self.attn_impl = os.environ.get("BRA_DEC_ATTN", "one")
-        nslot = (P + 63) // 64 + (C + 63) // 64 + 1
+        nslot = decode_slots(P, C)
         if self.attn_impl == "one" and nslot > 256:
             self.attn_impl = "both"
         if self.attn_impl == "one":
@@ -311,6 +317,9 @@ class SharedDecodeState:
         # sticky across the token steps, so persist_timed_out() after the loop sees a timeout of ANY step
         self.persist = None
         mode = os.environ.get("BRA_DEC_PERSIST", "0")
+        if mode != "0" and not getattr(get_lib(), "debug", False):
+            raise RuntimeError("BRA_DEC_PERSIST needs the debug library (the persistent decode step is not part of the product ABI): "
+                               "call bioreason_amd._lib.use_debug_library() first (`make -C bioreason_amd/csrc debug`)")
         if mode != "0" and self.attn_impl == "one" and use_packed and B <= 8 and all(Rw.get("folded") for Rw in self.rw) and dev.type == "cuda":
             tab = torch.tensor([[Rw["Wqkv_p"].data_ptr(), Rw["Wo_p"].data_ptr(), Rw["Wgu_p"].data_ptr(), Rw["Wd_p"].data_ptr(),
                                  L.qn.data_ptr(), L.kn.data_ptr(), self.kp[i].data_ptr(), self.vtp[i].data_ptr(),
@@ -443,7 +452,10 @@ def _row_chunks(B: int, prompt_alias):
 
 
 def _generate_in_row_chunks(model, inputs_embeds, attention_mask, prompt_alias, force_tokens, eos_schedule, seed, kw):
+    """`kw`: EVERY other keyword of generate() (built from its locals, so a keyword added later is forwarded too)"""
     B = inputs_embeds.shape[0]
+    trace = kw.pop("trace_logits", None)
+    traces = []
     eos_ = kw["eos_token_id"]
     eos0 = (list(eos_)[0] if len(eos_) else None) if isinstance(eos_, (list, tuple)) else eos_
     pad = int(kw["pad_token_id"]) if kw["pad_token_id"] is not None else (int(eos0) if eos0 is not None else 0)
@@ -458,7 +470,11 @@ def _generate_in_row_chunks(model, inputs_embeds, attention_mask, prompt_alias, 
                              force_tokens=None if force_tokens is None else force_tokens[lo:hi],
                              eos_schedule=None if eos_schedule is None else eos_schedule[lo:hi].contiguous(),
                              seed=seed + 7919 * ci,                               # rows restart at 0 in every chunk: distinct draw streams
+                             trace_logits=None if trace is None else traces.append([]) or traces[-1],
                              **kw))
+    if trace is not None:                                                          # per step: the chunks' logits stacked back into [B, V]
+        for t_ in range(max(len(tr) for tr in traces)):
+            trace.append(torch.cat([tr[min(t_, len(tr) - 1)] for tr in traces], 0))
     T = max(o.shape[1] for o in outs)
     full = torch.full((B, T), pad, dtype=torch.long, device=inputs_embeds.device)
     r = 0
@@ -487,6 +503,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     lists two); the first one is the pad default.  `eos_schedule` int32 [B] (benchmarks / tests with random-init weights):
     row b is made to draw the first EOS id at step eos_schedule[b].
     `trace_logits` (tests): a list that receives a copy of the fp32 logits [B, V] after every decode step (eager issue only)."""
+    _call_kw = dict(locals())                      # every argument of this call, by name (forwarded whole by the row-chunk path)
     eng = model.ensure_packed()
     B, P, H = inputs_embeds.shape
     dev = inputs_embeds.device
@@ -494,12 +511,9 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
         # the streaming decode kernels take up to 16 sequences per launch (one MFMA tile of rows); the reference's
         # per_device_train_batch_size is free (grpo_config.py), so larger batches run as consecutive row chunks — whole prompt
         # groups where they fit — each with its own prefill, cache and token loop
+        own = ("model", "inputs_embeds", "attention_mask", "prompt_alias", "force_tokens", "eos_schedule", "seed", "eng", "B", "P", "H", "dev")
         return _generate_in_row_chunks(model, inputs_embeds, attention_mask, prompt_alias, force_tokens, eos_schedule, seed,
-                                       dict(max_new_tokens=max_new_tokens, do_sample=do_sample, temperature=temperature, top_k=top_k,
-                                            top_p=top_p, eos_token_id=eos_token_id, pad_token_id=pad_token_id, check_every=check_every,
-                                            return_full_length=return_full_length, native_step=native_step, decode_impl=decode_impl,
-                                            use_graph=use_graph, shared_prefix_decode=shared_prefix_decode, profile=profile,
-                                            loop_events=loop_events))
+                                       {k: v for k, v in _call_kw.items() if k not in own})
     import time as _time
     _t0 = [_time.perf_counter()]
 
@@ -533,7 +547,10 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     # (more than 16 query rows per (prompt, kv-head) — Qwen3-4B: 8 rollouts x G = 4 — run as virtual prompts of <= 16 rows each in
     #  bra_dec_attn_one; the first-generation attention keeps the 16-row limit)
     G_ = eng.Hq // eng.Hkv
-    rows_ok = grp is not None and (grp[1] * G_ <= 16 or (os.environ.get("BRA_DEC_ATTN", "one") == "one" and G_ <= 16
+    # (SharedDecodeState falls back from "one" to the first-generation attention beyond 256 partial slots — P + C above ~16 K — and
+    #  that one keeps the 16-row limit: such a batch takes the per-copy decode instead of failing in the kernel)
+    one_ok = os.environ.get("BRA_DEC_ATTN", "one") == "one" and decode_slots(P, max_new_tokens) <= 256
+    rows_ok = grp is not None and (grp[1] * G_ <= 16 or (one_ok and G_ <= 16
                                                           and any(grp[1] % s_ == 0 and (grp[1] // s_) * G_ <= 16 for s_ in range(1, grp[1] + 1))))
     use_shared = (grp is not None and shared_prefix_decode and native_step and decode_impl == "fused" and eng.hd >= 64 and rows_ok)
     if prompt_alias is None:

@@ -97,10 +97,12 @@ class DNALLMGRPOConfig(TrainingArguments):
     log_completions: bool = field(default=True)
     logging_first_step: bool = field(default=False)
     logging_steps: float = field(default=2)
-    # ---- not in the reference: False runs the policy forward / backward over every copy's full prompt with an independent LoRA-dropout
-    # mask per copy, exactly as the reference draws them (grpo_trainer.py:777-779); True (default) runs the prompt rows of a group once
-    # with one mask stream — identical at lora_dropout = 0, unbiased with lower gradient variance otherwise
-    share_policy_prompt: bool = field(default=True)
+    # ---- not in the reference: None (default) runs the prompt rows of a group once in the policy pass when that is IDENTICAL to the
+    # reference's full-row pass (lora_dropout = 0) and falls back to the full-row pass — an independent LoRA-dropout mask per copy, exactly
+    # as the reference draws them (grpo_trainer.py:777-779) — when the adapters have dropout.  True forces the shared pass (one mask
+    # stream for the shared rows: unbiased, lower gradient variance, NOT the reference's sampling scheme), False the
+    # full-row pass.
+    share_policy_prompt: Optional[bool] = field(default=None)
 
 
 def _lora_fields(peft_config) -> Optional[Dict[str, Any]]:
@@ -181,7 +183,7 @@ class DNALLMGRPOTrainer:
                          learning_rate=args.learning_rate, weight_decay=args.weight_decay, adam_beta1=args.adam_beta1,
                          adam_beta2=args.adam_beta2, adam_epsilon=args.adam_epsilon, max_grad_norm=args.max_grad_norm,
                          eos_token_id=self.processing_class.eos_token_id, pad_token_id=pad_token_id,
-                         seed=args.seed, share_policy_prompt=bool(getattr(args, "share_policy_prompt", True)))
+                         seed=args.seed, share_policy_prompt=getattr(args, "share_policy_prompt", None))
         self.runner = GRPOStepRunner(model, cfg)
         self.state = SimpleNamespace(global_step=0, epoch=0.0, log_history=self.log_history)
         model.train()                                               # HF Trainer.training_step puts the model in train mode

@@ -588,9 +588,9 @@ def dec_gemm2(x, W, ss_in=None, norm_w=None, eps=1e-6, res=None, act=False, out_
     if tile_max is not None:
         assert out_f32 and not want_ss
         ss_out, nss_out, want_ss = tile_max, _ld(tile_max), True
-    get_lib().call("bra_dec_gemm2_probe", x, _ld(x), ss_in, ss_in.shape[1] if ss_in is not None else 0, norm_w, eps, W, _ld(W),
+    get_lib().call("bra_dec_gemm2_packed", x, _ld(x), ss_in, ss_in.shape[1] if ss_in is not None else 0, norm_w, eps, W, _ld(W),
                    res, _ld(res) if res is not None else 0, out, _ld(out), ss_out, nss_out if want_ss else 0, M, N, K,
-                   int(act), int(out_f32), int(packed), None, current_stream(x))
+                   int(act), int(out_f32), int(packed), current_stream(x))
     return out, (None if tile_max is not None else ss_out)
 
 

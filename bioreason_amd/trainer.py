@@ -62,9 +62,13 @@ class GRPOConfig:
     rollout_shared_prefix: bool = True
     grad_buckets: int = 4
     share_dna_encoding: bool = True      # frozen-encoder rows computed once per step and shared by its three passes
-    # the policy pass (forward AND backward) runs the prompt of a group of consecutive copies once (grpo.per_token_logps_shared_policy);
-    # under LoRA dropout the shared prompt rows then carry one mask stream for all copies of a prompt (deviations)
-    share_policy_prompt: bool = True
+    # the policy pass (forward AND backward) may run the prompt of a group of consecutive copies once
+    # (grpo.per_token_logps_shared_policy): identical results at lora_dropout = 0; under LoRA dropout the shared prompt rows would carry
+    # ONE mask stream for all copies of a prompt, where PEFT draws one per copy (grpo_trainer.py:777-779 runs every row's full prompt).
+    # None (default) = the reference's sampling scheme decides: shared when the adapters have no dropout, the full-row pass with
+    # independent masks per copy when they do.  True opts into the shared pass under dropout too (unbiased, lower variance — DESIGN.md
+    # section 6 — but not the reference's scheme; bench.py opts in explicitly and reports both).
+    share_policy_prompt: Optional[bool] = None
     # the reference-policy pass (no grad, adapters off) on a second HIP stream, concurrent with the policy forward: at one prompt x 8
     # rollouts both are chains of kernels that fill about half of the chip (grids of 128 - 144 workgroups on 256 CUs)
     overlap_ref_pass: bool = True
@@ -297,11 +301,18 @@ class GRPOStepRunner(_DataParallelStep):
                 "prompt_alias": batch.get("prompt_alias"), "ref_join": ref_join,
                 "rewards_per_func": all_rewards.mean(0), "roll_metrics": roll_metrics}
 
+    def shares_policy_prompt(self) -> bool:
+        """`cfg.share_policy_prompt`, with None resolved by the adapters' dropout (see GRPOConfig)"""
+        want = self.cfg.share_policy_prompt
+        if want is None:
+            return float(getattr(self.model.text_model, "lora_dropout_p", 0.0) or 0.0) == 0.0
+        return bool(want)
+
     # ---- compute_loss (:751-814) ----------------------------------------------------------------------------------
     def compute_loss(self, inputs: Dict):
         m, c = self.model, self.cfg
         lp = None
-        if c.share_policy_prompt and inputs.get("prompt_alias") is not None:
+        if self.shares_policy_prompt() and inputs.get("prompt_alias") is not None:
             side2 = self._side_stream(inputs["prompt_ids"].device, 1) if c.overlap_policy_chains else None
             lp = grpo.per_token_logps_shared_policy(m, inputs["prompt_ids"], inputs["prompt_mask"], inputs["completion_ids"],
                                                     inputs["completion_mask"], inputs["prompt_alias"], side=side2,

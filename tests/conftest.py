@@ -50,6 +50,39 @@ def backend(request, emu_lib_path):
         torch.cuda.synchronize()
 
 
+@pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def debug_backend(request, emu_lib_path):
+    """like `backend`, for tests that pin a tile variant / use a probe (include/bioreason_hip_debug.h): on the GPU these run against
+    libbioreason_hip_debug.so — the same kernel sources built with -DBRA_DEBUG — never against the product library, which has no knobs"""
+    from bioreason_amd import _lib
+    if request.param == "emu":
+        _lib.use_library_for_tests(emu_lib_path)
+        yield torch.device("cpu")
+        _lib.reset_library()
+    else:
+        if not torch.cuda.is_available():
+            pytest.skip("no GPU")
+        _lib.reset_library()
+        lib = _lib.use_debug_library()
+        assert lib.debug and not lib.emulated
+        yield torch.device("cuda:0")
+        torch.cuda.synchronize()
+        _lib.reset_library()
+
+
+@pytest.fixture
+def hip_debug_device():
+    """Real-GPU-only tests of the debug build (knobs, probes, the persistent decode step)."""
+    from bioreason_amd import _lib
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _lib.reset_library()
+    _lib.use_debug_library()
+    yield torch.device("cuda:0")
+    torch.cuda.synchronize()
+    _lib.reset_library()
+
+
 @pytest.fixture
 def hip_device():
     """Real-GPU-only tests."""

@@ -198,9 +198,23 @@ def runs(any_device):
     t0 = time.time()
     bf16 = _oracle_run(ora, text, b, comp, want_decode=False)
     t_bf16 = time.time() - t0
+    # ---- the same bf16 oracle modules on THIS GPU through stock PyTorch-ROCm eager kernels: what the reference itself
+    # executes on a GPU box — the HIP path is compared with that run directly in test_hip_vs_hf_on_the_same_gpu
+    hf_gpu, t_gpu = None, 0.0
+    if dev.type == "cuda":
+        t0 = time.time()
+        ora.to(dev)
+        bg = {"input_ids": b["input_ids"].to(dev), "attention_mask": b["attention_mask"].to(dev), "labels": b["labels"].to(dev),
+              "dna_tokenized": {k: v.to(dev) for k, v in b["dna_tokenized"].items()}, "batch_idx_map": list(b["batch_idx_map"])}
+        hf_gpu = {k: v.cpu() for k, v in _oracle_run(ora, text, bg, comp.to(dev), want_decode=True).items()}
+        torch.cuda.synchronize()
+        t_gpu = time.time() - t0
     del ora, text, dna
-    print(f"\n[fullsize] oracle build {t_build:.0f}s, fp32 run {t_fp32:.0f}s, bf16 run {t_bf16:.0f}s on {torch.get_num_threads()} threads")
-    return {"m": m, "b": b, "comp": comp, "fp32": fp32, "bf16": bf16, "dev": dev}
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
+    print(f"\n[fullsize] oracle build {t_build:.0f}s, fp32 run {t_fp32:.0f}s, bf16 run {t_bf16:.0f}s on {torch.get_num_threads()} threads; "
+          f"bf16 oracle on the GPU (stock PyTorch-ROCm) {t_gpu:.0f}s")
+    return {"m": m, "b": b, "comp": comp, "fp32": fp32, "bf16": bf16, "hf_gpu": hf_gpu, "dev": dev}
 
 
 def _dev_batch(b, dev):
@@ -324,7 +338,8 @@ def test_shared_policy_pass_fullsize(runs):
     # two bf16 executions of the same pass: their largest log-prob difference over the 4 x C positions is bounded by the reference's
     # OWN largest bf16 deviation from fp32 on these rows (measured in test_per_token_logps_fullsize; a max over 8x more positions
     # than round 3's C = 32 is heavier-tailed than the fixed 0.06 it was held to)
-    d_ref = RATIOS.get("logps_maxabs", {}).get("refbf16", 0.04)
+    assert "logps_maxabs" in RATIOS, "test_per_token_logps_fullsize must run first (it measures the reference's own bf16 deviation)"
+    d_ref = RATIOS["logps_maxabs"]["refbf16"]
     RATIOS["shared_policy_vs_full"]["logps_maxabs_refbf16"] = d_ref
     assert d <= 2.0 * d_ref + 1e-3, (d, d_ref)
     assert gr <= 1.5 * noise, (gr, noise)       # the two passes differ by where bf16 roundings of dK / dV fall: inside the gradients' own bf16 noise
@@ -360,7 +375,7 @@ def test_greedy_decode_fused_shared_prefix_fullsize(runs):
                 n_tie += 1
     RATIOS["greedy"] = {"near_ties": n_tie, "positions": 4 * NGREEDY, "tokens": NGREEDY, "last_position": int(ids4.shape[1]) + NGREEDY,
                         "free_run_equal": bool(torch.equal(free, want))}
-    assert n_tie <= max(4, (4 * NGREEDY) // 12)        # (round 3: 4 of 64 positions inside the oracle's own bf16 near-tie margin)
+    assert n_tie <= max(4, (4 * NGREEDY) // 64)        # measured: 4 of 512 positions inside the oracle's own bf16 near-tie margin
     if n_tie == 0:
         assert torch.equal(free, want)
 
@@ -395,7 +410,59 @@ def test_greedy_decode_many_rows_fullsize(runs):
                     assert 0 <= margin <= 3.0 * noise * scores[bi, t].norm().item() / scores.shape[-1] ** 0.5 + 1e-3, (tag, bi, t, ours, theirs, margin)
                     n_tie += 1
         RATIOS["greedy_" + tag] = {"near_ties": n_tie, "positions": len(first) * NGREEDY16, "sequences": n}
-        assert n_tie <= max(2, (len(first) * NGREEDY16) // 12)
+        assert n_tie <= max(2, (len(first) * NGREEDY16) // 32)      # measured: 1 of 64, 1 of 32
+
+
+@pytest.mark.gpu
+def test_hip_vs_hf_on_the_same_gpu(runs):
+    """the HIP path against the reference's own bf16 execution ON THIS GPU (the oracle modules through stock
+    PyTorch-ROCm eager kernels; `runs["hf_gpu"]`), not only against the CPU oracle: log-probs of the policy and of the adapter-off
+    reference, the logits of the last 64 positions, and greedy tokens teacher-forced with the HF-on-GPU run's own tokens.
+    Two bf16 executions of one network differ by about the sum of their distances from the exact answer: the bound is
+    rel(hip, hf_gpu) <= rel(hip, fp32) + rel(hf_gpu, fp32), each side measured here; a greedy token may differ only where the HF run's
+    own top-2 margin is inside that noise."""
+    from bioreason_amd import grpo
+    if runs["hf_gpu"] is None:
+        pytest.skip("no GPU run of the oracle (emulator plumbing run)")
+    m, b, comp, dev, hf, fp32 = runs["m"], runs["b"], runs["comp"], runs["dev"], runs["hf_gpu"], runs["fp32"]
+    db = _dev_batch(b, dev)
+    cm = torch.ones((2, C), dtype=torch.int32, device=dev)
+    mm = {"dna_tokenized": db["dna_tokenized"], "batch_idx_map": db["batch_idx_map"]}
+    with torch.no_grad():
+        lp = grpo.per_token_logps(m, db["input_ids"], db["attention_mask"], comp.to(dev), cm, **mm).float().cpu()
+        with m.text_model.disable_adapter():
+            rlp = grpo.per_token_logps(m, db["input_ids"], db["attention_mask"], comp.to(dev), cm, **mm).float().cpu()
+    out = {}
+    for name, got in (("logps", lp), ("ref_logps", rlp)):
+        e_pair, e_hip, e_hf = rel(got, hf[name]), rel(got, fp32[name]), rel(hf[name], fp32[name])
+        d_pair, d_hf = (got - hf[name]).abs().max().item(), (hf[name] - fp32[name]).abs().max().item()
+        out[name] = {"hip_vs_hfgpu": e_pair, "hip_vs_fp32": e_hip, "hfgpu_vs_fp32": e_hf, "maxabs_hip_vs_hfgpu": d_pair, "maxabs_hfgpu_vs_fp32": d_hf}
+        assert e_hf <= 2.0 * rel(runs["bf16"][name], fp32[name]) + 1e-6, (name, "the GPU run of the oracle is not a bf16 execution of the same network", e_hf)
+        assert e_pair <= FACTOR * (e_hip + e_hf), (name, e_pair, e_hip, e_hf)
+        assert d_pair <= 3.0 * d_hf + 1e-3, (name, d_pair, d_hf)
+    # greedy: teacher-forced with the HF-on-GPU run's tokens on the fused shared-prefix path (2 prompts x 2 copies)
+    rows = [0, 0, 1, 1]
+    ids4, mask4 = db["input_ids"][rows], db["attention_mask"][rows]
+    dna4 = {k: torch.cat([v[0:2], v[0:2], v[2:4], v[2:4]], 0) for k, v in db["dna_tokenized"].items()}
+    want, scores = hf["greedy_ids"][rows], hf["greedy_scores"][rows]
+    forced = m.generate(input_ids=ids4, attention_mask=mask4, dna_tokenized=dna4, batch_idx_map=[0, 0, 1, 1, 2, 2, 3, 3],
+                        dna_alias=[0, 1, 0, 1, 4, 5, 4, 5], prompt_alias=[0, 0, 2, 2], max_new_tokens=NGREEDY, do_sample=False,
+                        eos_token_id=None, force_tokens=want.to(dev)).cpu()
+    noise = max(RATIOS.get("logits_tail", {}).get("refbf16_vs_fp32", 1e-2), rel(hf["logits_tail"], fp32["logits_tail"]))
+    n_diff = 0
+    for bi in (0, 2):
+        for t in range(NGREEDY):
+            ours, theirs = int(forced[bi, t]), int(want[bi, t])
+            if ours != theirs:
+                margin = (scores[bi, t, theirs] - scores[bi, t, ours]).item()
+                assert 0 <= margin <= 3.0 * noise * scores[bi, t].norm().item() / scores.shape[-1] ** 0.5 + 1e-3, (bi, t, ours, theirs, margin)
+                n_diff += 1
+    # the HF run's own agreement with the fp32 oracle over the same positions (it free-runs: equal prefixes only)
+    agree_fp32 = int((hf["greedy_ids"] == fp32["greedy_ids"]).all(1).sum().item())
+    out["greedy"] = {"positions": 2 * NGREEDY, "hip_differs_from_hfgpu_inside_its_margin": n_diff, "hfgpu_rows_equal_to_fp32_oracle": agree_fp32,
+                     "logits_tail_hfgpu_vs_fp32": rel(hf["logits_tail"], fp32["logits_tail"])}
+    assert n_diff <= max(4, (2 * NGREEDY) // 32)
+    RATIOS["vs_hf_on_gpu"] = out
 
 
 @pytest.mark.gpu

@@ -857,7 +857,8 @@ def test_lmhead_lse_at_full_vocab(hip_device):
 
 
 @pytest.mark.parametrize("variant", [0, 5, 7, 9, 10, 11, 12, 13, 14])
-def test_gemm_bf16_epilogue_interior_and_edge_waves(backend, variant):
+def test_gemm_bf16_epilogue_interior_and_edge_waves(debug_backend, variant):
+    backend = debug_backend
     """k_gemm.hip epi_bf16_interior: a wave whose fragments all lie inside the matrix takes the batched epilogue (one base
     pointer per operand, every residual word requested up front), the others the generic one: every bias / residual combination
     on a matrix made of interior tiles only, on one with ragged edges, and with a residual whose row pitch is not a multiple of
@@ -886,7 +887,8 @@ def test_gemm_bf16_epilogue_interior_and_edge_waves(backend, variant):
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14])
-def test_gemm_tile_variants(backend, variant):
+def test_gemm_tile_variants(debug_backend, variant):
+    backend = debug_backend
     """every tile variant (128/256-row tiles x register prefetch depth 1/2; 5 / 9 / 10: the LDS-DMA kernel at 256 / 192 / 128-row tiles;
     11 - 14: four waves with 80 x 128 / 64 x 128 / 80 x 64 / 64 x 64 per-wave tiles (opt-in);
     6 / 7: the 256 x 256 ring) against the fp32 statement"""
@@ -1198,7 +1200,8 @@ def test_lora_dropout_padded_rank_blocks(backend, R, nlive):
 
 
 @pytest.mark.gpu
-def test_gemm_ring_row_split_is_exact(hip_device):
+def test_gemm_ring_row_split_is_exact(hip_debug_device):
+    hip_device = hip_debug_device
     """k_gemm.hip ring_split_rows: at N = 2048 the 19488-row projections are 616 ring tiles = 2.41 rounds, so the rows are split
     between the ring kernel (whole rounds) and the 256 x 128 kernel (the rest).  Same K order per output element in both
     kernels: the result must be bit-identical to the unsplit launch, residual included."""

@@ -497,3 +497,42 @@ def test_row_chunks_of_a_large_batch():
     for B, al in [(24, [0] * 8 + [8] * 8 + [16] * 8), (21, [0] * 18 + [18] * 3), (40, None)]:
         ch = _row_chunks(B, al)
         assert ch[0][0] == 0 and ch[-1][1] == B and all(a[1] == b[0] for a, b in zip(ch, ch[1:])) and all(h - l <= 16 for l, h in ch)
+
+
+def test_row_chunk_path_forwards_every_keyword_and_stacks_traces(backend):
+    """the > 16-row path used to rebuild generate()'s keywords by hand and dropped `trace_logits`; it now forwards the call's
+    own keywords whole and stacks the per-chunk traces back into [B, V] per step"""
+    fix = torch.load(os.path.join(GOLD, "tiny_b.pt"), weights_only=False)
+    cfg = fix["config"]
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    rows = [0] * 10 + [1] * 10
+    ids, mask = b["input_ids"][rows], b["attention_mask"][rows]
+    mm = {"dna_tokenized": {k: v[rows] for k, v in b["dna_tokenized"].items()}, "batch_idx_map": list(range(20))}
+    want = fix["fp32_lora"]["greedy_ids"][rows].to(backend)
+    T = 3
+    tr20, tr10 = [], []
+    kw = dict(max_new_tokens=T, do_sample=False, eos_token_id=None, use_graph=False)
+    m.generate(input_ids=ids, attention_mask=mask, **mm, prompt_alias=[0] * 10 + [10] * 10, force_tokens=want[:, :T], trace_logits=tr20, **kw)
+    m.generate(input_ids=ids[:10], attention_mask=mask[:10], dna_tokenized={k: v[:10] for k, v in mm["dna_tokenized"].items()},
+               batch_idx_map=list(range(10)), prompt_alias=[0] * 10, force_tokens=want[:10, :T], trace_logits=tr10, **kw)
+    assert len(tr20) == len(tr10) >= T - 1 and tr20[0].shape == (20, cfg["text"]["vocab_size"])
+    for a, c in zip(tr20, tr10):
+        assert torch.equal(a[:10].cpu(), c.cpu())                    # chunk 0 of the 20-row call IS the 10-row call
+
+
+def test_two_chunk_prefill_equals_one_chunk(backend, monkeypatch):
+    """the opt-in two-chunk prefill (rows [0, Sa) and [Sa, S) one layer apart; BRA_PREFILL_CHUNKS) against the one-chunk
+    prefill: same kernels on the same rows -> the same K / V cache and the same greedy tokens, left-padded row included"""
+    fix = torch.load(os.path.join(GOLD, "tiny_a.pt"), weights_only=False)
+    m = build(fix, backend, True)
+    b = to_dev(fix["batch"], backend)
+    mm = {"dna_tokenized": b["dna_tokenized"], "batch_idx_map": b["batch_idx_map"]}
+    kw = dict(max_new_tokens=6, do_sample=False, eos_token_id=None, use_graph=False)
+    t1, t2 = [], []
+    one = m.generate(input_ids=b["input_ids"], attention_mask=b["attention_mask"], **mm, trace_logits=t1, **kw)
+    monkeypatch.setenv("BRA_PREFILL_CHUNKS_FORCE", "2")
+    two = m.generate(input_ids=b["input_ids"], attention_mask=b["attention_mask"], **mm, trace_logits=t2, **kw)
+    assert torch.equal(one, two) and len(t1) == len(t2) > 0
+    for a, c in zip(t1, t2):
+        assert torch.equal(a.cpu(), c.cpu())

@@ -28,7 +28,8 @@ def _setup(dev, layers, vocab, P, pad):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("copies,P,T", [(8, 333, 70), (5, 130, 12)])
-def test_persistent_step_is_bit_identical_to_launched_step(hip_device, copies, P, T, monkeypatch):
+def test_persistent_step_is_bit_identical_to_launched_step(hip_debug_device, copies, P, T, monkeypatch):
+    hip_device = hip_debug_device
     from bioreason_amd import generation
     dev = hip_device
     if torch.cuda.get_device_properties(0).multi_processor_count < 256:
@@ -65,7 +66,8 @@ def test_persistent_step_is_bit_identical_to_launched_step(hip_device, copies, P
 
 
 @pytest.mark.gpu
-def test_persistent_step_under_graph_replay(hip_device, monkeypatch):
+def test_persistent_step_under_graph_replay(hip_debug_device, monkeypatch):
+    hip_device = hip_debug_device
     """the token loop replayed from a hipGraph (memset node of the barrier record + the persistent launch + lm_head + sampler):
     same tokens as eager issue of the launched kernels"""
     from bioreason_amd import generation

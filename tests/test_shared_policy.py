@@ -119,6 +119,20 @@ def test_runner_uses_the_shared_policy_pass(backend):
                                                share_policy_prompt=False))
         runner2.step(batch)
         assert calls["n"] == 1
+        # default (None): the adapters' dropout decides.  With lora_dropout > 0 the shared rows would carry one mask stream for all
+        # copies of a prompt, which is not how the reference draws them (grpo_trainer.py:777-779) -> the full-row pass, unless opted in
+        m.text_model.lora_dropout_p = 0.05
+        runner3 = GRPOStepRunner(m, GRPOConfig(num_generations=2, max_completion_length=4, eos_token_id=None, seed=3, learning_rate=1e-3))
+        assert runner3.cfg.share_policy_prompt is None and not runner3.shares_policy_prompt()
+        runner3.step(batch)
+        assert calls["n"] == 1
+        runner4 = GRPOStepRunner(m, GRPOConfig(num_generations=2, max_completion_length=4, eos_token_id=None, seed=3, learning_rate=1e-3,
+                                               share_policy_prompt=True))
+        assert runner4.shares_policy_prompt()
+        runner4.step(batch)
+        assert calls["n"] == 2
+        m.text_model.lora_dropout_p = 0.0
+        assert runner3.shares_policy_prompt()
     finally:
         grpo.per_token_logps_shared_policy = orig
 

@@ -2,6 +2,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bioreason_amd import configs
+from bioreason_amd import _lib as _bra_lib
+_bra_lib.use_debug_library()          # knobs / probes / persistent step: libbioreason_hip_debug.so (include/bioreason_hip_debug.h)
 from bioreason_amd._lib import get_lib
 from bioreason_amd.dna_llm import DNALLMModel
 from bioreason_amd.synth import synth_prompt_batch

@@ -5,6 +5,8 @@ Two probe buffers alternate over back-to-back launches in one stream; printed fo
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bioreason_amd import ops
+from bioreason_amd import _lib as _bra_lib
+_bra_lib.use_debug_library()          # knobs / probes / persistent step: libbioreason_hip_debug.so (include/bioreason_hip_debug.h)
 from bioreason_amd._lib import get_lib, current_stream
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 M = 8

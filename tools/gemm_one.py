@@ -3,6 +3,8 @@ usage: gemm_one.py <variant> <M> <N> <K> <K2> [iters]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bioreason_amd import ops
+from bioreason_amd import _lib as _bra_lib
+_bra_lib.use_debug_library()          # knobs / probes / persistent step: libbioreason_hip_debug.so (include/bioreason_hip_debug.h)
 from bioreason_amd._lib import get_lib
 v, M, N, K, K2 = (int(x) for x in sys.argv[1:6])
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 5

@@ -3,6 +3,8 @@ big-M shapes of a Qwen3-1.7B layer, and bit-equality of the two results."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bioreason_amd import ops
+from bioreason_amd import _lib as _bra_lib
+_bra_lib.use_debug_library()          # knobs / probes / persistent step: libbioreason_hip_debug.so (include/bioreason_hip_debug.h)
 from bioreason_amd._lib import get_lib
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 

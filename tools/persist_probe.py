@@ -5,6 +5,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bioreason_amd import configs, generation
+from bioreason_amd import _lib as _bra_lib
+_bra_lib.use_debug_library()          # knobs / probes / persistent step: libbioreason_hip_debug.so (include/bioreason_hip_debug.h)
 from bioreason_amd.modeling import Qwen3ForCausalLM
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 28
