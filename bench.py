@@ -330,7 +330,7 @@ def gpu_baseline_hf():
 
     def sync():
         if on_gpu:
-            sync()
+            torch.cuda.synchronize()
 
     tc = dict(vocab_size=151936, hidden_size=2048, intermediate_size=6144, num_hidden_layers=28, num_attention_heads=16,
               num_key_value_heads=8, head_dim=128, rope_theta=1e6, max_position_embeddings=40960)
@@ -420,7 +420,8 @@ def gpu_baseline_hf():
                             "log-probs, policy forward/backward over [8, P+C] rows with full-row lm_head logits (grpo_trainer.py:510-520), "
                             "LoRA r=32 dropout %g, AdamW; DNA encoder inside each pass" % (b["input_ids"].shape[1], LORA_DROPOUT))
     except Exception as e:
-        out.update(value=None, error="%s: %s" % (type(e).__name__, str(e)[:300]))
+        import traceback
+        out.update(value=None, error="%s: %s | %s" % (type(e).__name__, str(e)[:300], " <- ".join(traceback.format_exc().strip().splitlines()[-6:])[:600]))
     out["hbm_peak_gib_grpo"] = round(torch.cuda.max_memory_allocated(dev) / 2.0 ** 30, 1) if on_gpu else None
     # ---- SFT, cfg-2
     try:
