@@ -451,6 +451,14 @@ def gpu_baseline_hf():
 
 
 # ---------------------------------------------------------------------------------------------- GPU legs
+def fp8_weight_bytes(model):
+    """bytes of the fp8 weight stream per token step: one byte per parameter of the decoder linears and the lm_head + 4 bytes per output row"""
+    e = model.text_model.engine
+    rows = e.L * ((e.Nq + 2 * e.Nkv) + e.H + 2 * e.F + e.H) + e.V
+    params = e.L * ((e.Nq + 2 * e.Nkv) * e.H + e.H * e.Nq + 2 * e.F * e.H + e.H * e.F) + e.V * e.H
+    return params + 4 * rows
+
+
 def decode_roofline(model, rollout_profile, Cn, n_prompts, P, loop_ev=None):
     """HBM roofline of the rollout's token loop (the largest phase of the step by time; every kernel in it is a weight / KV
     stream): algorithmic bytes of one decode step = merged bf16 projection weights + tied lm_head + the K/V rows the
@@ -459,6 +467,8 @@ def decode_roofline(model, rollout_profile, Cn, n_prompts, P, loop_ev=None):
     (`loop_ev`); the host-synchronised wall time of the loop in the instrumented step is kept beside it as a cross-check."""
     e = model.text_model.engine
     w_bytes = 2 * (e.L * ((e.Nq + 2 * e.Nkv) * e.H + e.H * e.Nq + 3 * e.F * e.H) + e.V * e.H)
+    if getattr(model.text_model, "rollout_fp8", False):        # (--rollout-fp8 run: the stream is the e4m3 images + row scales)
+        w_bytes = fp8_weight_bytes(model)
     kv_bytes = e.L * 2 * e.Nkv * 2 * (n_prompts * P + n_prompts * G * (Cn / 2.0))
     ms = rollout_profile.get("decode_loop")
     steps = rollout_profile.get("decode_steps", Cn - 1)
@@ -532,7 +542,7 @@ def build_model(dims: Dims, dev, lora_dropout: float):
     return model
 
 
-def make_grpo_leg(model, dims: Dims, R: int, Cn: int, rank: int, dev, args, eos_uniform, nsteps: int, share_policy=None):
+def make_grpo_leg(model, dims: Dims, R: int, Cn: int, rank: int, dev, args, eos_uniform, nsteps: int, share_policy=None, fp8=None):
     """-> (runner, step(i, timing), samples per step): cfg-3 GRPO step on R prompts x G rollouts of this rank"""
     import torch
     from bioreason_amd.rewards import text_reward_fn
@@ -546,7 +556,8 @@ def make_grpo_leg(model, dims: Dims, R: int, Cn: int, rank: int, dev, args, eos_
                      overlap_ref_pass=not getattr(args, "no_overlap_ref", False),
                      overlap_policy_chains=not getattr(args, "no_overlap_chains", False),
                      overlap_rollout_weights=not getattr(args, "no_overlap_weights", False),
-                     overlap_ref_chains=bool(getattr(args, "overlap_ref_chains", False)))
+                     overlap_ref_chains=bool(getattr(args, "overlap_ref_chains", False)),
+                     rollout_fp8=bool(getattr(args, "rollout_fp8", False)) if fp8 is None else bool(fp8))
     # the reference's reward hop runs inside the timed step: ids -> host -> decode -> the five python reward functions
     # reason.py:291-296 enables by default -> device (a synthetic id -> text table stands in for the tokenizer files)
     reward_names = ["xmlcount", "soft_format", "strict_format", "less_than_4", "correctness"]
@@ -643,6 +654,10 @@ def main():
     ap.add_argument("--no-overlap-ref", action="store_true", help="reference-policy pass on the main stream instead of beside the policy forward")
     ap.add_argument("--no-shared-policy", action="store_true",
                     help="policy forward / backward over every row's full prompt (independent LoRA-dropout masks per copy, as the reference draws them)")
+    ap.add_argument("--rollout-fp8", action="store_true",
+                    help="BASELINE config 5's weight format in the token loop: e4m3 images of the merged weights, one fp32 scale per output "
+                         "row (half the streamed bytes; W8A16).  An opt-in configuration with its own parity criterion "
+                         "(tests/test_fp8_rollout.py), never the bf16 headline: the default run reports it as the secondary leg `rollout_fp8`")
     ap.add_argument("--no-w4-gemm", action="store_true",
                     help="A/B on one box: the per-shape GEMM choice without the four-wave large-tile kernel (bra_gemm_set_variant(-2))")
     ap.add_argument("--round3-kernels", action="store_true",
@@ -778,6 +793,30 @@ def main():
                                   "workload": "the headline GRPO step with every rollout's EOS drawn at U[%d, %d] (SURVEY §8d straggler "
                                               "run; mean completion %.0f tokens; the step waits for its longest row)" % (lo_hi + (mean_len,))}
         del s_runner, s_step
+        if not dims.dry and not args.rollout_fp8:
+            # BASELINE config 5's weight format on the cfg-3 step (opt-in): the token loop over e4m3 weights; everything else unchanged
+            try:
+                e_runner, e_step, e_B = make_grpo_leg(model, dims, R, Cn, rank, dev, args, None, S + 3, fp8=True)
+                e_runner.loop_events = []
+                e_el, _ = timed_steps(e_step, S, 2, 1, dev)
+                torch.cuda.synchronize()
+                ev = [(a.elapsed_time(b), n) for a, b, n in (e_runner.loop_events or [])][-S:]
+                e_runner.loop_events = None
+                e_tok = (sum(ms for ms, _ in ev) / max(1, sum(n for _, n in ev))) if ev else None
+                secondary["rollout_fp8"] = {
+                    "value": e_B * S / e_el, "unit": "samples/s", "ms_per_step": 1000.0 * e_el / S, "steps": S, "warmup": 2,
+                    "ms_per_token_step": e_tok,
+                    "weight_bytes_per_token_step": fp8_weight_bytes(model),
+                    "hbm_frac_of_peak": ((fp8_weight_bytes(model) + 0.366e9) / (e_tok * 1e-3) / 1e9 / PEAK_HBM_GBS) if e_tok else None,
+                    "workload": "the headline GRPO step with the rollout's token loop streaming fp8 (OCP e4m3) images of the merged, "
+                                "norm-folded weights — one fp32 scale per output row, decoded to bf16 in registers in front of the bf16 MFMAs "
+                                "(W8A16), lm_head included; prompt pass, reference pass, policy pass and gradients in bf16.  Rollouts are "
+                                "sampled from the quantised policy (BASELINE config 5 'fp8 weights'); parity: tests/test_fp8_rollout.py"}
+                model.text_model.rollout_fp8 = False
+                del e_runner, e_step
+            except Exception as e:
+                model.text_model.rollout_fp8 = False
+                secondary["rollout_fp8"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if not args.no_shared_policy:
             # transparency leg: the same step with the policy pass over every row's FULL prompt (what the reference executes;
             # independent LoRA-dropout masks per copy) — the headline shares the prompt rows of a group in that pass

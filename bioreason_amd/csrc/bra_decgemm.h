@@ -16,6 +16,8 @@ struct DecGemm2Args {
     float* ss_out; int nss_out;         // partial sums of squares of the bf16 outputs, [8 | 16][nss_out], column = workgroup
     int M, N, K;
     int packed;                         // W is in fragment order (bra_dec_pack_weights): [tile][k-step][lane][8]
+    const float* wscale;                // non-null: W is the fp8 e4m3 image of bra_dec_pack_weights_fp8 ([tile][k-step pair][lane][8 + 8 bytes]),
+                                        // wscale[n] the fp32 scale of weight row n
     BRA_DBG_FIELD(unsigned long long* probe;)   // BRA_DEBUG only: timing probe (tools/dec_overhead_probe.py), 8 stamps per probed workgroup
     float inv_K;                        // 1 / K rounded on the host (NORM == 2: mean of squares = fma(sum, inv_K, eps))
 };

@@ -297,6 +297,60 @@ __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfi
 #endif
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+// ---- fp8 (OCP e4m3fn: 1-4-3, bias 7, max 448, no infinities) — the rollout's optional weight format (BASELINE config 5) -------
+// Every e4m3 value is exactly representable in bf16, so the decode is exact; the encode (bra_dec_pack_weights_fp8, offline) is
+// round-to-nearest-even with saturation, in integer arithmetic so that the emulator and the device produce the same bytes.
+__host__ __device__ inline float e4m3_to_f32(unsigned b) {
+    const unsigned e = (b >> 3) & 15u, m = b & 7u;
+    float v;
+    if (e == 0) v = (float)m * (1.0f / 512.0f);                           // subnormal: m / 8 * 2^-6
+    else { unsigned bits = ((e + 120u) << 23) | (m << 20); v = __builtin_bit_cast(float, bits); }      // 2^(e-7) * (1 + m/8)
+    if (e == 15 && m == 7) v = __builtin_nanf("");
+    return (b & 0x80u) ? -v : v;
+}
+__host__ __device__ inline unsigned f32_to_e4m3(float f) {
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    const unsigned sign = (u >> 24) & 0x80u;
+    const unsigned a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return sign | 0x7fu;                             // NaN
+    if (a >= 0x43e80000u) return sign | 0x7eu;                            // >= 464 = halfway to the next step above 448: saturate
+    if (a < 0x3c800000u) {                                                // < 2^-6: subnormal grid, step 2^-9
+        const float q = __builtin_rintf(__builtin_bit_cast(float, a) * 512.0f);    // exact product, ties to even
+        return sign | (unsigned)q;                                        // q == 8 is 2^-6 = (e 1, m 0) = code 8
+    }
+    unsigned e = (a >> 23) - 120u;                                        // biased by 7
+    unsigned m = (a >> 20) & 7u;
+    const unsigned rem = a & 0xfffffu;
+    if (rem > 0x80000u || (rem == 0x80000u && (m & 1u))) { if (++m == 8u) { m = 0; ++e; } }
+    if (e > 15u || (e == 15u && m == 7u)) return sign | 0x7eu;
+    return sign | (e << 3) | m;
+}
+// 8 fp8 (two dwords) -> 8 bf16 (the A fragment of one 16x16x32 MFMA step)
+#ifdef BRA_EMU
+__device__ inline u32x4 f8x8_to_bf16x8(unsigned lo, unsigned hi) {
+    unsigned r[4];
+    for (int i = 0; i < 4; ++i) {
+        const unsigned w = i < 2 ? lo : hi;
+        const unsigned b0 = (w >> ((i & 1) * 16)) & 0xffu, b1 = (w >> ((i & 1) * 16 + 8)) & 0xffu;
+        r[i] = (__builtin_bit_cast(unsigned, e4m3_to_f32(b0)) >> 16) | (__builtin_bit_cast(unsigned, e4m3_to_f32(b1)) & 0xffff0000u);
+    }
+    u32x4 o = {r[0], r[1], r[2], r[3]};
+    return o;
+}
+#else
+__device__ __forceinline__ u32x4 f8x8_to_bf16x8(unsigned lo, unsigned hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    // v_cvt_scalef32_pk_bf16_fp8 with scale 1: two e4m3 -> two bf16 per instruction (exact)
+    u32x4 o;
+    o.x = __builtin_bit_cast(unsigned, (bf16x2_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false));
+    o.y = __builtin_bit_cast(unsigned, (bf16x2_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true));
+    o.z = __builtin_bit_cast(unsigned, (bf16x2_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false));
+    o.w = __builtin_bit_cast(unsigned, (bf16x2_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true));
+    return o;
+}
+#endif
+
 // returns x but hides its origin from the compiler: address arithmetic built on it cannot be hoisted out of a loop
 // (hipcc otherwise computes every lane-constant address at kernel entry and spills it around the tile loop)
 #ifdef BRA_EMU

@@ -32,7 +32,11 @@ namespace bra {
 #define BRA_DG2_HEAD_PARAMS const bf16_t* h_x, const bf16_t* h_W, const bf16_t* h_res, const float* h_ss_in, int h_ldx, int h_ldres, int h_M, int h_N, \
                             int h_K, int h_nss_in
 #define BRA_DG2_HEAD_ARGS(g) (g).x, (g).W, (g).res, (g).ss_in, (int)(g).ldx, (int)(g).ldres, (g).M, (g).N, (g).K, (g).nss_in
-template <int MODE, int NORM, int ACT, int OUTF32, int NW, int NL, int WIDE = 0, int PK = 0, int FAST = 0>
+// F8 (round 5; FAST only): the packed weights are fp8 e4m3 with one fp32 scale per output row (bra_dec_pack_weights_fp8) — HALF the
+// streamed bytes.  A 16-byte request then carries the lane's fragments of TWO consecutive k-steps (8 + 8 bytes), decoded to bf16 in
+// registers (exact: v_cvt_scalef32_pk_bf16_fp8, 4 instructions per step) in front of the same bf16 MFMAs; the row scale multiplies the
+// K-reduced products next to rstd.  Activations, accumulation and every epilogue are unchanged (W8A16).
+template <int MODE, int NORM, int ACT, int OUTF32, int NW, int NL, int WIDE = 0, int PK = 0, int FAST = 0, int F8 = 0>
 __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(BRA_DG2_HEAD_PARAMS, DecGemm2Args g0) {
     // everything between kernel entry and the first weight / activation request arrives in SGPRs with the wave (kernel-argument
     // preload, -mllvm -amdgpu-kernarg-preload-count: the leading 14 dwords); the rest of the record is fetched from the argument
@@ -42,6 +46,8 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(BRA_DG2_HEAD_PARAMS,
     g.x = h_x; g.W = h_W; g.res = h_res; g.ss_in = h_ss_in; g.ldx = h_ldx; g.ldres = h_ldres; g.M = h_M; g.N = h_N; g.K = h_K; g.nss_in = h_nss_in;
     static_assert(!WIDE || (MODE == 0 && NORM != 1), "wide rows: 16-column tiles, statistics applied in the epilogue");
     static_assert(!FAST || (PK && NORM != 1), "fast form: packed weights, folded norm or none");
+    static_assert(!F8 || (FAST && NL % 2 == 0 && NW != 16 && !WIDE), "fp8 weights: fast form, two k-steps per 16-byte request");
+    constexpr int NLW = F8 ? NL / 2 : NL;                               // 16-byte weight requests per lane and tile
     __shared__ float red[2][NW][64][4];
     constexpr int KS = MODE ? 64 : 32;
     constexpr int NCOL = MODE ? 8 : 16;
@@ -94,7 +100,8 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(BRA_DG2_HEAD_PARAMS,
         if (FAST) xp += (unsigned)(wave * (NL * KS));
         // request order = arrival order (one in-order counter per wave): statistics, activations, norm weights, then
         // the weight tile, so that the normalisation below runs while the weights are still in flight
-        u32x4 w0[NL], w1[NL], x[NL], nv[NL];
+        u32x4 w0[NLW], w1[NLW], x[NL], nv[NL];
+        f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0;                      // F8: scales of the four weight rows behind this lane's products
 #pragma unroll
         for (int u = 0; u < NL; ++u) x[u] = ld16(xp + so[u]);
         if (NORM == 1) {
@@ -103,19 +110,28 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(BRA_DG2_HEAD_PARAMS,
         }
         // packed: lane l's 16 bytes of (tile, step) sit at ((tile * nsteps + step) * 64 + l) * 8 — one contiguous KiB per
         // wave-instruction (full 128-byte lines) instead of 16 row segments of 64 bytes
-        long wo[NL];
+        long wo[NLW];
 #pragma unroll
-        for (int u = 0; u < NL; ++u) wo[u] = FAST ? (long)(u * 512) : (PK ? (long)(st[u] < nsteps ? st[u] : nsteps - 1) * 512 : so[u]);
-        const unsigned wlane = (unsigned)(wave * (NL * 512) + lane * 8);          // FAST: the lane's offset inside every tile
+        for (int u = 0; u < NLW; ++u) wo[u] = FAST ? (long)(u * 512) : (PK ? (long)(st[u] < nsteps ? st[u] : nsteps - 1) * 512 : so[u]);
+        const unsigned wlane = (unsigned)(wave * (NLW * 512) + lane * 8);         // FAST: the lane's offset inside every tile
+        // F8: the row scales of tile t, requested by every wave with the tile's weights (no branch around a load; one KiB line
+        // shared by the workgroup) — lane (fr, fq) holds the products of weight rows (4 fq + r) & (NCOL - 1)
+        auto scale_of = [&](int t) -> f32x4 {
+            return *reinterpret_cast<const f32x4*>(g.wscale + (unsigned)(t * NCOL + ((4 * fq) & (NCOL - 1))));
+        };
         auto tile_base = [&](int t) -> const bf16_t* {
-            if (FAST) return g.W + (long)t * (NW * NL * 512) + wlane;           // scalar base + 32-bit lane offset (+ immediates)
+            if (FAST) return g.W + (long)t * (NW * NLW * 512) + wlane;          // scalar base + 32-bit lane offset (+ immediates)
             if (PK) return g.W + (long)t * nsteps * 512 + lane * 8;
             int rnn = t * NCOL + lrow; rnn = rnn < g.N ? rnn : g.N - 1;
             return g.W + (long)rnn * g.ldw + koff;
         };
         wp = tile_base(tile);
 #pragma unroll
-        for (int u = 0; u < NL; ++u) w0[u] = ld16_nt(wp + wo[u]);
+        for (int u = 0; u < NLW; ++u) w0[u] = ld16_nt(wp + wo[u]);
+        if (F8) {
+            sched_fence();                // the weight requests go out before anything waits for the scale pointer (argument segment)
+            sc0 = scale_of(tile);
+        }
         if (FAST && !ACT && !OUTF32) {            // needed last (epilogue of the first tile), requested last; no branch around the load
             const bf16_t* rp = g.res ? g.res : g.x;
             const unsigned ro = g.res ? dg2_mul24(em, (int)g.ldres) + (unsigned)en : 0u;
@@ -175,15 +191,24 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(BRA_DG2_HEAD_PARAMS,
         // one or two tiles are peeled.
         const int G = (int)gridDim.x;
         const int nmine = (ntiles - tile + G - 1) / G;
-        auto issue = [&](u32x4 (&wn)[NL], int t) {
+        auto issue = [&](u32x4 (&wn)[NLW], f32x4& scn, int t) {
             const bf16_t* wpn = tile_base(t);
 #pragma unroll
-            for (int u = 0; u < NL; ++u) wn[u] = ld16_nt(wpn + wo[u]);
+            for (int u = 0; u < NLW; ++u) wn[u] = ld16_nt(wpn + wo[u]);
+            if (F8) scn = scale_of(t);
         };
-        auto compute = [&](u32x4 (&wc)[NL], int t, int it) {
+        auto compute = [&](u32x4 (&wc)[NLW], const f32x4& scc, int t, int it) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (F8 != 0) {
 #pragma unroll
-            for (int u = 0; u < NL; ++u) acc = mfma_16x16x32(wc[u], x[u], acc);
+                for (int u = 0; u < NLW; ++u) {
+                    acc = mfma_16x16x32(f8x8_to_bf16x8(wc[u].x, wc[u].y), x[2 * u], acc);
+                    acc = mfma_16x16x32(f8x8_to_bf16x8(wc[u].z, wc[u].w), x[2 * u + 1], acc);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NL; ++u) acc = mfma_16x16x32(wc[u], x[u], acc);
+            }
             if (NORM == 2 && it == 0 && wave == 0) fold_stats();
             float (*slab)[64][4] = red[it & 1];
 #pragma unroll
@@ -200,24 +225,28 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm2_kernel(BRA_DG2_HEAD_PARAMS,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= rsf;
                 }
+                if (F8) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= scc[r];
+                }
                 dg2_epilogue<MODE, ACT, OUTF32, PK>(g, v, t, lane, it == 0, resv);
             }
             if (!FAST && it == 0) dg2_stamp(g, 4);
         };
         if (NW == 16) {                   // 16 waves x 12 chunks: no registers for a second weight set; the host launches one
-            compute(w0, tile, 0);         // workgroup per tile (launch_dg2)
+            compute(w0, sc0, tile, 0);    // workgroup per tile (launch_dg2)
             return;
         }
         int it = 0;
         for (; it + 2 < nmine; it += 2) {
-            issue(w1, tile + (it + 1) * G); compute(w0, tile + it * G, it);
-            issue(w0, tile + (it + 2) * G); compute(w1, tile + (it + 1) * G, it + 1);
+            issue(w1, sc1, tile + (it + 1) * G); compute(w0, sc0, tile + it * G, it);
+            issue(w0, sc0, tile + (it + 2) * G); compute(w1, sc1, tile + (it + 1) * G, it + 1);
         }
         if (nmine - it == 2) {
-            issue(w1, tile + (it + 1) * G); compute(w0, tile + it * G, it);
-            compute(w1, tile + (it + 1) * G, it + 1);
+            issue(w1, sc1, tile + (it + 1) * G); compute(w0, sc0, tile + it * G, it);
+            compute(w1, sc1, tile + (it + 1) * G, it + 1);
         } else {
-            compute(w0, tile + it * G, it);
+            compute(w0, sc0, tile + it * G, it);
         }
         return;
     }
@@ -326,17 +355,78 @@ __global__ __launch_bounds__(256) void dec_pack_kernel(const bf16_t* W, long ldw
     st16(out + c * 8, v);
 }
 
+// fp8 image of a projection (BASELINE config 5: "fp8 weights"): scale[n] = max_k |W[n, k] nw[k]| / 448 (the e4m3
+// maximum; 1 for an all-zero row), q[n, k] = e4m3(W[n, k] nw[k] / scale[n]) rounded to nearest even.  One wave per row.
+__global__ __launch_bounds__(256) void dec_rowscale_fp8_kernel(const bf16_t* W, long ldw, int N, int K, const bf16_t* nw, float* scale) {
+    const int row = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    if (row >= N) return;
+    float mx = 0.f;
+    for (int j = lane; j < K / 8; j += 64) {
+        float f[8], s[8];
+        unpack8(ld16(W + (long)row * ldw + j * 8), f);
+        if (nw) { unpack8(ld16(nw + j * 8), s);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] *= s[i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(f[i]));
+    }
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, wave_shfl_xor(mx, m));
+    if (lane == 0) scale[row] = mx > 0.f ? mx * (1.0f / 448.0f) : 1.0f;
+}
+
+// fragment order of dec_gemm2_kernel<.., F8 = 1>: 16-byte chunk ((tile * nsteps / 2 + s2) * 64 + lane) = the lane's 8 elements of
+// k-step 2 s2 followed by its 8 elements of k-step 2 s2 + 1, one byte each.  One thread per chunk.
+template <int MODE>
+__global__ __launch_bounds__(256) void dec_pack_fp8_kernel(const bf16_t* W, long ldw, int N, int K, const bf16_t* nw, const float* scale,
+                                                           unsigned* out) {
+    constexpr int KS = MODE ? 64 : 32, NCOL = MODE ? 8 : 16;
+    const int npair = K / KS / 2;
+    const long nchunk = (long)(N / NCOL) * npair * 64;
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunk) return;
+    const int lane = (int)(c & 63);
+    const long ts = c >> 6;
+    const int s2 = (int)(ts % npair), tile = (int)(ts / npair);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int row = tile * NCOL + (MODE ? (fr & 7) : fr);
+    const float inv = 1.0f / scale[row];
+    unsigned o[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = (2 * s2 + h) * KS + (MODE ? ((fr >> 3) * 32 + fq * 8) : fq * 8);
+        float f[8];
+        unpack8(ld16(W + (long)row * ldw + col), f);
+        if (nw) { float s[8]; unpack8(ld16(nw + col), s);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] *= s[i]; }
+        unsigned b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = f32_to_e4m3(f[i] * inv);
+        o[2 * h] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        o[2 * h + 1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+    }
+    u32x4 v = {o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<u32x4*>(out + c * 4) = v;
+}
+
+// waves per workgroup and 16-byte chunks per lane of a projection with `nsteps` k-steps (one rule for the launcher and for the fp8
+// packer, which must refuse what the fp8 kernel cannot stream)
+static void dg2_waves_and_chunks(int nsteps, bool wide, int& nw, int& nl) {
+    nw = (wide && nsteps >= 128) ? 16 : (nsteps >= 64 ? 8 : 4);
+    const int spw = (nsteps + nw - 1) / nw;
+    // (10: K = 2560, Qwen3-4B's hidden size — instantiated for the 8-wave form only; 4- and 16-wave shapes with ten steps per wave
+    //  take nl = 8 in the generic multi-round loop, as before that form existed)
+    nl = (spw >= 12 && spw % 12 == 0) ? 12 : ((spw == 10 && nw == 8) ? 10 : (spw > 4 ? 8 : 4));
+}
+
 template <int MODE, int NORM, int ACT, int OUTF32, int WIDE = 0>
 static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     constexpr int KS = MODE ? 64 : 32;
     const int nsteps = g.K / KS;
     // (wide rows stream K = 6144 of down_proj in 32-deep steps — the 8-row form takes it in 64-deep diagonal steps — so that
     //  projection runs 16 waves to keep the single register round)
-    const int nw = (WIDE && nsteps >= 128) ? 16 : (nsteps >= 64 ? 8 : 4);
-    const int spw = (nsteps + nw - 1) / nw;
-    // (10: K = 2560, Qwen3-4B's hidden size — instantiated for the 8-wave form only; 4- and 16-wave shapes with ten steps per wave
-    //  take nl = 8 in the generic multi-round loop, as before that form existed)
-    const int nl = (spw >= 12 && spw % 12 == 0) ? 12 : ((spw == 10 && nw == 8) ? 10 : (spw > 4 ? 8 : 4));
+    int nw, nl;
+    dg2_waves_and_chunks(nsteps, WIDE != 0, nw, nl);
     if (NORM == 2 && (nsteps + nw * nl - 1) / (nw * nl) != 1) return BRA_ERR_UNSUPPORTED;     // folded norm: single-round path only
     const int ntiles = MODE ? g.N / 8 : (g.N + 15) / 16;
     // one workgroup of 8 waves (two of 4) per CU, looping over the tiles; the 16-wave form takes one tile per workgroup
@@ -356,6 +446,14 @@ static int launch_dg2(const DecGemm2Args& g, bra_stream_t st) {
     (void)fast;
 #define BRA_DG2(NW_, NL_)                                                                                                      \
     do {                                                                                                                       \
+        if constexpr (NORM != 1 && !WIDE && NW_ != 16 && NL_ % 2 == 0) {                                                       \
+            if (g.wscale) {                                                                                                    \
+                if (!fast) return BRA_ERR_UNSUPPORTED;                                                                         \
+                BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 1, 1, 1>), grid, dim3(NW_ * 64), 0, st, BRA_DG2_HEAD_ARGS(g), g); \
+                break;                                                                                                         \
+            }                                                                                                                  \
+        }                                                                                                                      \
+        if (g.wscale) return BRA_ERR_UNSUPPORTED;                                                                              \
         if constexpr (NORM != 1) {                                                                                             \
             if (fast) {                                                                                                        \
                 BRA_LAUNCH((dec_gemm2_kernel<MODE, NORM, ACT, OUTF32, NW_, NL_, WIDE, 1, 1>), grid, dim3(NW_ * 64), 0, st, BRA_DG2_HEAD_ARGS(g), g); \
@@ -380,7 +478,8 @@ using namespace bra;
 
 static int dec_gemm2_any(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
                         const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
-                        int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* probe, void* stream);
+                        int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* probe, void* stream,
+                        const float* wscale = nullptr);
 
 extern "C" int bra_dec_gemm2(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
                              const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
@@ -396,6 +495,18 @@ extern "C" int bra_dec_gemm2_packed(const void* x, long ldx, const float* ss_in,
                          packed, nullptr, stream);
 }
 
+// fp8 (e4m3) weights with one fp32 scale per output row (bra_dec_pack_weights_fp8): y = rstd * scale[n] * (x Wq^T) ... — the same
+// epilogues as bra_dec_gemm2_packed.  `norm_folded` != 0: ss_in / nss_in carry the statistics of x and the norm weight was folded
+// into Wq before quantisation.  BRA_ERR_UNSUPPORTED outside the single-register-round shapes (the caller keeps bf16 weights there).
+extern "C" int bra_dec_gemm2_fp8(const void* x, long ldx, const float* ss_in, int nss_in, float eps, const void* Wq, const float* wscale,
+                                 const void* res, long ldres, void* out, long ldo, float* ss_out, int nss_out, int M, int N, int K,
+                                 int act, int out_f32, int norm_folded, void* stream) {
+    if (!Wq || !wscale) return BRA_ERR_ARG;
+    // (norm_w only selects the folded-norm form here: its values are never read when the weights carry it)
+    return dec_gemm2_any(x, ldx, norm_folded ? ss_in : nullptr, norm_folded ? nss_in : 0, norm_folded ? Wq : nullptr, eps, Wq, K, res, ldres,
+                         out, ldo, ss_out, nss_out, M, N, K, act, out_f32, norm_folded ? 3 : 1, nullptr, stream, wscale);
+}
+
 #ifdef BRA_DEBUG
 extern "C" int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
                                    const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
@@ -407,8 +518,10 @@ extern "C" int bra_dec_gemm2_probe(const void* x, long ldx, const float* ss_in, 
 
 static int dec_gemm2_any(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps,
                         const void* W, long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out,
-                        int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* probe, void* stream) {
+                        int nss_out, int M, int N, int K, int act, int out_f32, int packed, void* probe, void* stream,
+                        const float* wscale) {
     (void)probe;
+    if (wscale && (M > 8 || !(packed & 1) || (norm_w && !(packed & 2)))) return BRA_ERR_UNSUPPORTED;   // fp8 weights: <= 8 rows, packed, norm folded or absent
     if (M <= 0 || M > 16 || N <= 0 || K <= 0 || K % 32 || ldx % 8 || ldw % 8 || !x || !W || !out) return BRA_ERR_ARG;
     if (act && (N % 16 || out_f32 || res || ss_out)) return BRA_ERR_ARG;
     if (out_f32 && res) return BRA_ERR_ARG;            // (out_f32 with ss_out: per-tile maxima of the logits, 16-column tiles)
@@ -420,7 +533,7 @@ static int dec_gemm2_any(const void* x, long ldx, const float* ss_in, int nss_in
     const bool diag = !wide && !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256 && N / 8 <= 256;
     if (ss_out && nss_out < (diag ? N / 8 : (N + 15) / 16)) return BRA_ERR_ARG;
     DecGemm2Args g = {(const bf16_t*)x, ldx, ss_in, nss_in, (const bf16_t*)norm_w, eps, (const bf16_t*)W, ldw,
-                      (const bf16_t*)res, ldres, out, ldo, ss_out, nss_out, M, N, K, packed, BRA_DBG_INIT((unsigned long long*)probe) 1.f / (float)K};
+                      (const bf16_t*)res, ldres, out, ldo, ss_out, nss_out, M, N, K, packed, wscale, BRA_DBG_INIT((unsigned long long*)probe) 1.f / (float)K};
     if (packed && (N % (diag ? 8 : 16) || K % (diag ? 64 : 32))) return BRA_ERR_ARG;
     bra_stream_t st = (bra_stream_t)stream;
     if ((packed & 2) && !(packed & 1)) return BRA_ERR_ARG;
@@ -468,6 +581,31 @@ extern "C" int bra_dec_pack_weights_rows(const void* W, long ldw, int N, int K, 
     const dim3 grid((unsigned)((nchunk + 255) / 256));
     if (diag) BRA_LAUNCH((dec_pack_kernel<1>), grid, dim3(256), 0, (bra_stream_t)stream, (const bf16_t*)W, ldw, N, K, (const bf16_t*)norm_w, (bf16_t*)out);
     else BRA_LAUNCH((dec_pack_kernel<0>), grid, dim3(256), 0, (bra_stream_t)stream, (const bf16_t*)W, ldw, N, K, (const bf16_t*)norm_w, (bf16_t*)out);
+    return BRA_LAUNCH_STATUS();
+}
+
+// W [N, K] bf16 (optionally with the input's RMSNorm weight folded in) -> fp8 e4m3 image in bra_dec_gemm2_fp8's fragment order
+// (out_q: N * K bytes) + one fp32 scale per row (out_scale: N floats).  Same tile rule as bra_dec_pack_weights for <= 8 batch rows;
+// BRA_ERR_UNSUPPORTED when the shape is not a whole number of tiles and k-step pairs.
+extern "C" int bra_dec_pack_weights_fp8(const void* W, long ldw, int N, int K, int act, int out_f32, const void* norm_w, void* out_q,
+                                        float* out_scale, void* stream) {
+    if (!W || !out_q || !out_scale || N <= 0 || K <= 0 || ldw % 8) return BRA_ERR_ARG;
+    const bool diag = !act && !out_f32 && N % 8 == 0 && K % 64 == 0 && (N + 15) / 16 < 256 && N / 8 <= 256;      // bra_dec_gemm2's rule
+    if (N % (diag ? 8 : 16) || K % (diag ? 128 : 64)) return BRA_ERR_UNSUPPORTED;
+    {   // only what bra_dec_gemm2_fp8 streams: K exactly one register round of the (waves, chunks) the launcher picks
+        int nw, nl;
+        const int nsteps = K / (diag ? 64 : 32);
+        dg2_waves_and_chunks(nsteps, false, nw, nl);
+        if (nsteps != nw * nl || nl % 2 || nw == 16) return BRA_ERR_UNSUPPORTED;
+    }
+    bra_stream_t st = (bra_stream_t)stream;
+    BRA_LAUNCH(dec_rowscale_fp8_kernel, dim3((N + 3) / 4), dim3(256), 0, st, (const bf16_t*)W, ldw, N, K, (const bf16_t*)norm_w, out_scale);
+    int rc = BRA_LAUNCH_STATUS();
+    if (rc) return rc;
+    const long nchunk = (long)N * K / 16;
+    const dim3 grid((unsigned)((nchunk + 255) / 256));
+    if (diag) BRA_LAUNCH((dec_pack_fp8_kernel<1>), grid, dim3(256), 0, st, (const bf16_t*)W, ldw, N, K, (const bf16_t*)norm_w, out_scale, (unsigned*)out_q);
+    else BRA_LAUNCH((dec_pack_fp8_kernel<0>), grid, dim3(256), 0, st, (const bf16_t*)W, ldw, N, K, (const bf16_t*)norm_w, out_scale, (unsigned*)out_q);
     return BRA_LAUNCH_STATUS();
 }
 

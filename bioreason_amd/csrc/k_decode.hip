@@ -24,6 +24,9 @@ struct Layer {
     const void* head_packed;                                           // record 0 only: fragment-packed lm_head matrix, or null
     const float* rope_rows;                                            // record 0 only: [B, hd] cos | sin rows of the current positions, or null
     float* head_tmax;                                                  // record 0 only: [B, ceil(V / 16)] maxima of the logits' 16-column tiles (sampler), or null
+    // fp8 rollout weights (bra_dec_pack_weights_fp8; flags bit 3: Wqkv / Wo / Wgu / Wd are e4m3 images, bit 4 (record 0): head_packed is):
+    // one fp32 scale per output row of each projection
+    const float *sc_qkv, *sc_o, *sc_gu, *sc_d, *sc_head;
 };
 
 }  // namespace
@@ -92,6 +95,8 @@ static int sg_begin(const StepGemms& s, const void* x) {
 }
 static int sg_qkv(const StepGemms& s, const Layer& l, const void* x, void* qkv) {
     const int pk = l.flags & 3;
+    if (s.v2 && (l.flags & 8))
+        return bra_dec_gemm2_fp8(x, s.H, s.ssx, s.nss, s.eps, l.Wqkv, l.sc_qkv, nullptr, 0, qkv, s.Nqkv, nullptr, 0, s.B, s.Nqkv, s.H, 0, 0, 1, s.stream);
     if (s.v2) return bra_dec_gemm2_packed(x, s.H, s.ssx, s.nss, l.ln1, s.eps, l.Wqkv, s.H, nullptr, 0, qkv, s.Nqkv, nullptr, 0, s.B, s.Nqkv, s.H, 0, 0, pk, s.stream);
     if (pk) return BRA_ERR_UNSUPPORTED;
     return bra_dec_gemm(x, s.H, l.ln1, s.eps, l.Wqkv, s.H, nullptr, 0, qkv, s.Nqkv, s.B, s.Nqkv, s.H, 0, 0, s.stream);
@@ -100,6 +105,11 @@ static int sg_qkv(const StepGemms& s, const Layer& l, const void* x, void* qkv) 
 static int sg_tail(const StepGemms& s, const Layer& l, const void* o, void* x, void* h, void* act) {
     int rc;
     const int pk = l.flags & 1;
+    if (s.v2 && (l.flags & 8)) {
+        if ((rc = bra_dec_gemm2_fp8(o, s.Nq, nullptr, 0, 0.f, l.Wo, l.sc_o, x, s.H, h, s.H, s.ssh, s.nss, s.B, s.H, s.Nq, 0, 0, 0, s.stream))) return rc;
+        if ((rc = bra_dec_gemm2_fp8(h, s.H, s.ssh, s.nss, s.eps, l.Wgu, l.sc_gu, nullptr, 0, act, s.F, nullptr, 0, s.B, 2 * s.F, s.H, 1, 0, 1, s.stream))) return rc;
+        return bra_dec_gemm2_fp8(act, s.F, nullptr, 0, 0.f, l.Wd, l.sc_d, h, s.H, x, s.H, s.ssx, s.nss, s.B, s.H, s.F, 0, 0, 0, s.stream);
+    }
     if (s.v2) {
         if ((rc = bra_dec_gemm2_packed(o, s.Nq, nullptr, 0, nullptr, 0.f, l.Wo, s.Nq, x, s.H, h, s.H, s.ssh, s.nss, s.B, s.H, s.Nq, 0, 0, pk, s.stream))) return rc;
         if ((rc = bra_dec_gemm2_packed(h, s.H, s.ssh, s.nss, l.ln2, s.eps, l.Wgu, s.H, nullptr, 0, act, s.F, nullptr, 0, s.B, 2 * s.F, s.H, 1, 0, l.flags & 3, s.stream))) return rc;
@@ -113,8 +123,10 @@ static int sg_tail(const StepGemms& s, const Layer& l, const void* o, void* x, v
 // `tmax` (optional, [B, ceil(V / 16)]): the projection's epilogue also leaves the maximum of every 16-column tile of the logits
 // (bra_sample_tiles); the first-generation kernel has no such epilogue — bra_tile_max then computes them in a launch of its own
 static int sg_head(const StepGemms& s, const void* x, const void* norm_w, const void* E, const void* Epacked, int folded, float* logits,
-                   float* tmax) {
+                   float* tmax, const float* sc_head = nullptr) {
     const int nt = (s.V + 15) / 16;
+    if (s.v2 && Epacked && sc_head)      // fp8 lm_head image (final norm folded)
+        return bra_dec_gemm2_fp8(x, s.H, s.ssx, s.nss, s.eps, Epacked, sc_head, nullptr, 0, logits, s.V, tmax, tmax ? nt : 0, s.B, s.V, s.H, 0, 1, 1, s.stream);
     if (s.v2 && Epacked)
         return bra_dec_gemm2_packed(x, s.H, s.ssx, s.nss, norm_w, s.eps, Epacked, s.H, nullptr, 0, logits, s.V, tmax, tmax ? nt : 0, s.B, s.V, s.H, 0, 1, folded ? 3 : 1, s.stream);
     if (s.v2) return bra_dec_gemm2(x, s.H, s.ssx, s.nss, norm_w, s.eps, E, s.H, nullptr, 0, logits, s.V, tmax, tmax ? nt : 0, s.B, s.V, s.H, 0, 1, s.stream);
@@ -150,7 +162,7 @@ extern "C" int bra_qwen_decode_step_fused(const void* layers_host, int L, int B,
         CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, nchunk, len_dev, 0, stream));
         CK(sg_tail(sg, l, o, x, h, act));
     }
-    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits, L > 0 ? ls[0].head_tmax : nullptr));
+    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits, L > 0 ? ls[0].head_tmax : nullptr, (L > 0 && (ls[0].flags & 16)) ? ls[0].sc_head : nullptr));
 #undef CK
     return 0;
 }
@@ -186,7 +198,7 @@ extern "C" int bra_qwen_decode_step_shared(const void* layers_host, int L, int R
         CK(bra_attn_decode_merge(part_o, part_ml, o, B, Hq, hd, ntot, t_dev, npc, stream));
         CK(sg_tail(sg, l, o, x, h, act));
     }
-    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits, L > 0 ? ls[0].head_tmax : nullptr));
+    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits, L > 0 ? ls[0].head_tmax : nullptr, (L > 0 && (ls[0].flags & 16)) ? ls[0].sc_head : nullptr));
 #undef CK
     return 0;
 }
@@ -217,7 +229,7 @@ extern "C" int bra_qwen_decode_step_one(const void* layers_host, int L, int R, i
                             part_o, part_ml, nslot, o, Nq, R, copies, Hq, Hkv, hd, P, C, t, eps, scale, t_dev, stream));
         CK(sg_tail(sg, l, o, x, h, act));
     }
-    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits, L > 0 ? ls[0].head_tmax : nullptr));
+    if (logits) CK(sg_head(sg, x, norm_w, E, L > 0 ? ls[0].head_packed : nullptr, L > 0 ? (ls[0].flags & 4) : 0, logits, L > 0 ? ls[0].head_tmax : nullptr, (L > 0 && (ls[0].flags & 16)) ? ls[0].sc_head : nullptr));
 #undef CK
     return 0;
 }
@@ -276,7 +288,7 @@ extern "C" int bra_qwen_decode_step_persist(const void* layers_host, const void*
     CK(bra_qwen_layers_persist(layers_dev, L, R, copies, H, Hq, Hkv, hd, F, P, vt_pitch, C, cp, eps, scale, cosT, sinT, pos,
                                ls[0].rope_rows, pmask, t, t_dev, x, qkv, o, h, act, ss_ws, nss, part_o, part_ml, nslot, sync,
                                prefetch, stop_after, timeout_us, stream));
-    if (logits) CK(sg_head(sg, x, norm_w, E, ls[0].head_packed, ls[0].flags & 4, logits, ls[0].head_tmax));
+    if (logits) CK(sg_head(sg, x, norm_w, E, ls[0].head_packed, ls[0].flags & 4, logits, ls[0].head_tmax, (ls[0].flags & 16) ? ls[0].sc_head : nullptr));
 #undef CK
     return 0;
 }

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(512) void decode_persist_kernel(PersistArgs a) {
             it0.kind = 0;
             if (BRA_PRUN()) {
             BRA_PIDS();
-            DecGemm2Args g = {a.x, H, a.ssx, a.nss, nullptr, a.eps, Lr.Wqkv, H, nullptr, 0, (void*)at.qkv, NQKV, nullptr, 0, M, NQKV, H, 3, nullptr, 1.f / (float)H};
+            DecGemm2Args g = {a.x, H, a.ssx, a.nss, nullptr, a.eps, Lr.Wqkv, H, nullptr, 0, (void*)at.qkv, NQKV, nullptr, 0, M, NQKV, H, 3, nullptr, nullptr, 1.f / (float)H};
             if (PF >= 2) {                  // the wave's attention item: its K / V^T chunk does not depend on the new token
                 const int iw = wg + NWG * wave;
                 if (iw < nitems) dec_item_decode<HD, G>(at, iw, t, it0);
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(512) void decode_persist_kernel(PersistArgs a) {
             if (BRA_PRUN()) {
             BRA_PIDS();
             BRA_PSTAMP(0);
-            DecGemm2Args g = {at.o, NQ, nullptr, 0, nullptr, 0.f, Lr.Wo, NQ, a.x, H, (void*)a.h, H, a.ssh, a.nss, M, H, NQ, 1, nullptr, 1.f / (float)NQ};
+            DecGemm2Args g = {at.o, NQ, nullptr, 0, nullptr, 0.f, Lr.Wo, NQ, a.x, H, (void*)a.h, H, a.ssh, a.nss, M, H, NQ, 1, nullptr, nullptr, 1.f / (float)NQ};
             if (!PF) pw_issue<NW_O, NL_O>(wo, Lr.Wo, wg, wave, lane_id());
             Frag<NL_O> xf;
             px_load<1, NW_O, NL_O>(xf, at.o, NQ, M, wave, lane_id());
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(512) void decode_persist_kernel(PersistArgs a) {
             if (BRA_PRUN()) {
             BRA_PIDS();
             BRA_PSTAMP(0);
-            DecGemm2Args g = {a.h, H, a.ssh, a.nss, nullptr, a.eps, Lr.Wgu, H, nullptr, 0, (void*)a.act, F, nullptr, 0, M, 2 * F, H, 3, nullptr, 1.f / (float)H};
+            DecGemm2Args g = {a.h, H, a.ssh, a.nss, nullptr, a.eps, Lr.Wgu, H, nullptr, 0, (void*)a.act, F, nullptr, 0, M, 2 * F, H, 3, nullptr, nullptr, 1.f / (float)H};
             if (!PF) {
                 pw_issue<8, NL_QKV>(wg0, Lr.Wgu, wg, wave, lane_id());
                 pw_issue<8, NL_QKV>(wg1, Lr.Wgu, wg + NWG, wave, lane_id());
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(512) void decode_persist_kernel(PersistArgs a) {
             if (BRA_PRUN()) {
             BRA_PIDS();
             BRA_PSTAMP(0);
-            DecGemm2Args g = {a.act, F, nullptr, 0, nullptr, 0.f, Lr.Wd, F, a.h, H, (void*)a.x, H, a.ssx, a.nss, M, H, F, 1, nullptr, 1.f / (float)F};
+            DecGemm2Args g = {a.act, F, nullptr, 0, nullptr, 0.f, Lr.Wd, F, a.h, H, (void*)a.x, H, a.ssx, a.nss, M, H, F, 1, nullptr, nullptr, 1.f / (float)F};
             if (!PF) pw_issue<8, NL_D>(wd, Lr.Wd, wg, wave, lane_id());
             Frag<NL_D> xf;
             px_load<1, 8, NL_D>(xf, a.act, F, M, wave, lane_id());

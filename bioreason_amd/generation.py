@@ -100,7 +100,8 @@ class _LayerDesc(ctypes.Structure):
                 + [(n, ctypes.c_float) for n in ("s_qkv", "s_o", "s_gu", "s_d")]
                 + [("kc", ctypes.c_void_p), ("vc", ctypes.c_void_p), ("kp", ctypes.c_void_p), ("vtp", ctypes.c_void_p)]
                 + [("flags", ctypes.c_int), ("pad_", ctypes.c_int), ("head_packed", ctypes.c_void_p), ("rope_rows", ctypes.c_void_p),
-                   ("head_tmax", ctypes.c_void_p)])
+                   ("head_tmax", ctypes.c_void_p)]
+                + [(n, ctypes.c_void_p) for n in ("sc_qkv", "sc_o", "sc_gu", "sc_d", "sc_head")])
 
 
 def _layer_table(n: int):
@@ -161,7 +162,8 @@ def rollout_weights(model, rows: int = 8):
     pack = os.environ.get("BRA_DEC_PACK", "1") == "1"
     fold = pack and os.environ.get("BRA_DEC_FOLD", "1") == "1"
     wide = rows > 8             # 9 .. 16 sequences: every projection is packed for 16-column tiles (ops.dec_pack_weights(rows=16))
-    key = (model._packed_sig, model._lora_enabled, pack, fold, wide, None if arena is None or arena.params is None else (arena.step_count, arena.params._version))
+    fp8 = rollout_fp8_enabled(model) and pack and fold and not wide
+    key = (model._packed_sig, model._lora_enabled, pack, fold, wide, fp8, None if arena is None or arena.params is None else (arena.step_count, arena.params._version))
     cached = getattr(eng, "_rollout", None)
     if cached is not None and cached[0] == key:
         return cached[1]
@@ -182,6 +184,18 @@ def rollout_weights(model, rows: int = 8):
             # (and, `fold`, the RMSNorm weight of the projection's input multiplied in: the kernel then applies rstd to the reduced
             # products and loads no norm weights / statistics ahead of its MFMAs)
             nws = {"Wqkv": L.ln1 if fold else None, "Wgu": L.ln2 if fold else None, "Wo": None, "Wd": None}
+            if fp8:
+                # opt-in fp8 rollout weights (BASELINE config 5): e4m3 + one fp32 scale per output row of the MERGED, norm-folded weight;
+                # a layer whose shapes the fp8 kernel does not take keeps bf16 (all four projections together)
+                q8 = {nm: ops.dec_pack_weights_fp8(rec[nm], act=(nm == "Wgu"), norm_w=nws[nm]) for nm in ("Wqkv", "Wo", "Wgu", "Wd")}
+                if all(v is not None for v in q8.values()):
+                    for nm, (q, sc) in q8.items():
+                        rec[nm + "_q"], rec[nm + "_s"] = q, sc
+                    rec["fp8"], rec["folded"] = True, True
+                    for nm in ("Wqkv", "Wo", "Wgu", "Wd"):
+                        rec[nm + "_p"] = rec[nm + "_q"]            # (one pointer set for `_packed_ok` / the descriptor table)
+                    out.append(rec)
+                    continue
             pk = {nm: ops.dec_pack_weights(rec[nm], act=(nm == "Wgu"), norm_w=nws[nm], rows=16 if wide else 8)
                   for nm in ("Wqkv", "Wo", "Wgu", "Wd")}
             if all(v is not None for v in pk.values()):
@@ -190,6 +204,22 @@ def rollout_weights(model, rows: int = 8):
         out.append(rec)
     eng._rollout = (key, out)
     return out
+
+
+def rollout_fp8_enabled(model) -> bool:
+    """fp8 (e4m3) weights in the token loop: `model.rollout_fp8 = True` (GRPOConfig.rollout_fp8, bench --rollout-fp8) or BRA_ROLLOUT_FP8=1.
+    Never the default: the bf16 rollout is the parity-tested reference path."""
+    return bool(getattr(model, "rollout_fp8", False)) or os.environ.get("BRA_ROLLOUT_FP8") == "1"
+
+
+def packed_head_fp8(model):
+    """fp8 image of the tied lm_head with the final RMSNorm weight folded in -> (q, scale) or None (311 MB instead of 622 at Qwen3-1.7B)"""
+    eng: QwenEngine = model.ensure_packed()
+    key = (eng.E.data_ptr(), eng.E._version, tuple(eng.E.shape), eng.norm_w.data_ptr(), eng.norm_w._version)
+    cached = getattr(eng, "_head_fp8", None)
+    if cached is None or cached[0] != key:
+        eng._head_fp8 = (key, ops.dec_pack_weights_fp8(eng.E, out_f32=True, norm_w=eng.norm_w))
+    return eng._head_fp8[1]
 
 
 def packed_head(model):
@@ -221,10 +251,16 @@ class FusedDecodeState:
             _set_proj(d, R, use_packed)
             d.kc, d.vc = cache.k[i].data_ptr(), cache.v[i].data_ptr()
         if use_packed and (B > 8 or os.environ.get("BRA_DEC_PACK_HEAD", "1") == "1"):      # (above 8 rows only the packed head streams)
-            self.head_p, head_folded = packed_head(model)
-            if self.head_p is not None:
-                arr[0].head_packed = self.head_p.data_ptr()
-                arr[0].flags |= 4 if head_folded else 0
+            h8 = packed_head_fp8(model) if (B <= 8 and all(R_.get("fp8") for R_ in self.rw)) else None
+            if h8 is not None:
+                self.head_p, self.head_s = h8
+                arr[0].head_packed, arr[0].sc_head = self.head_p.data_ptr(), self.head_s.data_ptr()
+                arr[0].flags |= 4 | 16
+            else:
+                self.head_p, head_folded = packed_head(model)
+                if self.head_p is not None:
+                    arr[0].head_packed = self.head_p.data_ptr()
+                    arr[0].flags |= 4 if head_folded else 0
         self.arr = arr
 
         def buf(n):
@@ -292,10 +328,16 @@ class SharedDecodeState:
             d.kc, d.vc = self.kc[i].data_ptr(), self.vc[i].data_ptr()
             d.kp, d.vtp = self.kp[i].data_ptr(), self.vtp[i].data_ptr()
         if use_packed and (B > 8 or os.environ.get("BRA_DEC_PACK_HEAD", "1") == "1"):
-            self.head_p, head_folded = packed_head(model)
-            if self.head_p is not None:
-                arr[0].head_packed = self.head_p.data_ptr()
-                arr[0].flags |= 4 if head_folded else 0
+            h8 = packed_head_fp8(model) if (B <= 8 and all(R_.get("fp8") for R_ in self.rw)) else None
+            if h8 is not None:
+                self.head_p, self.head_s = h8
+                arr[0].head_packed, arr[0].sc_head = self.head_p.data_ptr(), self.head_s.data_ptr()
+                arr[0].flags |= 4 | 16
+            else:
+                self.head_p, head_folded = packed_head(model)
+                if self.head_p is not None:
+                    arr[0].head_packed = self.head_p.data_ptr()
+                    arr[0].flags |= 4 if head_folded else 0
         # (cos | sin) rows of every sequence's current position, refreshed once per token by bra_advance_counters
         self.rope_rows = torch.zeros((B, eng.hd), dtype=torch.float32, device=dev) if os.environ.get("BRA_DEC_ROPE_ROWS", "1") == "1" else None
         if self.rope_rows is not None:
@@ -320,7 +362,7 @@ class SharedDecodeState:
         if mode != "0" and not getattr(get_lib(), "debug", False):
             raise RuntimeError("BRA_DEC_PERSIST needs the debug library (the persistent decode step is not part of the product ABI): "
                                "call bioreason_amd._lib.use_debug_library() first (`make -C bioreason_amd/csrc debug`)")
-        if mode != "0" and self.attn_impl == "one" and use_packed and B <= 8 and all(Rw.get("folded") for Rw in self.rw) and dev.type == "cuda":
+        if mode != "0" and self.attn_impl == "one" and use_packed and B <= 8 and all(Rw.get("folded") and not Rw.get("fp8") for Rw in self.rw) and dev.type == "cuda":
             tab = torch.tensor([[Rw["Wqkv_p"].data_ptr(), Rw["Wo_p"].data_ptr(), Rw["Wgu_p"].data_ptr(), Rw["Wd_p"].data_ptr(),
                                  L.qn.data_ptr(), L.kn.data_ptr(), self.kp[i].data_ptr(), self.vtp[i].data_ptr(),
                                  self.kc[i].data_ptr(), self.vc[i].data_ptr()] for i, (L, Rw) in enumerate(zip(eng.layers, self.rw))],
@@ -361,6 +403,9 @@ def _set_proj(d, R, use_packed: bool):
     d.Wqkv, d.Wo, d.Wgu, d.Wd = (R["Wqkv" + sfx].data_ptr(), R["Wo" + sfx].data_ptr(), R["Wgu" + sfx].data_ptr(),
                                   R["Wd" + sfx].data_ptr())
     d.flags = (1 | (2 if R.get("folded") else 0)) if use_packed else 0
+    if use_packed and R.get("fp8"):                   # e4m3 images + row scales (bra_dec_gemm2_fp8)
+        d.flags |= 8
+        d.sc_qkv, d.sc_o, d.sc_gu, d.sc_d = R["Wqkv_s"].data_ptr(), R["Wo_s"].data_ptr(), R["Wgu_s"].data_ptr(), R["Wd_s"].data_ptr()
 
 
 def _packed_ok(B: int, rw) -> bool:

@@ -103,6 +103,9 @@ class DNALLMGRPOConfig(TrainingArguments):
     # stream for the shared rows: unbiased, lower gradient variance, NOT the reference's sampling scheme), False the
     # full-row pass.
     share_policy_prompt: Optional[bool] = field(default=None)
+    # ---- not in the reference: stream fp8 (e4m3, one scale per output row) images of the merged weights in the rollout's token loop
+    # (BASELINE config 5; bioreason_amd.trainer.GRPOConfig.rollout_fp8)
+    rollout_fp8: bool = field(default=False)
 
 
 def _lora_fields(peft_config) -> Optional[Dict[str, Any]]:
@@ -183,7 +186,8 @@ class DNALLMGRPOTrainer:
                          learning_rate=args.learning_rate, weight_decay=args.weight_decay, adam_beta1=args.adam_beta1,
                          adam_beta2=args.adam_beta2, adam_epsilon=args.adam_epsilon, max_grad_norm=args.max_grad_norm,
                          eos_token_id=self.processing_class.eos_token_id, pad_token_id=pad_token_id,
-                         seed=args.seed, share_policy_prompt=getattr(args, "share_policy_prompt", None))
+                         seed=args.seed, share_policy_prompt=getattr(args, "share_policy_prompt", None),
+                         rollout_fp8=bool(getattr(args, "rollout_fp8", False)))
         self.runner = GRPOStepRunner(model, cfg)
         self.state = SimpleNamespace(global_step=0, epoch=0.0, log_history=self.log_history)
         model.train()                                               # HF Trainer.training_step puts the model in train mode

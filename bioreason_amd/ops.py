@@ -609,6 +609,37 @@ def dec_pack_weights(W: torch.Tensor, act: bool = False, out_f32: bool = False, 
     return out
 
 
+def dec_pack_weights_fp8(W: torch.Tensor, act: bool = False, out_f32: bool = False, norm_w: Optional[torch.Tensor] = None):
+    """W [N, K] bf16 -> (q uint8 [N, K] in bra_dec_gemm2_fp8's fragment order, scale fp32 [N]) — e4m3 with one scale per output row
+    (bra_dec_pack_weights_fp8); None when the shape is not a whole number of tiles / k-step pairs"""
+    N, K = W.shape
+    q = torch.empty((N, K), dtype=torch.uint8, device=W.device)
+    scale = torch.empty((N,), dtype=torch.float32, device=W.device)
+    rc = get_lib().call_rc("bra_dec_pack_weights_fp8", W, _ld(W), N, K, int(act), int(out_f32), norm_w, q, scale, current_stream(W))
+    if rc == -2:
+        return None
+    return q, scale
+
+
+def dec_gemm2_fp8(x, Wq, scale, ss_in=None, eps=1e-6, res=None, act=False, out_f32=False, want_ss=False, tile_max=None):
+    """decode-time projection over fp8 weights (bra_dec_gemm2_fp8): y = [rstd] scale[n] (x q^T) (+res | SwiGLU | fp32);
+    `ss_in` given = the input's RMSNorm weight was folded into the weights; returns (y, ss_out or None); None when unsupported"""
+    M, K = x.shape
+    N = Wq.shape[0]
+    out = torch.empty((M, N // 2 if act else N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    nss_out = (N // 8 + 32) // 32 * 32
+    ss_out = torch.zeros((8, nss_out), dtype=torch.float32, device=x.device) if want_ss else None
+    if tile_max is not None:
+        assert out_f32 and not want_ss
+        ss_out, nss_out, want_ss = tile_max, _ld(tile_max), True
+    rc = get_lib().call_rc("bra_dec_gemm2_fp8", x, _ld(x), ss_in, ss_in.shape[1] if ss_in is not None else 0, eps, Wq, scale,
+                           res, _ld(res) if res is not None else 0, out, _ld(out), ss_out, nss_out if want_ss else 0, M, N, K,
+                           int(act), int(out_f32), int(ss_in is not None), current_stream(x))
+    if rc == -2:
+        return None
+    return out, (None if tile_max is not None else ss_out)
+
+
 def eos_mask(ids32: torch.Tensor, eos_id: int):
     B, C = ids32.shape
     mask = torch.empty((B, C), dtype=torch.int32, device=ids32.device)

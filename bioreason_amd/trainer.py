@@ -60,6 +60,11 @@ class GRPOConfig:
     # copy of each prompt's K/V, number of gradient buckets overlapped with the backward
     rollout_graph: Optional[bool] = None
     rollout_shared_prefix: bool = True
+    # opt-in (BASELINE config 5, "fp8 weights"): the token loop streams e4m3 images of the merged weights, one fp32 scale per output row
+    # (half the bytes; W8A16: bf16 activations, fp32 accumulation).  The rollouts are then sampled from the QUANTISED policy — log-probs,
+    # the reference pass and the gradients stay bf16 — i.e. the behaviour policy differs from the trained one by quantisation noise, as
+    # with any fp8 rollout engine; never on in the bf16 headline.
+    rollout_fp8: bool = False
     grad_buckets: int = 4
     share_dna_encoding: bool = True      # frozen-encoder rows computed once per step and shared by its three passes
     # the policy pass (forward AND backward) may run the prompt of a group of consecutive copies once
@@ -218,6 +223,7 @@ class GRPOStepRunner(_DataParallelStep):
         m, c = self.model, self.cfg
         dev = batch["input_ids"].device
         mm = {"dna_tokenized": batch["dna_tokenized"], "batch_idx_map": batch["batch_idx_map"], "dna_alias": batch.get("dna_alias")}
+        m.text_model.rollout_fp8 = bool(c.rollout_fp8)                 # read by generation.rollout_weights / the decode states
         wside = None
         if (c.overlap_rollout_weights and dev.type == "cuda" and not timing and c.rollout_shared_prefix
                 and batch.get("prompt_alias") is not None):

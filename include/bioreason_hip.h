@@ -207,6 +207,19 @@ int bra_dec_gemm2(const void* x, long ldx, const float* ss_in, int nss_in, const
 int bra_dec_gemm2_packed(const void* x, long ldx, const float* ss_in, int nss_in, const void* norm_w, float eps, const void* W,
                          long ldw, const void* res, long ldres, void* out, long ldo, float* ss_out, int nss_out, int M, int N,
                          int K, int act, int out_f32, int packed, void* stream);
+/* fp8 (OCP e4m3) rollout weights — BASELINE config 5 ("GRPO fp8 weights"), opt-in: half the bytes of the token loop's weight stream.
+ * bra_dec_pack_weights_fp8: W [N, K] bf16 (norm_w [K] optional: the input's RMSNorm weight multiplied in first) -> out_q, N * K bytes
+ * in bra_dec_gemm2_fp8's fragment order, + out_scale [N] fp32, scale[n] = max_k |W[n,k] w[k]| / 448, q = e4m3(W w / scale) rounded to
+ * nearest even.  bra_dec_gemm2_fp8: y = [rstd *] scale[n] * (x q^T) with bra_dec_gemm2_packed's epilogues (residual | SwiGLU | fp32
+ * logits + tile maxima); the fp8 values are decoded to bf16 in registers (exact) in front of the bf16 MFMAs, activations stay bf16,
+ * accumulation fp32 (W8A16: the step is HBM-bound, the fp8 MFMA rate is not what it needs).  M <= 8, single-register-round shapes
+ * (every projection of Qwen3-1.7B); BRA_ERR_UNSUPPORTED otherwise — the caller keeps bf16 weights for that projection.
+ * Replaces the same nn.Linear forwards as bra_dec_gemm2 (TF:qwen3:225-236, :81-83, :495) under weight-only quantisation. */
+int bra_dec_pack_weights_fp8(const void* W, long ldw, int N, int K, int act, int out_f32, const void* norm_w, void* out_q,
+                             float* out_scale, void* stream);
+int bra_dec_gemm2_fp8(const void* x, long ldx, const float* ss_in, int nss_in, float eps, const void* Wq, const float* wscale,
+                      const void* res, long ldres, void* out, long ldo, float* ss_out, int nss_out, int M, int N, int K, int act,
+                      int out_f32, int norm_folded, void* stream);
 /* W [N, K] -> the fragment order bra_dec_gemm2 streams with `packed` = 1 (same act / out_f32 flags as the projection it feeds:
  * they select the tile mode): every wave-instruction of the weight stream then reads one contiguous KiB of full 128-byte lines
  * instead of 16 row segments of 64 bytes.  out: N * K bf16.  BRA_ERR_UNSUPPORTED when N, K are not tile multiples.
