@@ -268,6 +268,15 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(const float* part_max, c
     }
 }
 
+// fp32 <-> bf16 images of a flat gradient range: the optional bf16 transport of the data-parallel all-reduce (half the xGMI bytes of
+// the 148 MB fp32 arena; SURVEY section 8e "148 MB fp32 (or 74 MB bf16) bucket").  dir 0: dst(bf16) = round(src(f32)); 1: dst(f32) = src(bf16)
+__global__ __launch_bounds__(256) void cast_grad_kernel(const void* src, void* dst, long n, int dir) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (dir == 0) ((bf16_t*)dst)[i] = f2bf(((const float*)src)[i]);
+    else ((float*)dst)[i] = bf2f(((const bf16_t*)src)[i]);
+}
+
 // out[0] = scale * sum(x[0..n)) — the mean reduction of the cross-entropy / per-token losses
 __global__ __launch_bounds__(256) void vec_sum_kernel(const float* x, long n, float scale, float* out) {
     __shared__ float red[4];
@@ -502,6 +511,13 @@ extern "C" int bra_lse_merge(const float* part_max, const float* part_sum, const
     if (!part_max || !part_sum || !lse || nchunk <= 0 || (logp && !tgt_logit)) return BRA_ERR_ARG;
     BRA_LAUNCH(lse_merge_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, part_max, part_sum, tgt_logit, lse,
                logp, rows, nchunk);
+    return BRA_LAUNCH_STATUS();
+}
+
+extern "C" int bra_cast_grad(const void* src, void* dst, long n, int to_f32, void* stream) {
+    if (n == 0) return 0;
+    if (!src || !dst || n < 0) return BRA_ERR_ARG;
+    BRA_LAUNCH(cast_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, n, to_f32 ? 1 : 0);
     return BRA_LAUNCH_STATUS();
 }
 

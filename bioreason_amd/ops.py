@@ -665,6 +665,15 @@ def grpo_loss(logp, old_logp, ref_logp, adv, mask, eps_lo, eps_hi, beta, need_gr
     return out3, dlogp
 
 
+def cast_grad(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """flat fp32 -> bf16 (or bf16 -> fp32) copy of a gradient range: the bf16 transport of the data-parallel all-reduce"""
+    assert src.numel() == dst.numel() and src.is_contiguous() and dst.is_contiguous()
+    to_f32 = dst.dtype == torch.float32
+    assert (src.dtype, dst.dtype) in ((torch.float32, BF16), (BF16, torch.float32))
+    get_lib().call("bra_cast_grad", src, dst, src.numel(), int(to_f32), current_stream(src))
+    return dst
+
+
 def vec_sum(x: torch.Tensor, scale: float) -> torch.Tensor:
     out = torch.empty((1,), dtype=torch.float32, device=x.device)
     get_lib().call("bra_vec_sum", x, x.numel(), scale, out, current_stream(x))

@@ -29,7 +29,7 @@ from typing import Callable, Dict, List, Optional
 import torch
 import torch.distributed as dist
 
-from . import grpo
+from . import grpo, ops
 
 METRIC_SLOT = "__dp_metrics__"
 
@@ -66,6 +66,10 @@ class GRPOConfig:
     # with any fp8 rollout engine; never on in the bf16 headline.
     rollout_fp8: bool = False
     grad_buckets: int = 4
+    # transport dtype of the gradient all-reduce: "fp32" (default: the flat arena itself, 148 MB) or "bf16" (each bucket is rounded to a
+    # bf16 image, summed over the ranks in bf16 and widened back: half the xGMI bytes, one rounding per rank and per sum step — DDP's
+    # bf16 compression hook; the metric slot rides in fp32 either way)
+    grad_allreduce_dtype: str = "fp32"
     share_dna_encoding: bool = True      # frozen-encoder rows computed once per step and shared by its three passes
     # the policy pass (forward AND backward) may run the prompt of a group of consecutive copies once
     # (grpo.per_token_logps_shared_policy): identical results at lora_dropout = 0; under LoRA dropout the shared prompt rows would carry
@@ -102,8 +106,12 @@ class _DataParallelStep:
     all-reduced asynchronously from inside the backward (engine.layer_done_hook), the tail bucket (first layers + the
     projection, whose gradients arrive last) after it; AdamW + global-norm clip is one fused launch."""
 
-    def __init__(self, model, n_buckets: int = 4):
+    def __init__(self, model, n_buckets: int = 4, grad_dtype: str = "fp32"):
         self.model = model
+        if grad_dtype not in ("fp32", "bf16"):
+            raise ValueError("grad_allreduce_dtype must be 'fp32' or 'bf16'")
+        self._grad_bf16 = grad_dtype == "bf16"
+        self._bf_images: List = []
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         # `dp`: the collectives of the step are issued.  BRA_DP_SINGLE_RANK=1 issues them in a ONE-rank group too (each is then the
@@ -145,10 +153,26 @@ class _DataParallelStep:
                 hi = lo
         self._tail_hi = hi
 
+    def _issue(self, lo: int, hi: int):
+        """asynchronous sum of the gradient range [lo, hi) over the ranks, in the configured transport dtype"""
+        g = self.model.arena.grads[lo:hi]
+        if not self._grad_bf16:
+            self._handles.append(dist.all_reduce(g, async_op=True))
+            return
+        a = self.model.arena
+        # the per-rank loss / KL / clip-ratio scalars (METRIC_SLOT) are averaged in fp32: cut them out of the bf16 image
+        m_lo = a._offsets.get(METRIC_SLOT)
+        if m_lo is not None and lo <= m_lo < hi:
+            self._handles.append(dist.all_reduce(a.grads[m_lo:m_lo + 64], async_op=True))
+        img = torch.empty(hi - lo, dtype=torch.bfloat16, device=g.device)
+        ops.cast_grad(g, img)
+        self._handles.append(dist.all_reduce(img, async_op=True))
+        self._bf_images.append((lo, hi, img, m_lo))
+
     def _layer_done(self, li: int):
         cut = self._cuts.get(li)
         if cut is not None:
-            self._handles.append(dist.all_reduce(self.model.arena.grads[cut[0]:cut[1]], async_op=True))
+            self._issue(cut[0], cut[1])
 
     def begin_backward(self):
         self._handles = []
@@ -163,10 +187,18 @@ class _DataParallelStep:
         eng.layer_done_hook = None
         g = self.model.arena.grads
         hi = self._tail_hi if self._cuts else g.numel()
-        self._handles.append(dist.all_reduce(g[:hi], async_op=True))
+        self._issue(0, hi)
         for h in self._handles:
             h.wait()
         self._handles = []
+        for lo, hi_, img, m_lo in self._bf_images:              # widen the summed bf16 images back into the arena
+            keep = None
+            if m_lo is not None and lo <= m_lo < hi_:
+                keep = self.model.arena.grads[m_lo:m_lo + 64].clone()
+            ops.cast_grad(img, g[lo:hi_])
+            if keep is not None:
+                self.model.arena.grads[m_lo:m_lo + 64].copy_(keep)
+        self._bf_images = []
         return 1.0 / self.world
 
     def _marks(self, timing: bool, dev):
@@ -191,7 +223,7 @@ class GRPOStepRunner(_DataParallelStep):
     metric_names = ["completion_length", "reward", "reward_std", "loss", "kl", "clip_ratio"]
 
     def __init__(self, model, cfg: GRPOConfig, reward_fn: Callable = token_stat_rewards):
-        super().__init__(model, cfg.grad_buckets)
+        super().__init__(model, cfg.grad_buckets, getattr(cfg, "grad_allreduce_dtype", "fp32"))
         self.cfg, self.reward_fn = cfg, reward_fn
         self.global_step = 0                # optimiser steps (HF: self.state.global_step)
         self._step = 0                      # forward/backward passes, incl. those inside an accumulation cycle (:395)

@@ -312,6 +312,9 @@ int bra_pack_params(const void* descs_dev, int ndesc, long max_elems, void* stre
 /* AdamW over one flat arena with device-side global-norm clip (train_dna_qwen.py:393-411, :1003 clip 1.0) */
 /* out[0] = scale * sum(x): the `mean` of F.cross_entropy (TF:loss/loss_utils.py:32-46) */
 int bra_vec_sum(const float* x, long n, float scale, float* out, void* stream);
+/* dst = bf16(src fp32) (to_f32 = 0) or dst = fp32(src bf16) (to_f32 = 1) over n elements: the optional bf16 transport of the gradient
+ * all-reduce (DDP / ZeRO-2 reduce of ~37 M trainable parameters, train_dna_qwen.py:985-1005, ds_config_stage2.json:22-34) */
+int bra_cast_grad(const void* src, void* dst, long n, int to_f32, void* stream);
 /* out[0] = sum of squares of g (global-norm clip, max_grad_norm); ws = float[1024] scratch.  Fixed summation order,
  * no atomics: replicas holding identical gradients get identical norms.
  * mask (bytes, optional): 0 = structural zero of the packed LoRA layout, excluded from norm and update */

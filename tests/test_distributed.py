@@ -48,9 +48,17 @@ def _worker(rank, world, port, emu_path, q, grouped=False):
         return r
 
     G = 2 if grouped else 2 * world          # (ungrouped) one group spans both ranks: 2 local rows per rank, G = 4 (exercises the cross-rank gather)
-    runner = GRPOStepRunner(m, GRPOConfig(num_generations=G, max_completion_length=4, eos_token_id=None, seed=7, learning_rate=1e-3), reward)
+    gdt = os.environ.get("BRA_TEST_GRAD_DTYPE", "fp32")
+    runner = GRPOStepRunner(m, GRPOConfig(num_generations=G, max_completion_length=4, eos_token_id=None, seed=7, learning_rate=1e-3,
+                                          grad_allreduce_dtype=gdt), reward)
     p0 = m.arena.params.clone()
     out = runner.step(b)
+    if gdt == "bf16":        # every summed gradient went through a bf16 image (the fp32 metric slot excepted)
+        from bioreason_amd.trainer import METRIC_SLOT
+        g_ = m.arena.grads.clone()
+        o_ = m.arena._offsets[METRIC_SLOT]
+        g_[o_:o_ + 64] = 0
+        assert torch.equal(g_, g_.to(torch.bfloat16).float()) and float(g_.abs().max()) > 0
     gathered = [torch.empty_like(seen["local"]) for _ in range(world)]
     dist.all_gather(gathered, seen["local"])
     allr = torch.cat(gathered, 0).sum(1)
@@ -101,6 +109,25 @@ def test_grpo_step_two_ranks(emu_lib_path):
         assert abs(mets[0] - 4.0) < 1e-6 and abs(mets[1] - want_reward) < 1e-5
         assert abs(mets[3] - want_loss) < 1e-5 * max(1.0, abs(want_loss))
         assert ncuts >= 1, "the gradient reduction was not cut into overlapped buckets"
+
+
+def test_grpo_step_two_ranks_bf16_gradient_transport(emu_lib_path, monkeypatch):
+    """GRPOConfig.grad_allreduce_dtype = "bf16": each bucket travels as a bf16 image (half the xGMI bytes), the per-rank loss / KL / clip
+    ratio in the spare slot stay fp32; replicas identical, metrics exact, the bucket cuts unchanged"""
+    monkeypatch.setenv("BRA_TEST_GRAD_DTYPE", "bf16")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same_p, same_g, moved, loss, want_adv, got_adv, same_m, mets, want_loss, want_reward, ncuts in res:
+        assert same_p and same_g and same_m and moved > 0 and loss == loss
+        assert abs(mets[3] - want_loss) < 1e-5 * max(1.0, abs(want_loss)) and ncuts >= 1
 
 
 def test_grpo_step_two_ranks_shared_prompt_groups(emu_lib_path):

@@ -19,6 +19,14 @@ def _worker(rank, world, port, q):
     torch.cuda.set_device(rank)
     dev = torch.device("cuda", rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if rank == 0:        # the first multi-GPU execution is self-diagnosing: what RCCL, how many ranks, which devices
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:
+            ver = "unknown (%s)" % type(e).__name__
+        print("[nccl smoke] RCCL %s, world_size %d, visible devices %d (%s), HSA_ENABLE_IPC_MODE_LEGACY=%s"
+              % (ver, dist.get_world_size(), torch.cuda.device_count(), torch.cuda.get_device_name(0),
+                 os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")), flush=True)
     from test_model_parity import GOLD, build, to_dev
     from bioreason_amd.trainer import GRPOConfig, GRPOStepRunner
     fix = torch.load(os.path.join(GOLD, "tiny_a.pt"), weights_only=False)
