@@ -52,7 +52,7 @@ PEAK_HBM_GBS = 8000.0
 SD, TEXT_LEN, NDNA, G, C = 1024, 128, 2, 8, 256
 LORA_DROPOUT = 0.05          # reason.py:266 / train_dna_qwen.py:1038
 SFT_LABEL_TAIL = 64
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r4_pmc_gemm.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r5_pmc_gemm.json")
 DRYRUN = os.environ.get("BENCH_DRYRUN") == "1"
 
 
@@ -136,14 +136,14 @@ def pmc_traffic():
         with open(PMC_PROFILE) as fh:
             d = json.load(fh)
     except Exception:
-        return None, "no PMC summary committed for this round (profiles/r4_pmc_gemm.json)"
+        return None, "no PMC summary committed for this round (profiles/%s)" % os.path.basename(PMC_PROFILE)
     if d.get("kernel_source_sha") != kernel_source_sha():
-        return None, ("profiles/r4_pmc_gemm.json was collected from different kernel sources (sha %s, running %s): not reported. "
+        return None, ("profiles/" + os.path.basename(PMC_PROFILE) + " was collected from different kernel sources (sha %s, running %s): not reported. "
                       "Last collected value, for sha %s: %.0f bytes per API call" % (
                           d.get("kernel_source_sha"), kernel_source_sha(), d.get("kernel_source_sha"),
                           float(d.get("traffic_bytes_per_call", 0.0))))
     return float(d["traffic_bytes_per_call"]), ("HBM-side bytes per API call (one call = one ring dispatch, or ring + 256x128 remainder), rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + "
-                                                  "WRITE_SIZE, separate passes) on this command: profiles/r4_pmc_gemm.json")
+                                                  "WRITE_SIZE, separate passes) on this command: profiles/" + os.path.basename(PMC_PROFILE))
 
 
 # ---------------------------------------------------------------------------------------------- CPU baseline

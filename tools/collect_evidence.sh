@@ -4,14 +4,14 @@
 #   profiles/<tag>_bench_kernel_stats.csv     rocprofv3 --kernel-trace --stats of `bench.py --steps 1 --warmup 1` (3 steps in the trace)
 #   profiles/<tag>_pmc_*.csv                  separate rocprofv3 --pmc passes on the SAME command (FETCH_SIZE | WRITE_SIZE | SQ busy counters)
 #   profiles/<tag>_pmc_gemm.json              dominant-kernel traffic per launch + the kernel-source hash bench.py checks
-tag=${1:-r4_x}
+tag=${1:-r5_x}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 out=$R/gpurun_out/evidence_$tag; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-one-stream-profile"
 if [ "$PMC_ONLY" = "1" ]; then :      # only the counter passes (the bench line and the kernel stats of this state exist already)
 elif [ "$NOCPU" = "1" ]; then timeout 300 python $R/bench.py --no-cpu-baseline --steps 5 2>/dev/null | tail -1 > $out/${tag}_bench.json
-else timeout 600 python $R/bench.py --steps 5 2>/dev/null | tail -1 > $out/${tag}_bench.json; fi
+else timeout 1200 python $R/bench.py --steps 5 2>$out/${tag}_bench.err | tail -1 > $out/${tag}_bench.json; fi
 [ "$PMC_ONLY" = "1" ] || { rm -rf /tmp/ev_stats; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ev_stats -o r --output-format csv -- $BENCH > /tmp/ev_stats.log 2>&1
 f=$(find /tmp/ev_stats -name "*kernel_stats.csv" | head -1)
 { echo "# rocprofv3 --kernel-trace --stats --output-format csv -- $BENCH   (MI355X, $tag; 3 GRPO steps in the trace: warm-up, timed, instrumented)"; cat $f; } > $out/${tag}_bench_kernel_stats.csv; }
