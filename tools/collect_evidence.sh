@@ -8,7 +8,7 @@ tag=${1:-r5_x}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 out=$R/gpurun_out/evidence_$tag; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-one-stream-profile"
+BENCH="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-one-stream-profile --no-gpu-baseline-hf"
 if [ "$PMC_ONLY" = "1" ]; then :      # only the counter passes (the bench line and the kernel stats of this state exist already)
 elif [ "$NOCPU" = "1" ]; then timeout 300 python $R/bench.py --no-cpu-baseline --steps 5 2>/dev/null | tail -1 > $out/${tag}_bench.json
 else timeout 1200 python $R/bench.py --steps 5 2>$out/${tag}_bench.err | tail -1 > $out/${tag}_bench.json; fi
