@@ -69,7 +69,7 @@ struct Tile {
     __device__ static __forceinline__ int koff(int row, int chunk) {   // byte offset in a [64][HD] tile
         return row * (HD * 2) + ((chunk ^ ((row / RPB) & (CH - 1))) << 4);
     }
-    __device__ static __forceinline__ int toff(int d, int chunk) {     // byte offset in a [HD][64] tile
+    __device__ static __forceinline__ int toff(int d, int chunk) {     // byte offset of 16-byte unit `chunk` of row d in a [HD][64] tile
         return d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4);
     }
 };
@@ -113,9 +113,23 @@ __device__ __forceinline__ void store_trans(char* lds, const u32x4 (&r)[(HD * 8)
 #pragma unroll
     for (int i = 0; i < (HD * 8) / NT; ++i) {
         int q = tid + NT * i;
-        // (measured, round 4: swapping the 8-byte halves of a chunk in rows with bit 4 set — on paper rows d and d + 16 share the banks
-        //  of their chunks under the 8-byte fragment reads — changed nothing at B = 8 and cost the 4-wave dK / dV kernel 15-22 %)
+#ifdef BRA_TRANS_B64
+        // (rounds 1-4: the global chunk as it is; the reader then assembles its fragment from two 8-byte pieces 16 bytes apart)
         st16(lds + Tile<HD>::toff(q >> 3, q & 7), r[i]);
+#else
+        // round 5: positions regrouped per 16 as [0..3, 8..11 | 4..7, 12..15] — exactly the two 8-position fragments the 32x32 MFMA
+        // register order asks for (frag_trans), each now ONE 16-byte unit: chunk c = 2 g + e (e: first / second half of the group)
+        // puts its low half into unit 2 g at byte 8 e and its high half into unit 2 g + 1 at byte 8 e.  One ds_read_b128 per fragment
+        // instead of two strided ds_read_b64 and the v_mov that glued them (48 per 64-key tile in the forward, 250 - 450 per tile loop in
+        // the backward kernels); the staging side pays two 8-byte writes per chunk instead of one 16-byte write.
+        {
+            const int d = q >> 3, c = q & 7, g = c >> 1, e = c & 1;
+            u32x2 lo, hi;
+            lo.x = r[i].x; lo.y = r[i].y; hi.x = r[i].z; hi.y = r[i].w;
+            st8(lds + Tile<HD>::toff(d, 2 * g) + 8 * e, lo);
+            st8(lds + Tile<HD>::toff(d, 2 * g + 1) + 8 * e, hi);
+        }
+#endif
     }
 }
 
@@ -130,10 +144,14 @@ __device__ __forceinline__ u32x4 frag_rows(const char* lds, int rbase, int ds, i
 template <int HD>
 __device__ __forceinline__ u32x4 frag_trans(const char* lds, int dbase, int s, int lane) {
     const int d = dbase + (lane & 31), h = lane >> 5;
+#ifdef BRA_TRANS_B64
     u32x2 p0 = ld8(lds + Tile<HD>::toff(d, 2 * s) + 8 * h);
     u32x2 p1 = ld8(lds + Tile<HD>::toff(d, 2 * s + 1) + 8 * h);
     u32x4 o; o.x = p0.x; o.y = p0.y; o.z = p1.x; o.w = p1.y;
     return o;
+#else
+    return ld16(lds + Tile<HD>::toff(d, 2 * s + h));          // [16 s + 4 h + 0..3 | 16 s + 8 + 4 h + 0..3] (store_trans)
+#endif
 }
 // sequence index (within a 32-block) held in register r of a 32x32 C/D fragment
 __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
