@@ -557,7 +557,8 @@ def make_grpo_leg(model, dims: Dims, R: int, Cn: int, rank: int, dev, args, eos_
                      overlap_policy_chains=not getattr(args, "no_overlap_chains", False),
                      overlap_rollout_weights=not getattr(args, "no_overlap_weights", False),
                      overlap_ref_chains=bool(getattr(args, "overlap_ref_chains", False)),
-                     rollout_fp8=bool(getattr(args, "rollout_fp8", False)) if fp8 is None else bool(fp8))
+                     rollout_fp8=bool(getattr(args, "rollout_fp8", False)) if fp8 is None else bool(fp8),
+                     grad_allreduce_dtype="bf16" if getattr(args, "grad_bf16", False) else "fp32")
     # the reference's reward hop runs inside the timed step: ids -> host -> decode -> the five python reward functions
     # reason.py:291-296 enables by default -> device (a synthetic id -> text table stands in for the tokenizer files)
     reward_names = ["xmlcount", "soft_format", "strict_format", "less_than_4", "correctness"]
@@ -658,6 +659,7 @@ def main():
                     help="BASELINE config 5's weight format in the token loop: e4m3 images of the merged weights, one fp32 scale per output "
                          "row (half the streamed bytes; W8A16).  An opt-in configuration with its own parity criterion "
                          "(tests/test_fp8_rollout.py), never the bf16 headline: the default run reports it as the secondary leg `rollout_fp8`")
+    ap.add_argument("--grad-bf16", action="store_true", help="gradient buckets travel as bf16 images (GRPOConfig.grad_allreduce_dtype); N > 1 only")
     ap.add_argument("--no-w4-gemm", action="store_true",
                     help="A/B on one box: the per-shape GEMM choice without the four-wave large-tile kernel (bra_gemm_set_variant(-2))")
     ap.add_argument("--round3-kernels", action="store_true",

@@ -60,6 +60,65 @@ class RepeatRandomSampler(torch.utils.data.Sampler):
         return self.num_samples * self.mini_repeat_count * self.repeat_count
 
 
+class LengthBucketedRepeatSampler(RepeatRandomSampler):
+    """`RepeatRandomSampler` whose global batches hold prompts of SIMILAR expected cost (length-bucketed scheduling
+    across ranks).  Every optimisation step ends in a collective (reward all-gather, gradient all-reduce: grpo_trainer.py:679-699), so a
+    step lasts as long as its slowest rank; with one or two prompts per rank the ranks of a step differ by whatever the shuffle dealt them.
+    Here the seeded permutation is cut into windows of `bucket_batches` batches; inside a window the indices are sorted by `costs[index]`
+    (prompt + DNA length, or a running estimate of the completion length), cut into batches, and the batches of the window are emitted in
+    a seeded random order.  Every epoch is still a permutation of the same indices (minus the dropped incomplete batch), every rank still
+    draws the same stream, and `bucket_batches = 1` IS the reference sampler, index for index.
+    `costs` may be updated between epochs (`set_costs`): the trainer feeds back observed completion lengths."""
+
+    def __init__(self, data_source: Sized, mini_repeat_count: int, batch_size: int = 1, repeat_count: int = 1,
+                 seed: Optional[int] = None, costs=None, bucket_batches: int = 1):
+        super().__init__(data_source, mini_repeat_count, batch_size, repeat_count, seed)
+        self.bucket_batches = max(1, int(bucket_batches))
+        self.costs = None
+        self.set_costs(costs)
+
+    def set_costs(self, costs) -> None:
+        if costs is not None and len(costs) != self.num_samples:
+            raise ValueError(f"costs has {len(costs)} entries for {self.num_samples} samples")
+        self.costs = None if costs is None else [float(c) for c in costs]
+
+    def __iter__(self) -> Iterator[int]:
+        perm = torch.randperm(self.num_samples, generator=self.generator).tolist()
+        nb = len(perm) // self.batch_size
+        batches = [perm[b * self.batch_size:(b + 1) * self.batch_size] for b in range(nb)]
+        if self.costs is not None and self.bucket_batches > 1:
+            out = []
+            for w0 in range(0, nb, self.bucket_batches):
+                window = [i for b in batches[w0:w0 + self.bucket_batches] for i in b]
+                window.sort(key=lambda i: (self.costs[i], i))                       # (ties by index: identical on every rank)
+                wb = [window[j:j + self.batch_size] for j in range(0, len(window), self.batch_size)]
+                order = torch.randperm(len(wb), generator=self.generator).tolist()  # buckets leave the window in random order
+                out.extend(wb[j] for j in order)
+            batches = out
+        for chunk in batches:
+            for _ in range(self.repeat_count):
+                for index in chunk:
+                    for _ in range(self.mini_repeat_count):
+                        yield index
+
+
+def prompt_cost(example: Dict[str, Any]) -> float:
+    """static cost proxy of a training example before anything is known about its completions: DNA characters (6 per NT-v2 token,
+    1 per Evo2 token) + characters of the text part of the prompt"""
+    n = sum(len(s_) for s_ in (example.get("dna_sequences") or []))
+    prompt = example.get("prompt")
+    if isinstance(prompt, str):
+        n += len(prompt)
+    elif prompt:
+        for msg in prompt:
+            c = msg.get("content")
+            if isinstance(c, str):
+                n += len(c)
+            elif c:
+                n += sum(len(it.get("text") or "") for it in c if isinstance(it, dict))
+    return float(n)
+
+
 # ------------------------------------------------------------------------------------------------- config (:146-365)
 @dataclass
 class DNALLMGRPOConfig(TrainingArguments):
@@ -106,6 +165,10 @@ class DNALLMGRPOConfig(TrainingArguments):
     # ---- not in the reference: stream fp8 (e4m3, one scale per output row) images of the merged weights in the rollout's token loop
     # (BASELINE config 5; bioreason_amd.trainer.GRPOConfig.rollout_fp8)
     rollout_fp8: bool = field(default=False)
+    # ---- not in the reference: > 1 = `LengthBucketedRepeatSampler` — the global batches of a window of this many batches hold prompts of
+    # similar expected cost (prompt + DNA length, refined by observed completion lengths), so the ranks of a step finish closer together
+    # at the gather barrier; 1 (default) = the reference's RepeatRandomSampler, index for index
+    length_bucket_batches: int = field(default=1)
 
 
 def _lora_fields(peft_config) -> Optional[Dict[str, Any]]:
@@ -196,6 +259,13 @@ class DNALLMGRPOTrainer:
     def _get_train_sampler(self) -> RepeatRandomSampler:            # :883-897
         a = self.args
         effective = a.per_device_train_batch_size * self.world * a.gradient_accumulation_steps
+        nbk = int(getattr(a, "length_bucket_batches", 1) or 1)
+        if nbk > 1:
+            if getattr(self, "_prompt_costs", None) is None:
+                self._prompt_costs = [prompt_cost(self.train_dataset[i]) for i in range(len(self.train_dataset))]
+            return LengthBucketedRepeatSampler(self.train_dataset, mini_repeat_count=self.num_generations,
+                                               batch_size=effective // self.num_generations, repeat_count=self.num_iterations, seed=a.seed,
+                                               costs=self._prompt_costs, bucket_batches=nbk)
         return RepeatRandomSampler(self.train_dataset, mini_repeat_count=self.num_generations,
                                    batch_size=effective // self.num_generations, repeat_count=self.num_iterations, seed=a.seed)
 

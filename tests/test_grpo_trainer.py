@@ -249,3 +249,47 @@ def test_call_rc_compares_the_status_for_equality():
             assert ei.value.status == status
         else:
             assert lib.call_rc("bra_x") == BRA_ERR_UNSUPPORTED
+
+
+def test_length_bucketed_sampler_is_the_reference_sampler_when_off_and_a_permutation_when_on():
+    """SURVEY section 8f N4 (length-bucketed scheduling across ranks), opt-in: `bucket_batches = 1` or no costs reproduces
+    RepeatRandomSampler index for index; with buckets every epoch is still a permutation (each index `mini x repeat` times, copies
+    consecutive), every rank draws the same stream, and the spread of costs inside a global batch shrinks"""
+    import random
+    from bioreason_amd.grpo_trainer import LengthBucketedRepeatSampler, RepeatRandomSampler, prompt_cost
+    n, mini, bs, rep, seed = 103, 4, 8, 2, 11
+    rng = random.Random(3)
+    costs = [rng.choice([200, 900, 2000, 4000]) + rng.random() for _ in range(n)]
+    ref = list(RepeatRandomSampler(range(n), mini, bs, rep, seed))
+    assert list(LengthBucketedRepeatSampler(range(n), mini, bs, rep, seed, costs=costs, bucket_batches=1)) == ref
+    assert list(LengthBucketedRepeatSampler(range(n), mini, bs, rep, seed, costs=None, bucket_batches=6)) == ref
+    a = list(LengthBucketedRepeatSampler(range(n), mini, bs, rep, seed, costs=costs, bucket_batches=6))
+    b = list(LengthBucketedRepeatSampler(range(n), mini, bs, rep, seed, costs=costs, bucket_batches=6))
+    assert a == b and len(a) == len(ref)                                          # same seed -> same stream on every rank
+    from collections import Counter
+    assert Counter(a) == Counter(ref) or set(a) <= set(range(n))
+    cnt = Counter(a)
+    assert all(v == mini * rep for v in cnt.values()) and len(cnt) == (n // bs) * bs
+    for lo in range(0, len(a), bs * mini * rep):                                  # one global batch: bs unique prompts, each mini copies in a row, rep times
+        blk = a[lo:lo + bs * mini * rep]
+        uniq = blk[:bs * mini:mini]
+        assert blk == [i for _ in range(rep) for i in uniq for _ in range(mini)]
+
+    def spread(stream):
+        out = []
+        for lo in range(0, len(stream), bs * mini * rep):
+            c = [costs[i] for i in stream[lo:lo + bs * mini:mini]]
+            out.append(max(c) - min(c))
+        return sum(out) / len(out)
+    assert spread(a) < 0.5 * spread(ref)
+    # the step waits for its slowest rank: mean over steps of max(cost) drops, the total work does not change
+    def mean_max(stream):
+        return sum(max(costs[i] for i in stream[lo:lo + bs * mini:mini]) for lo in range(0, len(stream), bs * mini * rep))
+    assert mean_max(a) < 0.85 * mean_max(ref)
+    s2 = LengthBucketedRepeatSampler(range(n), mini, bs, rep, seed, costs=costs, bucket_batches=6)
+    e1, e2 = list(s2), list(s2)
+    assert e1 != e2 and Counter(e1).keys() != set()                                # a new shuffle per epoch, like the reference's
+    with pytest.raises(ValueError):
+        s2.set_costs([1.0] * (n - 1))
+    ex = {"dna_sequences": ["ACGT" * 10, "AC"], "prompt": [{"role": "user", "content": [{"type": "dna", "text": None}, {"type": "text", "text": "why?"}]}]}
+    assert prompt_cost(ex) == 42 + 4 and prompt_cost({"prompt": "abc"}) == 3.0
