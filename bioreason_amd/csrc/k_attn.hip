@@ -74,18 +74,29 @@ struct Tile {
     }
 };
 
+// full-rate 24-bit multiply (v_mul_u32_u24): row index x stride, both below 2^24 (host-checked)
+#ifdef BRA_EMU
+__device__ __forceinline__ unsigned attn_mul24(int a, int b) { return ((unsigned)a & 0xffffffu) * ((unsigned)b & 0xffffffu); }
+#else
+__device__ __forceinline__ unsigned attn_mul24(int a, int b) { return __umul24((unsigned)a, (unsigned)b); }
+#endif
+
 // load a [64][HD] row-major tile (rows r0.., clamped to nrows-1) into registers / LDS
 template <int HD, int NT>
 __device__ __forceinline__ void load_rows(u32x4 (&r)[(64 * (HD / 8)) / NT], const bf16_t* base, long row_stride,
                                           int r0, int nrows, int tid) {
     constexpr int CH = HD / 8;
+    // round 5: `base` is uniform (one (batch, head) slice), the lane part is a 32-bit ELEMENT offset built with one full-rate 24-bit
+    // multiply — the 64-bit `row * stride` of rounds 1-4 cost two quarter-rate multiplies and a 64-bit add per request, 60 of the
+    // ~380 VALU instructions of a forward tile in a kernel that is VALU-bound (NOTES.md); the host checks that the slice fits
+    // (attn_check: strides < 2^24, slice < 2^31 elements)
 #pragma unroll
     for (int i = 0; i < (64 * CH) / NT; ++i) {
         int q = tid + NT * i;
         int row = q / CH, c = q % CH;
         int rr = r0 + row;
         rr = rr < nrows ? rr : nrows - 1;
-        r[i] = ld16(base + (long)rr * row_stride + c * 8);
+        r[i] = ld16(base + (attn_mul24(rr, (int)row_stride) + (unsigned)(c * 8)));
     }
 }
 template <int HD, int NT>
@@ -105,7 +116,7 @@ __device__ __forceinline__ void load_trans(u32x4 (&r)[(HD * 8) / NT], const bf16
     for (int i = 0; i < (HD * 8) / NT; ++i) {
         int q = tid + NT * i;
         int d = q >> 3, c = q & 7;
-        r[i] = ld16(base + (long)d * d_stride + s0 + c * 8);
+        r[i] = ld16(base + (attn_mul24(d, (int)d_stride) + (unsigned)(s0 + c * 8)));
     }
 }
 template <int HD, int NT>
@@ -1076,6 +1087,11 @@ static int g_attn_legacy_order = 0;
 static std::atomic<int> g_attn_legacy_order{0};
 #endif
 
+// the tile loaders address one (batch, head) slice with 32-bit element offsets built by a 24-bit multiply (load_rows / load_trans)
+static bool attn_fit32(long rows, long stride) {
+    return stride >= 0 && stride < (1L << 24) && rows < (1L << 24) && rows * stride < (1L << 31);
+}
+
 static int attn_check(int B, int Hq, int Hkv, int Sq, int Sk, int hd) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0 || Hq % Hkv) return BRA_ERR_ARG;
     if (hd != 32 && hd != 64 && hd != 128) return BRA_ERR_UNSUPPORTED;
@@ -1089,6 +1105,7 @@ extern "C" int bra_attn_fwd(const void* q, long q_sb, long q_ss, long q_sh, cons
     int e = attn_check(B, Hq, Hkv, Sq, Sk, hd);
     if (e) return e;
     if (!q || !k || !vt || !o || vt_sd % 8 || vt_sd < ((Sk + 63) / 64) * 64) return BRA_ERR_ARG;
+    if (!attn_fit32(Sk, k_ss) || !attn_fit32(hd, vt_sd)) return BRA_ERR_UNSUPPORTED;
     AttnArgs a = {};
     a.q = (const bf16_t*)q; a.q_sb = q_sb; a.q_ss = q_ss; a.q_sh = q_sh;
     a.k = (const bf16_t*)k; a.k_sb = k_sb; a.k_ss = k_ss; a.k_sh = k_sh;
@@ -1117,6 +1134,7 @@ extern "C" int bra_attn_fwd_split(const void* q, long q_sb, long q_ss, long q_sh
     if (!q || !k || !vt || !o || vt_sd % 8 || vt_sd < ((Sk + 63) / 64) * 64) return BRA_ERR_ARG;
     if (nsplit < 2 || nsplit > 8 || !part_o || !part_ml || o_sh % 4 || o_ss % 4 || o_sb % 4) return BRA_ERR_ARG;
     if (hd < 64 || Sq <= 128) return BRA_ERR_UNSUPPORTED;
+    if (!attn_fit32(Sk, k_ss) || !attn_fit32(hd, vt_sd)) return BRA_ERR_UNSUPPORTED;
     AttnArgs a = {};
     a.q = (const bf16_t*)q; a.q_sb = q_sb; a.q_ss = q_ss; a.q_sh = q_sh;
     a.k = (const bf16_t*)k; a.k_sb = k_sb; a.k_ss = k_ss; a.k_sh = k_sh;
@@ -1145,6 +1163,8 @@ static int attn_bwd_impl(const void* q, long q_sb, long q_ss, long q_sh, const v
     if (!q || !k || !v || !dout || !kt || !qt || !dot || !lse || !delta || !dq || !dk || !dv) return BRA_ERR_ARG;
     const int sk_pad = ((Sk + 63) / 64) * 64, sq_pad = ((Sq + 63) / 64) * 64;
     if (kt_sd % 8 || qt_sd % 8 || dot_sd % 8 || kt_sd < sk_pad || qt_sd < sq_pad || dot_sd < sq_pad) return BRA_ERR_ARG;
+    if (!attn_fit32(Sq, q_ss) || !attn_fit32(Sk, k_ss) || !attn_fit32(Sk, v_ss) || !attn_fit32(Sq, do_ss) || !attn_fit32(hd, kt_sd) ||
+        !attn_fit32(hd, qt_sd) || !attn_fit32(hd, dot_sd)) return BRA_ERR_UNSUPPORTED;
     AttnArgs a = {};
     a.q = (const bf16_t*)q; a.q_sb = q_sb; a.q_ss = q_ss; a.q_sh = q_sh;
     a.k = (const bf16_t*)k; a.k_sb = k_sb; a.k_ss = k_ss; a.k_sh = k_sh;

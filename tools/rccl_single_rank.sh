@@ -8,4 +8,4 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export BRA_DP_SINGLE_RANK=1 HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout ${T:-280} python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port ${PORT:-29517} \
-    $R/bench.py --gpus 1 --steps ${STEPS:-3} --warmup 2 --no-cpu-baseline --no-secondary
+    $R/bench.py --gpus 1 --steps ${STEPS:-3} --warmup 2 --no-cpu-baseline --no-secondary --no-gpu-baseline-hf "$@"
