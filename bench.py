@@ -831,6 +831,17 @@ def main():
                                                         "prompt (B x (P + C) rows, an independent LoRA-dropout mask per copy, as the reference "
                                                         "draws them) instead of the shared-prompt pass"}
             del u_runner, u_step
+        if not dims.dry:
+            # the other lever on the token loop: more rows per weight stream — sh_reason.sh's per_device_train_batch_size
+            # style of 2 prompts x G = 8 per GPU (16 rows share every streamed weight byte); a different configuration, reported beside the headline
+            try:
+                p_runner, p_step, p_B = make_grpo_leg(model, dims, 2, Cn, rank, dev, args, None, S + 3)
+                p_el, _ = timed_steps(p_step, S, 2, 1, dev)
+                secondary["prompts_per_gpu_2"] = {"value": p_B * S / p_el, "unit": "samples/s", "ms_per_step": 1000.0 * p_el / S, "steps": S, "warmup": 2,
+                                                  "workload": "the headline GRPO step with 2 distinct prompts x G = 8 per GPU (16 sequences per token step)"}
+                del p_runner, p_step
+            except Exception as e:
+                secondary["prompts_per_gpu_2"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         f_runner, f_step, f_B = make_sft_leg(model, dims, R, rank, dev)
         f_el, _ = timed_steps(f_step, S, 2, 1, dev)
         f_ex = executed_flops(R, dims.P, 0, "sft")
