@@ -34,6 +34,14 @@ The JSON line also carries
   cpu_baseline    — the oracle (the reference's glue restated around the INSTALLED HF Qwen3 / ESM modules — the code the reference
                     itself executes on a CPU) timed on the host cores for a bounded sample of the same workload, bf16 (the
                     reference's dtype) and fp32 (separate process, after the GPU line is measured).
+  gpu_baseline_hf — (round 5) the SAME oracle on THIS GPU through stock PyTorch-ROCm eager kernels (bf16, sdpa): the reference's full
+                    GRPO step for 1 prompt x G = 8 (HF generate, reference log-probs, policy forward / backward with full-row logits,
+                    AdamW) and its cfg-2 SFT step; its own process, after the timed region; `hip_over_hf` = value / its value.
+  value_reference_semantics, policy_pass — (round 5) `value` runs the shared-prompt policy pass (opted into explicitly; under LoRA dropout
+                    one mask stream for the shared rows); the same step with the reference's sampling scheme (full rows, a mask per copy:
+                    the library default whenever the adapters have dropout) is `value_reference_semantics` (= leg `unshared_policy`).
+  rollout_fp8, prompts_per_gpu_2 — (round 5) secondary legs: the token loop over fp8 e4m3 weights (BASELINE config 5's weight format,
+                    opt-in), and 16 rows per weight stream (2 prompts x G = 8 per GPU).
 """
 import argparse
 import hashlib
