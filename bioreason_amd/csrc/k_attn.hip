@@ -711,24 +711,30 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs a) {
                     st = mfma_32x32x16(frag_rows<HD>(sq, qb * 32, ds, ll), kf[ds], st);
                     if constexpr (DK) dp = mfma_32x32x16(frag_rows<HD>(sd, qb * 32, ds, ll), vf[ds], dp);
                 }
+                // the per-query statistics sit at sl[32 qb + crow(r, h)]: one per-iteration base (the lane's half h, re-derived from the
+                // opaque lane id) + compile-time offsets, so that the reads are `ds_read_b32 base offset:imm`.  With `h` from outside the
+                // loop the compiler hoisted all 64 addresses, ran out of registers and reloaded them from scratch in every tile
+                // (round 5: 95 scratch loads per tile in the one-pass dK + dV kernel, behind the same counter as the tile prefetch)
+                const int hl = ll >> 5;
+                const float* slh = sl + 4 * hl;
                 if (full) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int ql = qb * 32 + crow(r, h);
-                        const float p = fast_exp2(fmaf(st[r], sc, -sl[ql]));
+                        const int qo = qb * 32 + (r & 3) + 8 * (r >> 2);
+                        const float p = fast_exp2(fmaf(st[r], sc, -slh[qo]));
                         st[r] = p;                                                     // P
-                        if constexpr (DK) dp[r] = p * (dp[r] - sl[64 + ql]) * a.scale;   // dS
+                        if constexpr (DK) dp[r] = p * (dp[r] - slh[64 + qo]) * a.scale;   // dS
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int ql = qb * 32 + crow(r, h);
-                        const int qi = s0 + ql;
+                        const int qo = qb * 32 + (r & 3) + 8 * (r >> 2);
+                        const int qi = s0 + qo + 4 * hl;
                         bool ok = kvalid && qi < a.Sq;
                         if (a.causal) ok = ok && (kj <= qi + a.q_off);
-                        const float p = ok ? fast_exp2(st[r] * sc - sl[ql]) : 0.f;
+                        const float p = ok ? fast_exp2(st[r] * sc - slh[qo]) : 0.f;
                         st[r] = p;                                                     // P
-                        if constexpr (DK) dp[r] = p * (dp[r] - sl[64 + ql]) * a.scale;   // dS
+                        if constexpr (DK) dp[r] = p * (dp[r] - slh[64 + qo]) * a.scale;   // dS
                     }
                 }
 #pragma unroll
