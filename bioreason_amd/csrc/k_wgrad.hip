@@ -149,24 +149,28 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs g) {
     if (r_major) {
         // D[i][j]: i = r (register index), j = column n of Y (lane & 31): 32 consecutive floats of a row of C per atomic instruction
         const int n = n0 + wave * 32 + (lane & 31);
+        // (round 5) one lane-dependent base, wave-uniform offsets per atomic: each used to carry two 64-bit multiplies
+        float* const cb = g.C + (long)n * g.c_sn + (long)(4 * h) * g.c_sr;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int r = rb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (n < g.N && r < g.R) atomicAdd(g.C + (long)n * g.c_sn + (long)r * g.c_sr, g.alpha * acc[rb][q]);
+                const int rq = rb * 32 + (q & 3) + 8 * (q >> 2);
+                if (n < g.N && rq + 4 * h < g.R) atomicAdd(cb + (long)rq * g.c_sr, g.alpha * acc[rb][q]);
             }
         return;
     }
     // D[i][j]: i = A row = column n of Y (register index), j = B row = r (lane & 31)
+    float* const cb = g.C + (long)(n0 + wave * 32 + 4 * h) * g.c_sn + (long)(lane & 31) * g.c_sr;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int r = rb * 32 + (lane & 31);
         if (r >= g.R) continue;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int n = n0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (n < g.N) atomicAdd(g.C + (long)n * g.c_sn + (long)r * g.c_sr, g.alpha * acc[rb][q]);
+            const int nq = (q & 3) + 8 * (q >> 2);
+            const int n = n0 + wave * 32 + nq + 4 * h;
+            if (n < g.N) atomicAdd(cb + (long)nq * g.c_sn + (long)(32 * rb) * g.c_sr, g.alpha * acc[rb][q]);
         }
     }
 }
