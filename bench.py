@@ -611,6 +611,9 @@ def make_sft_leg(model, dims: Dims, R: int, rank: int, dev):
     return runner, step, B
 
 
+TIMED_DIAG: dict = {}      # diagnostics of the LAST timed_steps call (read by main() right after the headline's): host load, allocator
+
+
 def timed_steps(step, steps: int, warmup: int, world: int, dev, first_index: int = 0, before_timed=None):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks"""
     import torch
@@ -626,14 +629,37 @@ def timed_steps(step, steps: int, warmup: int, world: int, dev, first_index: int
     if world > 1:
         dist.barrier()
     sync()
+    diag = TIMED_DIAG
+    diag.clear()
+    if dev.type == "cuda":
+        ms0 = torch.cuda.memory_stats(dev)
+        diag["allocator_before"] = {"segments": ms0.get("segment.all.current", 0), "device_mallocs": ms0.get("num_device_alloc", 0),
+                                    "alloc_retries": ms0.get("num_alloc_retries", 0), "reserved_gib": ms0.get("reserved_bytes.all.current", 0) / 2.0 ** 30}
+    try:
+        diag["host_loadavg_before"] = list(os.getloadavg())
+    except OSError:
+        pass
+    per_step = []
     t0 = time.perf_counter()
     out = None
     for i in range(steps):
+        ts = time.perf_counter()
         out = step(first_index + warmup + i)
+        per_step.append(time.perf_counter() - ts)          # host time inside step(): no extra synchronisation is added for it
     sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    diag["host_ms_inside_step_calls"] = [round(1000.0 * t, 1) for t in per_step]
+    if dev.type == "cuda":
+        ms1 = torch.cuda.memory_stats(dev)
+        diag["allocator_after"] = {"segments": ms1.get("segment.all.current", 0), "device_mallocs": ms1.get("num_device_alloc", 0),
+                                   "alloc_retries": ms1.get("num_alloc_retries", 0), "reserved_gib": ms1.get("reserved_bytes.all.current", 0) / 2.0 ** 30}
+    try:
+        diag["host_loadavg_after"] = list(os.getloadavg())
+        diag["host_cpus"] = os.cpu_count()
+    except OSError:
+        pass
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -755,6 +781,8 @@ def main():
                 runner.loop_events = []          # generate() appends a HIP-event pair around its token loop: the timed steps only
 
     elapsed, out = timed_steps(step, args.steps, args.warmup, world, dev, before_timed=before_timed)
+    headline_diag = dict(TIMED_DIAG)      # (the forward / backward chains are issued from Python: a loaded host or an allocator that has to
+                                          #  go to the driver shows up in the step time — NOTES.md round 5; kept in the line so that a slow run explains itself)
     prof = ops.GEMM_PROFILE.summary() if ops.GEMM_PROFILE is not None else {
         "tflops": 0.0, "flops_per_launch": 0.0, "bytes_per_launch": 0.0, "launches": 0, "avg_launch_ms": 0.0}
     ops.GEMM_PROFILE = None
@@ -926,6 +954,7 @@ def main():
             "step_frac_of_mfma_peak_executed": ex / 1e12 / (elapsed / args.steps) / PEAK_BF16_TFLOPS,
             "phases_ms": {k: round(v, 2) for k, v in headline_timers.items()},
             "loss": loss,
+            "timed_region_diagnostics": headline_diag,
             "hbm_reserved_gib": (torch.cuda.max_memory_reserved(dev) / 2.0 ** 30) if dev.type == "cuda" else None,   # peak of the caching allocator over all legs run so far (of 288)
             "parity_tolerance": "bf16-noise-relative: every compared quantity within 1.25x the reference's OWN bf16-vs-fp32 distance "
                                 "(tests/test_fullsize_parity.py, tests/test_model_parity.py); north_star's 1e-3 rel is below one bf16 "
