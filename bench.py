@@ -671,7 +671,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=3,
+                    help="untimed warm-up steps (default 3: the caching allocator reaches its steady state after the THIRD step — streams that "
+                         "record blocks delay their reuse — and a hipMalloc inside the timed region costs 8 ms per step on a quiet host, far more "
+                         "on a loaded one: timed_region_diagnostics.allocator_* in the line shows whether any happened)")
     ap.add_argument("--mode", choices=["grpo", "sft"], default="grpo")
     ap.add_argument("--no-one-stream-profile", action="store_true", help="skip the extra untimed step that profiles the GEMM family with every chain on one stream")
     ap.add_argument("--prompts-per-gpu", type=int, default=1, help="distinct prompts per GPU (x G=8 rollouts each); headline = 1")
@@ -795,7 +798,9 @@ def main():
             loop_ev = {"ms": sum(ms_l) / len(ms_l), "steps": sum(st_l) / len(st_l), "rollouts": len(ms_l)}
     if hasattr(runner, "loop_events"):
         runner.loop_events = None
-    # phase breakdown (one extra, untimed, instrumented step)
+    # phase breakdown (extra, untimed, instrumented steps: the first one lets the allocator see the serialised path's buffers — a fresh
+    # hipMalloc inside a measured phase has been seen to cost 100 ms on a loaded host —, the second one is reported)
+    step(args.warmup + args.steps, timing=True)
     step(args.warmup + args.steps, timing=True)
     # the same GEMM family with the chains of the step issued on ONE stream (one more untimed step): in the timed steps the reference
     # pass and the two chains of the policy pass run concurrently, so a HIP-event pair around a launch also spans time in which the
@@ -824,10 +829,10 @@ def main():
     if headline_default and world == 1 and not args.no_secondary and args.secondary_steps > 0:
         S = args.secondary_steps
         lo_hi = (2, dims.c) if dims.dry else (64, 256)
-        s_runner, s_step, s_B = make_grpo_leg(model, dims, R, Cn, rank, dev, args, lo_hi, S + 3)
-        s_el, _ = timed_steps(s_step, S, 2, 1, dev)                 # 2 warm-up steps: the allocator sees the new shapes
+        s_runner, s_step, s_B = make_grpo_leg(model, dims, R, Cn, rank, dev, args, lo_hi, S + 4)
+        s_el, _ = timed_steps(s_step, S, 3, 1, dev)                 # 3 warm-up steps: the allocator reaches its steady state for the new shapes
         mean_len = (lo_hi[0] + lo_hi[1]) / 2.0
-        secondary["straggler"] = {"value": s_B * S / s_el, "unit": "samples/s", "ms_per_step": 1000.0 * s_el / S, "steps": S, "warmup": 2,
+        secondary["straggler"] = {"value": s_B * S / s_el, "unit": "samples/s", "ms_per_step": 1000.0 * s_el / S, "steps": S, "warmup": 3,
                                   "workload": "the headline GRPO step with every rollout's EOS drawn at U[%d, %d] (SURVEY §8d straggler "
                                               "run; mean completion %.0f tokens; the step waits for its longest row)" % (lo_hi + (mean_len,))}
         del s_runner, s_step
@@ -836,13 +841,13 @@ def main():
             try:
                 e_runner, e_step, e_B = make_grpo_leg(model, dims, R, Cn, rank, dev, args, None, S + 3, fp8=True)
                 e_runner.loop_events = []
-                e_el, _ = timed_steps(e_step, S, 2, 1, dev)
+                e_el, _ = timed_steps(e_step, S, 3, 1, dev)
                 torch.cuda.synchronize()
                 ev = [(a.elapsed_time(b), n) for a, b, n in (e_runner.loop_events or [])][-S:]
                 e_runner.loop_events = None
                 e_tok = (sum(ms for ms, _ in ev) / max(1, sum(n for _, n in ev))) if ev else None
                 secondary["rollout_fp8"] = {
-                    "value": e_B * S / e_el, "unit": "samples/s", "ms_per_step": 1000.0 * e_el / S, "steps": S, "warmup": 2,
+                    "value": e_B * S / e_el, "unit": "samples/s", "ms_per_step": 1000.0 * e_el / S, "steps": S, "warmup": 3,
                     "ms_per_token_step": e_tok,
                     "weight_bytes_per_token_step": fp8_weight_bytes(model),
                     "hbm_frac_of_peak": ((fp8_weight_bytes(model) + 0.366e9) / (e_tok * 1e-3) / 1e9 / PEAK_HBM_GBS) if e_tok else None,
@@ -859,9 +864,9 @@ def main():
             # transparency leg: the same step with the policy pass over every row's FULL prompt (what the reference executes;
             # independent LoRA-dropout masks per copy) — the headline shares the prompt rows of a group in that pass
             u_runner, u_step, u_B = make_grpo_leg(model, dims, R, Cn, rank, dev, args, None, S + 3, share_policy=False)
-            u_el, _ = timed_steps(u_step, S, 2, 1, dev)
+            u_el, _ = timed_steps(u_step, S, 3, 1, dev)
             u_ex = executed_flops(R, dims.P, Cn, "grpo", shared_policy=False)
-            secondary["unshared_policy"] = {"value": u_B * S / u_el, "unit": "samples/s", "ms_per_step": 1000.0 * u_el / S, "steps": S, "warmup": 2,
+            secondary["unshared_policy"] = {"value": u_B * S / u_el, "unit": "samples/s", "ms_per_step": 1000.0 * u_el / S, "steps": S, "warmup": 3,
                                             "step_tflops_executed": u_ex / 1e12 / (u_el / S),
                                             "workload": "the headline GRPO step with the policy forward / backward over every row's full "
                                                         "prompt (B x (P + C) rows, an independent LoRA-dropout mask per copy, as the reference "
@@ -871,17 +876,17 @@ def main():
             # the other lever on the token loop: more rows per weight stream — sh_reason.sh's per_device_train_batch_size
             # style of 2 prompts x G = 8 per GPU (16 rows share every streamed weight byte); a different configuration, reported beside the headline
             try:
-                p_runner, p_step, p_B = make_grpo_leg(model, dims, 2, Cn, rank, dev, args, None, S + 3)
-                p_el, _ = timed_steps(p_step, S, 2, 1, dev)
-                secondary["prompts_per_gpu_2"] = {"value": p_B * S / p_el, "unit": "samples/s", "ms_per_step": 1000.0 * p_el / S, "steps": S, "warmup": 2,
+                p_runner, p_step, p_B = make_grpo_leg(model, dims, 2, Cn, rank, dev, args, None, S + 4)
+                p_el, _ = timed_steps(p_step, S, 3, 1, dev)
+                secondary["prompts_per_gpu_2"] = {"value": p_B * S / p_el, "unit": "samples/s", "ms_per_step": 1000.0 * p_el / S, "steps": S, "warmup": 3,
                                                   "workload": "the headline GRPO step with 2 distinct prompts x G = 8 per GPU (16 sequences per token step)"}
                 del p_runner, p_step
             except Exception as e:
                 secondary["prompts_per_gpu_2"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         f_runner, f_step, f_B = make_sft_leg(model, dims, R, rank, dev)
-        f_el, _ = timed_steps(f_step, S, 2, 1, dev)
+        f_el, _ = timed_steps(f_step, S, 3, 1, dev)
         f_ex = executed_flops(R, dims.P, 0, "sft")
-        secondary["sft"] = {"value": f_B * S / f_el, "unit": "samples/s", "ms_per_step": 1000.0 * f_el / S, "steps": S, "warmup": 2,
+        secondary["sft"] = {"value": f_B * S / f_el, "unit": "samples/s", "ms_per_step": 1000.0 * f_el / S, "steps": S, "warmup": 3,
                             "step_tflops_executed": f_ex / 1e12 / (f_el / S),
                             "step_frac_of_mfma_peak_executed": f_ex / 1e12 / (f_el / S) / PEAK_BF16_TFLOPS,
                             "workload": "BASELINE config 2 (train_dna_qwen.py:179-213): B=%d distinct samples, P=%d, full-row lm_head "
@@ -898,9 +903,9 @@ def main():
             try:
                 q_model = build_model(q_dims, dev, args.lora_dropout)
                 q_S = max(1, min(3, S))
-                q_runner, q_step, q_B = make_grpo_leg(q_model, q_dims, R, Cn, rank, dev, args, None, q_S + 3)
-                q_el, _ = timed_steps(q_step, q_S, 2, 1, dev)
-                secondary["qwen3_4b"] = {"value": q_B * q_S / q_el, "unit": "samples/s", "ms_per_step": 1000.0 * q_el / q_S, "steps": q_S, "warmup": 2,
+                q_runner, q_step, q_B = make_grpo_leg(q_model, q_dims, R, Cn, rank, dev, args, None, q_S + 4)
+                q_el, _ = timed_steps(q_step, q_S, 3, 1, dev)
+                secondary["qwen3_4b"] = {"value": q_B * q_S / q_el, "unit": "samples/s", "ms_per_step": 1000.0 * q_el / q_S, "steps": q_S, "warmup": 3,
                                          "workload": "the headline GRPO step (1 prompt x G=8, P=%d, C=%d, LoRA r=32 dropout %g, shared-prompt policy "
                                                      "pass) with Qwen3-4B as the text model: 36 layers x 2560, 32 q-heads / 8 kv-heads (32 query rows "
                                                      "per (prompt, kv-head) in the decode attention), intermediate 9728; NT-v2-500M encoder; random-init "
