@@ -47,6 +47,9 @@ def test_two_rank_self_launch_prints_one_line(emu_lib_path):
     assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] / 1000.0)) < 1e-6 * d["value"]
     assert "sft" not in d and "straggler" not in d       # secondary legs are N = 1 only
     assert d["metrics"]["completion_length"] == 3.0
+    # the line explains a slow run by itself (round 5): per-step host time and the host's load around the timed region; allocator fields on a GPU
+    diag = d["timed_region_diagnostics"]
+    assert len(diag["host_ms_inside_step_calls"]) == d["steps"] and "host_loadavg_before" in diag
 
 
 def test_eight_rank_self_launch_prints_one_line(emu_lib_path):
