@@ -34,6 +34,9 @@ int bra_gemm_set_glds_rows(int rows);
 /* attention forward / backward: 1 = launch order of rounds 1-3 (query / key block index fastest), 0 (default) = block index
  * slowest and, under a causal mask, heaviest blocks first (A/B measurements) */
 int bra_attn_set_block_order(int legacy);
+/* attention forward: 1 (default) = the 4-wave kernel with 64 queries per wave (k_attn4.hip) for grids of whole 256-query workgroups,
+ * 0 = the 8-wave kernel of rounds 1-5 for every shape (A/B measurements) */
+int bra_attn_set_fwd4(int on);
 
 
 /* ---- timing probes of the token loop (k_decgemm.hip, k_decfused.hip) ---------------------------------------------------- */

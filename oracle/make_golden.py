@@ -61,13 +61,38 @@ def init_weights(model: nn.Module, seed: int):
         p.data = p.data.to(torch.bfloat16).to(torch.float32)
 
 
-def import_reference():
+def import_from_reference(modname: str, attr: str):
+    """`attr` of the reference's module `modname`, imported from /root/reference and from nowhere else.
+
+    The repository ships a drop-in package of the same name (`bioreason/`), so a plain `from bioreason... import` returns whichever
+    of the two an earlier import left in `sys.modules` — a pin would then compare the repository with itself.  Here every
+    `bioreason*` module already loaded is set aside, the reference is imported with its checkout first on `sys.path`, the object is
+    checked to come from a file under REF, and then `sys.modules` / `sys.path` are put back exactly as they were (the reference's
+    modules stay alive through the object's functions only), so that the caller's interpreter is left as it was found."""
+    import importlib
+    import inspect
     import transformers.processing_utils as pu
     if not hasattr(pu, "CommonKwargs"):           # removed in transformers 5; processing_dl.py:9 imports it
         pu.CommonKwargs = typing.TypedDict("CommonKwargs", {}, total=False)
+    def ours(k): return k == "bioreason" or k.startswith("bioreason.")
+    stashed = {k: sys.modules.pop(k) for k in list(sys.modules) if ours(k)}
+    path_before = list(sys.path)
     sys.path.insert(0, REF)
-    from bioreason.models.dna_llm import DNALLMModel
-    return DNALLMModel
+    try:
+        obj = getattr(importlib.import_module(modname), attr)
+        src = os.path.realpath(inspect.getfile(obj))
+        if not src.startswith(os.path.realpath(REF) + os.sep):
+            raise ImportError(f"reference pin would use {src}, which is not under {REF}")
+    finally:
+        for k in [k for k in sys.modules if ours(k)]:
+            del sys.modules[k]
+        sys.modules.update(stashed)
+        sys.path[:] = path_before
+    return obj
+
+
+def import_reference():
+    return import_from_reference("bioreason.models.dna_llm", "DNALLMModel")
 
 
 def build_reference(DNALLMModel, text_model, dna_model, projection, dna_token_id):

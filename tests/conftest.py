@@ -16,6 +16,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--reverse-modules", action="store_true", default=False,
+                     help="run the test MODULES in reversed order (tests inside a module keep theirs): the suite must not depend on "
+                          "which module imported `bioreason` / touched sys.path first")
+
+
+def pytest_collection_modifyitems(config, items):
+    if not config.getoption("--reverse-modules"):
+        return
+    groups, order = {}, []
+    for it in items:
+        key = it.nodeid.split("::", 1)[0]
+        if key not in groups:
+            groups[key] = []
+            order.append(key)
+        groups[key].append(it)
+    items[:] = [it for key in reversed(order) for it in groups[key]]
+
+
 def _build_emu():
     import fcntl
     os.makedirs(os.path.join(ROOT, "tests", "emu", "build"), exist_ok=True)

@@ -64,11 +64,9 @@ def test_known_answers(toks):
 @pytest.mark.skipif(not os.path.isdir("/root/reference/bioreason"), reason="reference sources not on this machine")
 def test_equals_reference_class(toks):
     text_tok, dna_tok = toks
-    sys.path.insert(0, "/root/reference")
-    import transformers.processing_utils as pu
-    if not hasattr(pu, "CommonKwargs"):
-        pu.CommonKwargs = typing.TypedDict("CommonKwargs", {}, total=False)
-    from bioreason.models.dl.processing_dl import DLProcessor as RefProcessor
+    from oracle.make_golden import import_from_reference      # isolated: leaves sys.modules / sys.path as found, checks the file's origin
+    RefProcessor = import_from_reference("bioreason.models.dl.processing_dl", "DLProcessor")
+    assert RefProcessor is not DLProcessor
     ref = RefProcessor(tokenizer=text_tok, dna_tokenizer=dna_tok)
     ref._merge_kwargs = lambda cls, tokenizer_init_kwargs=None, **kw: {"text_kwargs": dict(kw)}      # transformers 4.x routing
     want, got = _call(ref), _call(DLProcessor(tokenizer=text_tok, dna_tokenizer=dna_tok))
