@@ -230,6 +230,34 @@ def load_state_dict_tensors(model, tensors: Dict[str, torch.Tensor]) -> Tuple[li
     return missing, unexpected
 
 
+def load_adapter_dir(text_model, path: str) -> Tuple[list, list]:
+    """the tensors of a PEFT adapter directory (`adapter_model.safetensors` / `.bin`: `base_model.model.<hf name>.lora_A.weight`, adapter
+    name elided) into a text model that already carries adapters of that shape (`PeftModel.from_pretrained`, reason.py:430-438);
+    -> (missing, unexpected)"""
+    f = os.path.join(path, "adapter_model.safetensors")
+    if os.path.exists(f):
+        from safetensors.torch import load_file
+        tensors = load_file(f)
+    else:
+        tensors = torch.load(os.path.join(path, "adapter_model.bin"), map_location="cpu", weights_only=True)
+    own = {k: v for k, v in text_model.state_dict().items() if "lora_" in k}
+    seen, unexpected = set(), []
+    for k, v in tensors.items():
+        kk = k.replace(".lora_A.weight", ".lora_A.default.weight").replace(".lora_B.weight", ".lora_B.default.weight")
+        if kk.startswith("base_model.model."):
+            kk = kk[len("base_model.model."):]
+        if kk not in own:
+            unexpected.append(k)
+            continue
+        if tuple(own[kk].shape) != tuple(v.shape):
+            raise RuntimeError(f"bioreason_amd: shape mismatch for {k}: adapter {tuple(v.shape)} vs model {tuple(own[kk].shape)}")
+        own[kk].copy_(v.to(device=own[kk].device, dtype=own[kk].dtype))
+        seen.add(kk)
+    if text_model.arena is not None:
+        text_model.arena.pack()
+    return [k for k in own if k not in seen], unexpected
+
+
 def _infer_lora_r(tensors) -> Optional[int]:
     for k, v in tensors.items():
         if "lora_A" in k:

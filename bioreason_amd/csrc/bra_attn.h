@@ -40,6 +40,7 @@ struct AttnArgs {
     float* part_dk;
     float* part_dv;
     float scale;
+    BRA_DBG_FIELD(unsigned long long* probe;)    // k_attn4.hip, debug build: cycle stamps of one workgroup's hot loop (bra_attn_set_probe)
 };
 
 template <int HD>
@@ -93,7 +94,8 @@ __device__ __forceinline__ void attn_block_coords(int legacy, int heavy_is_last,
 }
 
 
-// k_attn4.hip: forward for grids of whole 256-query workgroups (no key split): 4 waves, one per SIMD, 64 queries per wave
+// k_attn4.hip: forward for grids of whole 256-query workgroups (no key split): 4 waves, one per SIMD, 64 queries per wave, every
+// wave with its own software pipeline over 32-key steps
 template <int HD> int launch_fwd4(const AttnArgs& a, bra_stream_t st);
 extern template int launch_fwd4<128>(const AttnArgs&, bra_stream_t);
 extern template int launch_fwd4<64>(const AttnArgs&, bra_stream_t);

@@ -915,8 +915,10 @@ using namespace bra;
 
 #ifdef BRA_EMU
 static int g_attn_fwd4 = 1;
+static unsigned long long* g_attn_probe = nullptr;
 #else
 static std::atomic<int> g_attn_fwd4{1};
+static std::atomic<unsigned long long*> g_attn_probe{nullptr};
 #endif
 
 template <int HD>
@@ -1044,6 +1046,9 @@ extern "C" int bra_attn_fwd(const void* q, long q_sb, long q_ss, long q_sh, cons
     a.lse = lse; a.kmask = (const uint8_t*)kmask;
     a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = Sq; a.Sk = Sk; a.causal = causal; a.q_off = q_off; a.scale = scale;
     a.legacy_order = g_attn_legacy_order;
+#if defined(BRA_DEBUG) && !defined(BRA_EMU)
+    a.probe = g_attn_probe;
+#endif
     bra_stream_t st = (bra_stream_t)stream;
     if (hd == 128) return launch_fwd<128>(a, st);
     if (hd == 64) return launch_fwd<64>(a, st);
@@ -1155,6 +1160,8 @@ extern "C" int bra_attn_bwd_split(const void* q, long q_sb, long q_ss, long q_sh
 extern "C" int bra_attn_set_block_order(int legacy) { g_attn_legacy_order = legacy ? 1 : 0; return 0; }
 // A/B knob: 0 = the 8-wave forward of rounds 1-5 for every shape, 1 (default) = the 4-wave kernel where it applies
 extern "C" int bra_attn_set_fwd4(int on) { g_attn_fwd4 = on ? 1 : 0; return 0; }
+// 80 x 8-byte device buffer that one workgroup of the next 4-wave forward launches fills with cycle counts (k_attn4.hip), or null
+extern "C" int bra_attn_set_probe(void* p) { g_attn_probe = (unsigned long long*)p; return 0; }
 #endif
 
 extern "C" int bra_attn_decode_nchunk(int len) { return (len + 127) / 128; }

@@ -110,6 +110,15 @@ class _EmbedScatterFn(torch.autograd.Function):
 
 
 class DNALLMModel(nn.Module):
+    def __setattr__(self, name, value):
+        # `model.text_model = get_peft_model(model.text_model, cfg)` (reason.py:388, train_dna_qwen.py:167): with peft_compat the same
+        # HIP object comes back; a REAL peft wrapper around it would be ignored by the engine — its adapters would train nothing —
+        # so it is refused here instead of accepted silently
+        if name == "text_model":
+            from .peft_compat import refuse_foreign_wrapper
+            refuse_foreign_wrapper(value)
+        super().__setattr__(name, value)
+
     def __init__(
         self,
         text_model_name: Union[str, Any],

@@ -34,9 +34,12 @@ int bra_gemm_set_glds_rows(int rows);
 /* attention forward / backward: 1 = launch order of rounds 1-3 (query / key block index fastest), 0 (default) = block index
  * slowest and, under a causal mask, heaviest blocks first (A/B measurements) */
 int bra_attn_set_block_order(int legacy);
-/* attention forward: 1 (default) = the 4-wave kernel with 64 queries per wave (k_attn4.hip) for grids of whole 256-query workgroups,
- * 0 = the 8-wave kernel of rounds 1-5 for every shape (A/B measurements) */
+/* attention forward for grids of whole 256-query workgroups: 1 (default) = the pipelined kernel of k_attn4.hip (4 waves of 64
+ * queries), 0 = the 8-wave kernel of rounds 1-5 for every shape (A/B measurements) */
 int bra_attn_set_fwd4(int on);
+/* 80 x 8-byte device buffer (or null) that one mid-sequence workgroup of the following 4-wave forward launches fills per wave with
+ * cycle counts of its hot loop: DMA wait, barrier, step 1, step 2, loop tail, iterations, whole kernel, steps (diagnostics) */
+int bra_attn_set_probe(void* buf);
 
 
 /* ---- timing probes of the token loop (k_decgemm.hip, k_decfused.hip) ---------------------------------------------------- */

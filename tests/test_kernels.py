@@ -9,7 +9,7 @@ import math
 import pytest
 import torch
 
-from bioreason_amd import ops
+from bioreason_amd import ops, _lib
 
 BF = torch.bfloat16
 
@@ -235,6 +235,55 @@ def test_attn_fwd_bwd(backend, hd, Hq, Hkv, Sq, Sk, causal, pad):
     assert rel(dk, kf.grad) < 1.5e-2
     assert rel(dv, vf.grad) < 1.5e-2
 
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,Sq,Sk,causal,pad,spike", [
+    (128, 2, 1, 700, 700, True, "left", True),        # eleven key tiles: the interleaved loop in both slot parities + its remainder trip
+    (128, 2, 2, 256, 700, True, "holes", False),      # a prefix (Sk > Sq) with masked keys in the middle of tiles
+    (128, 2, 2, 513, 513, True, None, True),          # a last workgroup with one live query row
+    (64, 2, 2, 400, 400, False, "right", True),
+    (64, 2, 1, 1024, 1024, False, None, False),       # the NT-v2 encoder's sequence length, every step unmasked
+    (128, 2, 1, 129, 300, True, "right", False),
+])
+def test_attn_fwd_pipelined_kernel(debug_backend, hd, Hq, Hkv, Sq, Sk, causal, pad, spike):
+    """k_attn4.hip (4 waves x 64 queries, software-pipelined 32-key steps, deferred rescaling) against the fp32 statement
+    (TF:qwen3:185-207, TF:esm:292-317) and against the 8-wave kernel of rounds 1-5 on the same inputs.  `spike`: a late key that
+    dominates some rows and an early one that dominates others — the running maximum grows long after the first step, so the rare
+    path (redo the step against the true maximum, rescale O and l) runs in the middle of the loop; rows without any visible key stay 0."""
+    backend = debug_backend
+    lib = _lib.get_lib()
+    B = 2
+    q, k, v = rnd(B, Sq, Hq, hd, dev=backend, seed=1), rnd(B, Sk, Hkv, hd, dev=backend, seed=2), rnd(B, Sk, Hkv, hd, dev=backend, seed=3)
+    if spike:
+        k[:, Sk - 40] = q[:, Sq - 3, :Hkv] * 6
+        k[:, 70] = q[:, Sq // 2, :Hkv] * 5
+    kmask = torch.ones(B, Sk, dtype=torch.uint8, device=backend)
+    if pad == "left":
+        kmask[0, :75] = 0
+    elif pad == "right":
+        kmask[1, Sk - 45:] = 0
+    elif pad == "holes":
+        kmask[0, 33:40] = 0
+        kmask[1, 200:290] = 0
+    km = kmask if pad else None
+    scale = hd ** -0.5
+    vt = ops.head_transpose(v)
+    res = {}
+    try:
+        for on in (1, 0):
+            lib.call("bra_attn_set_fwd4", on)
+            res[on] = ops.attn_fwd(q, k, vt, km, causal, scale, nsplit=1)
+    finally:
+        lib.call("bra_attn_set_fwd4", 1)
+    ro, rlse = _attn_ref(q.float(), k.float(), v.float(), km, causal, scale, Sk - Sq)
+    valid_q = torch.isfinite(rlse).cpu()
+    vq = valid_q.permute(0, 2, 1)[..., None]
+    (o4, l4), (o8, l8) = [(o.cpu(), l.cpu()) for o, l in (res[1], res[0])]
+    assert rel(o4 * vq, ro.cpu() * vq) < 6e-3
+    assert ((l4 - rlse.cpu()).abs() * valid_q).nan_to_num(0).max() < 2e-2
+    assert rel(o4 * vq, o8 * vq) < 5e-3                                  # two roundings of P apart at most
+    if (~vq).any():
+        assert o4[~vq.expand_as(o4)].float().abs().max() == 0 and torch.equal(l4[~valid_q], l8[~valid_q])
 
 
 @pytest.mark.parametrize("hd,Hq,Hkv,Sq,Sk,causal,pad,ns", [(128, 4, 2, 300, 300, True, "left", (2, 2)), (128, 2, 1, 256, 700, True, None, (3, 1)),
