@@ -162,7 +162,9 @@ class DNALLMModel(nn.Module):
                 self.text_model, self.text_tokenizer = Qwen3ForCausalLM(text_model_name, device=dev), None
             self.dna_model = encoder
             self.dna_tokenizer = Evo2Tokenizer(getattr(encoder, "tokenizer", None))
-            self.evo2_batched = bool(getattr(encoder, "supports_batch", True))
+            # one batched Evo2 call over left-padded rows only for an encoder that SAYS its rows are independent (`supports_batch =
+            # True`); anything else — a real `evo2.Evo2` included — gets the reference's call per sequence (dna_llm.py:126-140)
+            self.evo2_batched = bool(getattr(encoder, "supports_batch", False))
             self.processor = None
             if self.text_tokenizer is not None:
                 from .processing import DLProcessor
@@ -230,9 +232,9 @@ class DNALLMModel(nn.Module):
     def _run_encoder(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         """frozen encoder over token rows [m, Sd] -> hidden rows [m, Sd, H_dna] (bf16).  NT-v2: `hidden_states[-1]` of the HIP
         encoder (dna_llm.py:150-156).  Evo2 (dna_llm.py:123-146): the named layer's embeddings through Evo2's own call interface —
-        ONE call over the whole batch instead of the reference's call per sequence (the rows of a batch are independent in the
-        encoder, and the reference's per-sequence slices carry their left padding with them, so the rows are the same ones);
-        `evo2_batched=False` (or an encoder with `supports_batch = False`) restores the call per sequence."""
+        one call per sequence as the reference makes them, or, for an encoder that declares `supports_batch = True` (or with
+        `evo2_batched = True` set by the caller), ONE call over the whole batch (the reference's per-sequence slices carry their left
+        padding with them, so the rows are the same ones when the encoder treats rows independently)."""
         if not self.dna_is_evo2:
             return self.dna_model(input_ids=ids, attention_mask=mask).hidden_states[-1]
         layer = self.dna_embedding_layer

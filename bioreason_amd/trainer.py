@@ -112,6 +112,7 @@ class _DataParallelStep:
             raise ValueError("grad_allreduce_dtype must be 'fp32' or 'bf16'")
         self._grad_bf16 = grad_dtype == "bf16"
         self._bf_images: List = []
+        self._bf_cache: Dict[tuple, torch.Tensor] = {}      # bf16 transport images, one per arena range, allocated once
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         # `dp`: the collectives of the step are issued.  BRA_DP_SINGLE_RANK=1 issues them in a ONE-rank group too (each is then the
@@ -160,14 +161,24 @@ class _DataParallelStep:
             self._handles.append(dist.all_reduce(g, async_op=True))
             return
         a = self.model.arena
-        # the per-rank loss / KL / clip-ratio scalars (METRIC_SLOT) are averaged in fp32: cut them out of the bf16 image
+        # the per-rank loss / KL / clip-ratio scalars (METRIC_SLOT) are averaged in fp32 and never pass through a bf16 image: the
+        # bucket that holds the slot is cast, reduced and widened as the two ranges around it (no read of the slot by the cast
+        # while the fp32 all-reduce writes it, no restore afterwards).  The images are allocated once per range.
         m_lo = a._offsets.get(METRIC_SLOT)
         if m_lo is not None and lo <= m_lo < hi:
             self._handles.append(dist.all_reduce(a.grads[m_lo:m_lo + 64], async_op=True))
-        img = torch.empty(hi - lo, dtype=torch.bfloat16, device=g.device)
-        ops.cast_grad(g, img)
-        self._handles.append(dist.all_reduce(img, async_op=True))
-        self._bf_images.append((lo, hi, img, m_lo))
+            ranges = [(lo, m_lo), (m_lo + 64, hi)]
+        else:
+            ranges = [(lo, hi)]
+        for r_lo, r_hi in ranges:
+            if r_hi <= r_lo:
+                continue
+            img = self._bf_cache.get((r_lo, r_hi))
+            if img is None:
+                img = self._bf_cache[(r_lo, r_hi)] = torch.empty(r_hi - r_lo, dtype=torch.bfloat16, device=g.device)
+            ops.cast_grad(a.grads[r_lo:r_hi], img)
+            self._handles.append(dist.all_reduce(img, async_op=True))
+            self._bf_images.append((r_lo, r_hi, img))
 
     def _layer_done(self, li: int):
         cut = self._cuts.get(li)
@@ -191,13 +202,8 @@ class _DataParallelStep:
         for h in self._handles:
             h.wait()
         self._handles = []
-        for lo, hi_, img, m_lo in self._bf_images:              # widen the summed bf16 images back into the arena
-            keep = None
-            if m_lo is not None and lo <= m_lo < hi_:
-                keep = self.model.arena.grads[m_lo:m_lo + 64].clone()
+        for lo, hi_, img in self._bf_images:                    # widen the summed bf16 images back into the arena
             ops.cast_grad(img, g[lo:hi_])
-            if keep is not None:
-                self.model.arena.grads[m_lo:m_lo + 64].copy_(keep)
         self._bf_images = []
         return 1.0 / self.world
 
@@ -248,6 +254,23 @@ class GRPOStepRunner(_DataParallelStep):
 
     # ---- _generate_and_score_completions (:535-749) ---------------------------------------------------------------
     def generate_and_score(self, batch: Dict, timing: bool = False, mark=lambda n: None, defer_ref_join: bool = False) -> Dict:
+        """(the fp8 rollout switch of the config is in force for THIS call only: a `model.rollout_fp8` the user set by hand, or left
+        unset, is what later `generate()` / evaluation calls see again)"""
+        tm = self.model.text_model
+        had, prev = hasattr(tm, "rollout_fp8"), getattr(tm, "rollout_fp8", False)
+        tm.rollout_fp8 = bool(prev) or bool(self.cfg.rollout_fp8)        # read by generation.rollout_weights / the decode states
+        try:
+            return self._generate_and_score(batch, timing, mark, defer_ref_join)
+        finally:
+            if had:
+                tm.rollout_fp8 = prev
+            else:
+                try:
+                    delattr(tm, "rollout_fp8")
+                except AttributeError:
+                    pass
+
+    def _generate_and_score(self, batch: Dict, timing: bool = False, mark=lambda n: None, defer_ref_join: bool = False) -> Dict:
         """`defer_ref_join` (step() only): the reference pass may still be running on its side stream when this returns — the
         returned dict then carries the stream under "ref_join" and `compute_loss` joins it just before the loss reads
         `ref_per_token_logps`.  Every other caller gets the join here: whatever it reads from the dict is complete on the
@@ -255,7 +278,6 @@ class GRPOStepRunner(_DataParallelStep):
         m, c = self.model, self.cfg
         dev = batch["input_ids"].device
         mm = {"dna_tokenized": batch["dna_tokenized"], "batch_idx_map": batch["batch_idx_map"], "dna_alias": batch.get("dna_alias")}
-        m.text_model.rollout_fp8 = bool(c.rollout_fp8)                 # read by generation.rollout_weights / the decode states
         wside = None
         if (c.overlap_rollout_weights and dev.type == "cuda" and not timing and c.rollout_shared_prefix
                 and batch.get("prompt_alias") is not None):
