@@ -100,4 +100,9 @@ template <int HD> int launch_fwd4(const AttnArgs& a, bra_stream_t st);
 extern template int launch_fwd4<128>(const AttnArgs&, bra_stream_t);
 extern template int launch_fwd4<64>(const AttnArgs&, bra_stream_t);
 
+// k_attn4b.hip: the dQ kernel in the same structure (unit = 32-key step x query block)
+template <int HD> int launch_dq4(const AttnArgs& a, bra_stream_t st);
+extern template int launch_dq4<128>(const AttnArgs&, bra_stream_t);
+extern template int launch_dq4<64>(const AttnArgs&, bra_stream_t);
+
 }  // namespace bra

@@ -98,10 +98,12 @@ __device__ __forceinline__ void dma16(const BufDesc& d, unsigned voff, unsigned 
 __device__ __forceinline__ void to_agpr(u32x4&) {}
 __device__ __forceinline__ void pin_u32_f32(uint32_t&, float&, float&) {}
 __device__ __forceinline__ void pin_f32(float&) {}
+__device__ __forceinline__ void pin_u32(uint32_t&) {}
 #else
 __device__ __forceinline__ void to_agpr(u32x4& v) { asm volatile("" : "+a"(v)); }
 __device__ __forceinline__ void pin_u32_f32(uint32_t& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
 __device__ __forceinline__ void pin_f32(float& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pin_u32(uint32_t& a) { asm volatile("" : "+v"(a)); }
 #endif
 
 }  // namespace bra

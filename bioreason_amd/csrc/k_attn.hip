@@ -952,9 +952,19 @@ static int launch_sum_parts(const float* part, int ns, int B, int H, int S, bf16
     return BRA_LAUNCH_STATUS();
 }
 
+#ifdef BRA_EMU
+static int g_attn_bwd4 = 1;
+#else
+static std::atomic<int> g_attn_bwd4{1};
+#endif
+
 template <int HD>
 static int launch_dq(const AttnArgs& a, bra_stream_t st) {
     const size_t smem = 2 * (2 * Tile<HD>::KBYTES + Tile<HD>::TBYTES);
+    // whole 256-query workgroups, no key split: the pipelined 4-wave kernel (k_attn4b.hip)
+    if constexpr (HD >= 64) {
+        if (a.Sq > 128 && a.nsplit <= 1 && (g_attn_bwd4 & 1)) return launch_dq4<HD>(a, st);
+    }
     if (HD >= 64 && a.Sq > 128) {
         const int ns = a.nsplit > 1 ? a.nsplit : 1;
         BRA_ALLOW_SMEM((attn_bwd_dq_kernel<HD, (HD >= 64 ? 8 : 4)>), smem);
@@ -1160,6 +1170,8 @@ extern "C" int bra_attn_bwd_split(const void* q, long q_sb, long q_ss, long q_sh
 extern "C" int bra_attn_set_block_order(int legacy) { g_attn_legacy_order = legacy ? 1 : 0; return 0; }
 // A/B knob: 0 = the 8-wave forward of rounds 1-5 for every shape, 1 (default) = the 4-wave kernel where it applies
 extern "C" int bra_attn_set_fwd4(int on) { g_attn_fwd4 = on ? 1 : 0; return 0; }
+// attention backward: bit 0 = the pipelined dQ kernel (k_attn4b.hip) where it applies (default 1), 0 = the kernels of rounds 1-5
+extern "C" int bra_attn_set_bwd4(int mask) { g_attn_bwd4 = mask; return 0; }
 // 80 x 8-byte device buffer that one workgroup of the next 4-wave forward launches fills with cycle counts (k_attn4.hip), or null
 extern "C" int bra_attn_set_probe(void* p) { g_attn_probe = (unsigned long long*)p; return 0; }
 #endif

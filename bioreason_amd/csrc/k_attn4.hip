@@ -176,14 +176,14 @@ __device__ __forceinline__ void step4(const Ctx4<HD>& cx, const f32x16 (&s_cur)[
     u32x4 vfr[2][FB], kfr[2][FB];                     // [block parity][fragment of the block]
     // ---- phase A: PV(j-1) ------------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int f = 0; f < FB; ++f) vfr[0][f] = VPRE_IN ? vpre[f] : read_vfrag<HD>(cx, vt, kbv, f);
+    for (int f = FB - 1; f >= 0; --f) vfr[0][f] = VPRE_IN ? vpre[f] : read_vfrag<HD>(cx, vt, kbv, f);
 #define BRA_A_GROUP(G)                                                                                                     \
     if constexpr ((G) < T::NGA) {                                                                                          \
         constexpr int f_ = (G) / NQB, qb_ = (G) % NQB, s2_ = f_ / T::DB, db_ = f_ % T::DB, blk_ = f_ / FB;                  \
         mfma_o(o[qb_][db_], vfr[blk_ & 1][f_ % FB], p_prev[qb_][s2_]);                                                     \
         if constexpr ((G) % (2 * NQB) == 0) {                                                                              \
             sched_fence();                                                                                                 \
-            _Pragma("unroll") for (int u_ = 0; u_ < FB; ++u_) {                                                            \
+            _Pragma("unroll") for (int u_ = FB - 1; u_ >= 0; --u_) {      /* (youngest first: one wait per block) */         \
                 if constexpr ((G) + 2 * NQB < T::NGA) vfr[(blk_ + 1) & 1][u_] = read_vfrag<HD>(cx, vt, kbv, (blk_ + 1) * FB + u_); \
                 else kfr[0][u_] = read_kfrag<HD>(cx, kt, kbk, u_);                                                         \
             }                                                                                                              \
@@ -205,7 +205,7 @@ __device__ __forceinline__ void step4(const Ctx4<HD>& cx, const f32x16 (&s_cur)[
         else s_nxt[qb_] = mfma_32x32x16(kfr[blk_ & 1][ds_ % FB], qf[qb_][ds_], s_nxt[qb_]);                               \
         if constexpr ((G) % (2 * NQB) == 0) {                                                                              \
             sched_fence();                                                                                                 \
-            _Pragma("unroll") for (int u_ = 0; u_ < FB; ++u_) {                                                            \
+            _Pragma("unroll") for (int u_ = FB - 1; u_ >= 0; --u_) {                                                        \
                 if constexpr ((G) + 2 * NQB < T::NGB) kfr[(blk_ + 1) & 1][u_] = read_kfrag<HD>(cx, kt, kbk, (blk_ + 1) * FB + u_); \
                 else if constexpr (VPRE_OUT) vpre[u_] = read_vfrag<HD>(cx, vt_nxt, kbv_nxt, u_);                           \
             }                                                                                                              \

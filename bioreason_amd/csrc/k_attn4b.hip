@@ -1,0 +1,423 @@
+// k_attn4b.hip — attention BACKWARD for gfx950, second generation (the dQ kernel): the structure of k_attn4.hip — 4 waves per
+// workgroup, one per SIMD, 64 queries (two 32-row blocks A / B) per wave, every wave its own software pipeline, the elementwise
+// work placed by hand between the MFMAs — applied to
+//   S^T = K Q^T,  dP^T = V dO^T   ([key][q], query on lanes)
+//   dS^T = P^T * (dP^T - delta[q]) * scale,   P^T = exp2(S^T sc - lse2[q])
+//   dQ^T[d][q] += K^T[d][key] . dS^T[key][q]                                            (TF:qwen3:185-207 backward, TF:esm:292-317)
+// The pipeline's unit is (32-key step j, query block x), u = 2 j + x:
+//   phase(u):   MFMAs  dQ(u - 1)  [8: K^T fragments x the packed dS of the previous unit]
+//                      S, dP(u + 1) [16: K / V row fragments x this block's Q / dO fragments, which live in AGPRs]
+//               VALU   the 16 + 16 scores of unit u -> its packed dS                         (4.5 instructions per element)
+// i.e. 24 MFMAs (~790 cycles) beside ~100 issue slots: the matrix pipe is the bound, where the round 1-5 kernel (8 waves in lockstep
+// per tile, every wave re-reading the tile) ran at 0.15 of it.  Only one block's S / dP is live beside the other's (64 registers),
+// which is what lets Q, dO (128 AGPRs) and the dQ accumulators (128 AGPRs) stay resident.
+// Staging as in the forward: K, V (row tiles) and K^T (transposed image) by LDS-DMA through buffer descriptors, one tile ahead of
+// the barrier that publishes them, one barrier per 64-key tile; K / V in two slots, K^T in three (its last reader is half a tile
+// behind the row tiles').  Key bits 2 / 3 swapped on the row side (k_attn4.hip): a dS fragment is 8 consecutive keys.
+#include "bra_device.h"
+#include "bra_api_internal.h"
+#include "bra_attn.h"
+#include "bra_attn4.h"
+
+namespace bra {
+
+template <int HD>
+struct TB4 {
+    static constexpr int CH = HD / 8, DS = HD / 16, DB = HD / 32;
+    static constexpr int RSH = HD == 128 ? 0 : (HD == 64 ? 1 : 2);
+    static constexpr int KBYTES = 64 * HD * 2, TBYTES = HD * 128;
+    static constexpr int RSLOT = 2 * KBYTES;          // row tiles of one key tile: [K | V]
+    static constexpr int OFF_T = 2 * RSLOT;           // K^T ring behind the two row slots
+    static constexpr int SMEM = 2 * RSLOT + 3 * TBYTES;
+    static constexpr int KPW = KBYTES / 4096, TPW = TBYTES / 4096;      // DMA pieces per wave: K, V (KPW each), K^T (TPW)
+    static constexpr int NDMA = 2 * KPW + TPW;
+    static constexpr int NDQ = 2 * DB;                // MFMAs of dQ(u - 1)
+    static constexpr int NSD = 2 * DS;                // MFMAs of S, dP(u + 1)
+    static constexpr int NG = NDQ + NSD;
+    static constexpr int NITEM = 9 * (8 + 2);         // item slots of one unit's elementwise work (el_item)
+    static constexpr int QD = 1;
+    static constexpr int item0(int G, bool dma) {
+        if (!dma) return (G * NITEM) / NG;
+        return G <= NDMA ? G * QD : NDMA * QD + ((G - NDMA) * (NITEM - NDMA * QD)) / (NG - NDMA);
+    }
+};
+
+// One unit's elementwise work as single-instruction items, software-pipelined through slots of nine (k_attn4.hip sm_item): slot n
+// holds the four arguments of pair n (S and dP side), the two exponentials of pair n - 1, the two products and the pack of n - 2.
+struct ElState {
+    float x[2][2], t[2][2];     // by pair parity: exp2 arguments, (dP * scale - delta * scale)
+    float e[2][2], tt[2][2];
+};
+template <int K>
+__device__ __forceinline__ void el_item(const f32x16& s, const f32x16& dp, u32x4 (&ds)[2], ElState& st, float lse2, float dlt_s, float sc, float scale) {
+    constexpr int NP = 8, n = K / 9, u = K % 9;
+#ifdef BRA_A4_NOSM        // (timing probe: no elementwise work — garbage results)
+    return;
+#endif
+    if constexpr (u < 4) {
+        if constexpr (n < NP) {
+            if constexpr (u < 2) { st.x[n & 1][u] = fmaf(s[2 * n + u], sc, -lse2); pin_f32(st.x[n & 1][u]); }
+            else { st.t[n & 1][u - 2] = fmaf(dp[2 * n + u - 2], scale, -dlt_s); pin_f32(st.t[n & 1][u - 2]); }
+        }
+    } else if constexpr (u < 6) {
+        if constexpr (n >= 1 && n <= NP) {
+            st.e[(n - 1) & 1][u - 4] = fast_exp2(st.x[(n - 1) & 1][u - 4]); pin_f32(st.e[(n - 1) & 1][u - 4]);
+            st.tt[(n - 1) & 1][u - 4] = st.t[(n - 1) & 1][u - 4];
+        }
+    } else if constexpr (n >= 2 && n <= NP + 1) {
+        constexpr int pr = n - 2;
+        if constexpr (u < 8) { st.e[pr & 1][u - 6] *= st.tt[pr & 1][u - 6]; pin_f32(st.e[pr & 1][u - 6]); }
+        else {
+            uint32_t w2 = pack_bf2(st.e[pr & 1][0], st.e[pr & 1][1]);
+            pin_u32(w2);
+            constexpr int g = pr >> 2, c4 = pr & 3;
+            if constexpr (c4 == 0) ds[g].x = w2; else if constexpr (c4 == 1) ds[g].y = w2;
+            else if constexpr (c4 == 2) ds[g].z = w2; else ds[g].w = w2;
+        }
+    }
+}
+template <int LO, int HI>
+__device__ __forceinline__ void el_items(const f32x16& s, const f32x16& dp, u32x4 (&ds)[2], ElState& st, float lse2, float dlt_s, float sc, float scale) {
+    if constexpr (LO < HI) {
+        el_item<LO>(s, dp, ds, st, lse2, dlt_s, sc, scale);
+        el_items<LO + 1, HI>(s, dp, ds, st, lse2, dlt_s, sc, scale);
+    }
+}
+
+template <int HD>
+struct CtxB4 {
+    unsigned kfo[HD / 16];        // LDS byte offset of this lane's K (and, + KBYTES, V) row fragment of d-step ds in a 32-key half
+    unsigned tfo[2][2];           // LDS byte offset of this lane's K^T fragment of (key half kb, k-slot group s2), d block 0, in a K^T tile
+    float sc, scale;
+};
+
+// phase(u) of the hot loop.  s_cur / dp_cur: scores of unit u (complete); s_nxt / dp_nxt: receive unit u + 1; ds_prev: packed dS of
+// unit u - 1 (accumulated into dq_prev = the dQ accumulators of ITS query block); ds_cur: receives unit u's.
+//   ktp: K^T tile of unit u - 1's step (kbt = its key half); rows: [K | V] row tiles of unit u + 1's step (kbr = its key half);
+//   qf / dof: Q / dO fragments of unit u + 1's block.
+// Fragment reads in blocks of four behind a wait, first used four MFMAs later (k_attn4.hip step4).
+template <int HD, bool DMA, typename DmaFn>
+__device__ __forceinline__ void phase4(const CtxB4<HD>& cx, const f32x16& s_cur, const f32x16& dp_cur, f32x16& s_nxt, f32x16& dp_nxt,
+                                       const u32x4 (&ds_prev)[2], u32x4 (&ds_cur)[2], f32x16 (&dq_prev)[HD / 32],
+                                       const u32x4 (&qf)[HD / 16], const u32x4 (&dof)[HD / 16], float lse2, float dlt_s,
+                                       const char* ktp, int kbt, const char* rows, int kbr, DmaFn&& dma) {
+    using T = TB4<HD>;
+    ElState st;
+    u32x4 fr[2][4];                                   // [block parity][fragment of the block]
+    // fragment f of the phase: f < NDQ: K^T fragment (s2 = f / DB, db = f % DB); else pair index p = (f - NDQ): K row (p even) / V row
+    // (p odd) fragment of d-step p / 2
+    auto read_frag = [&](int f) -> u32x4 {
+#ifdef BRA_A4_NOLDS       // (timing probe: no fragment reads — garbage results)
+        { u32x4 z = {cx.kfo[0], cx.kfo[1], cx.tfo[0][0], 0x3c003c00u}; return z; }
+#endif
+        if (f < T::NDQ) return ld16(ktp + cx.tfo[kbt][f / T::DB] + (f % T::DB) * 4096);
+        const int p = f - T::NDQ;
+        return ld16(rows + cx.kfo[p >> 1] + (p & 1) * T::KBYTES + kbr * (32 * HD * 2));
+    };
+#pragma unroll
+    for (int f = 3; f >= 0; --f) fr[0][f] = read_frag(f);
+#define BRA_P_GROUP(G)                                                                                                     \
+    if constexpr ((G) < T::NG) {                                                                                           \
+        constexpr int blk_ = (G) / 4;                                                                                      \
+        if constexpr ((G) < T::NDQ) {                                                                                      \
+            constexpr int s2_ = (G) / T::DB, db_ = (G) % T::DB;                                                            \
+            mfma_o(dq_prev[db_], fr[blk_ & 1][(G) % 4], ds_prev[s2_]);                                                     \
+        } else {                                                                                                           \
+            constexpr int p_ = (G) - T::NDQ, ds_ = p_ >> 1;                                                                \
+            if constexpr ((p_ & 1) == 0) {                                                                                 \
+                if constexpr (ds_ == 0) { f32x16 z_ = {}; s_nxt = mfma_32x32x16(fr[blk_ & 1][(G) % 4], qf[0], z_); }        \
+                else s_nxt = mfma_32x32x16(fr[blk_ & 1][(G) % 4], qf[ds_], s_nxt);                                         \
+            } else {                                                                                                       \
+                if constexpr (ds_ == 0) { f32x16 z_ = {}; dp_nxt = mfma_32x32x16(fr[blk_ & 1][(G) % 4], dof[0], z_); }      \
+                else dp_nxt = mfma_32x32x16(fr[blk_ & 1][(G) % 4], dof[ds_], dp_nxt);                                      \
+            }                                                                                                              \
+        }                                                                                                                  \
+        if constexpr ((G) % 4 == 0 && (G) + 4 < T::NG) {                                                                   \
+            sched_fence();                                                                                                 \
+            /* (youngest first: LDS reads return in order, so the next block's FIRST MFMA waits for the read issued last and the */ \
+            /*  other three need no wait of their own) */                                                                  \
+            _Pragma("unroll") for (int u_ = 3; u_ >= 0; --u_) fr[(blk_ + 1) & 1][u_] = read_frag((G) + 4 + u_);            \
+        }                                                                                                                  \
+        if constexpr (DMA && (G) < T::NDMA && !kNoDma) dma(G);                                                             \
+        el_items<T::item0(G, DMA), T::item0((G) + 1, DMA)>(s_cur, dp_cur, ds_cur, st, lse2, dlt_s, cx.sc, cx.scale);        \
+        sched_fence();                                                                                                     \
+    }
+    BRA_P_GROUP(0) BRA_P_GROUP(1) BRA_P_GROUP(2) BRA_P_GROUP(3) BRA_P_GROUP(4) BRA_P_GROUP(5) BRA_P_GROUP(6) BRA_P_GROUP(7)
+    BRA_P_GROUP(8) BRA_P_GROUP(9) BRA_P_GROUP(10) BRA_P_GROUP(11) BRA_P_GROUP(12) BRA_P_GROUP(13) BRA_P_GROUP(14) BRA_P_GROUP(15)
+    BRA_P_GROUP(16) BRA_P_GROUP(17) BRA_P_GROUP(18) BRA_P_GROUP(19) BRA_P_GROUP(20) BRA_P_GROUP(21) BRA_P_GROUP(22) BRA_P_GROUP(23)
+#undef BRA_P_GROUP
+}
+
+// the same phase without the interleave, with run-time switches (block prologue / tail)
+template <int HD>
+__device__ __forceinline__ void cold_phase4(const CtxB4<HD>& cx, const f32x16& s_cur, const f32x16& dp_cur, f32x16& s_nxt, f32x16& dp_nxt,
+                                            const u32x4 (&ds_prev)[2], u32x4 (&ds_cur)[2], f32x16 (&dq_prev)[HD / 32],
+                                            const u32x4 (&qf)[HD / 16], const u32x4 (&dof)[HD / 16], float lse2, float dlt_s,
+                                            const char* ktp, int kbt, const char* rows, int kbr, bool do_dq, bool do_el, bool do_sdp) {
+    using T = TB4<HD>;
+    if (do_dq) {
+#pragma unroll
+        for (int f = 0; f < T::NDQ; ++f) mfma_o(dq_prev[f % T::DB], ld16(ktp + cx.tfo[kbt][f / T::DB] + (f % T::DB) * 4096), ds_prev[f / T::DB]);
+        mfma_drain();
+    }
+    if (do_el) {
+        float e[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e[r] = fast_exp2(fmaf(s_cur[r], cx.sc, -lse2)) * fmaf(dp_cur[r], cx.scale, -dlt_s);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            ds_cur[g].x = pack_bf2(e[8 * g + 0], e[8 * g + 1]); ds_cur[g].y = pack_bf2(e[8 * g + 2], e[8 * g + 3]);
+            ds_cur[g].z = pack_bf2(e[8 * g + 4], e[8 * g + 5]); ds_cur[g].w = pack_bf2(e[8 * g + 6], e[8 * g + 7]);
+        }
+    }
+    if (do_sdp) {
+#pragma unroll
+        for (int ds = 0; ds < T::DS; ++ds) {
+            const u32x4 kf = ld16(rows + cx.kfo[ds] + kbr * (32 * HD * 2));
+            const u32x4 vf = ld16(rows + cx.kfo[ds] + T::KBYTES + kbr * (32 * HD * 2));
+            if (ds == 0) { f32x16 z = {}; s_nxt = mfma_32x32x16(kf, qf[0], z); dp_nxt = mfma_32x32x16(vf, dof[0], z); }
+            else { s_nxt = mfma_32x32x16(kf, qf[ds], s_nxt); dp_nxt = mfma_32x32x16(vf, dof[ds], dp_nxt); }
+        }
+    }
+}
+
+// scores of masked keys -> kMasked (one block; qb_off = 32 for block B)
+__device__ __forceinline__ void mask_scores4b(f32x16& s, uint32_t valid32, bool causal, int lim0, int h) {
+    const uint32_t vb = valid32 >> (8 * h);
+    const int lim = lim0 - 8 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int kk = 16 * (r >> 3) + (r & 7);
+        bool ok = (vb >> kk) & 1u;
+        if (causal) ok = ok && kk <= lim;
+        s[r] = ok ? s[r] : kMasked;
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_dq4_kernel(AttnArgs a) {
+    using T = TB4<HD>;
+    BRA_DYN_SMEM(smem);                               // [2][K tile | V tile] [3][K^T tile]
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6), h = lane >> 5, l31 = lane & 31;
+    int bx_, hq, b;
+    attn_block_coords(0, a.causal, bx_, hq, b);
+    const int hkv = hq / (a.Hq / a.Hkv);
+    const int q0 = bx_ * 256, qw0 = q0 + wave * 64;
+    const char* kb_ = uniform_ptr(a.k + b * a.k_sb + hkv * a.k_sh);
+    const char* vb_ = uniform_ptr(a.v + b * a.v_sb + hkv * a.v_sh);
+    const char* ktb = uniform_ptr(a.kt + b * a.kt_sb + hkv * a.kt_sh);
+
+    CtxB4<HD> cx;
+    cx.sc = a.scale * kLog2e;
+    cx.scale = a.scale;
+    {
+        const int row = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);      // key bits 2 / 3 swapped (k_attn4.hip)
+        const int sw = (row >> T::RSH) & (T::CH - 1);
+#pragma unroll
+        for (int ds = 0; ds < T::DS; ++ds) cx.kfo[ds] = (unsigned)(row * (HD * 2) + (((2 * ds + h) ^ sw) << 4));
+        const int swv = (l31 >> 1) & 7;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) cx.tfo[kb][s2] = (unsigned)(l31 * 128 + (((4 * kb + 2 * s2 + h) ^ swv) << 4));
+    }
+    // DMA sources (byte offsets inside the (batch, kv-head) slices; rows beyond Sk are outside the descriptors: zeros)
+    const int k_sbytes = (int)a.k_ss * 2, v_sbytes = (int)a.v_ss * 2;
+    const BufDesc kdesc = make_bufdesc(kb_, (unsigned)((a.Sk - 1) * k_sbytes + HD * 2));
+    const BufDesc vdesc = make_bufdesc(vb_, (unsigned)((a.Sk - 1) * v_sbytes + HD * 2));
+    const BufDesc tdesc = make_bufdesc(ktb, (unsigned)(HD * (int)a.kt_sd * 2));
+    unsigned ksrc[T::KPW], vsrc[T::KPW], tsrc[T::TPW];
+#pragma unroll
+    for (int i = 0; i < T::KPW; ++i) {
+        const int u = 64 * (wave * T::KPW + i) + lane, row = u / T::CH, c = (u % T::CH) ^ ((row >> T::RSH) & (T::CH - 1));
+        ksrc[i] = attn_mul24(row, k_sbytes) + (unsigned)(c * 16);
+        vsrc[i] = attn_mul24(row, v_sbytes) + (unsigned)(c * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < T::TPW; ++i) {
+        const int u = 64 * (wave * T::TPW + i) + lane, d = u >> 3, c = (u & 7) ^ ((d >> 1) & 7);
+        tsrc[i] = attn_mul24(d, (int)a.kt_sd * 2) + (unsigned)(c * 16);
+    }
+    auto dma_piece = [&](int i, int tile, int rslot, int tslot) {
+        if (i < T::KPW) dma16(kdesc, ksrc[i], (unsigned)(tile * 64) * (unsigned)k_sbytes, smem + rslot * T::RSLOT + (wave * T::KPW + i) * 1024);
+        else if (i < 2 * T::KPW) dma16(vdesc, vsrc[i - T::KPW], (unsigned)(tile * 64) * (unsigned)v_sbytes,
+                                       smem + rslot * T::RSLOT + T::KBYTES + (wave * T::KPW + i - T::KPW) * 1024);
+        else dma16(tdesc, tsrc[i - 2 * T::KPW], (unsigned)(tile * 128), smem + T::OFF_T + tslot * T::TBYTES + (wave * T::TPW + i - 2 * T::KPW) * 1024);
+    };
+
+    int kv_end = a.Sk;
+    if (a.causal) { const int last = q0 + 255 + a.q_off + 1; kv_end = last < kv_end ? last : kv_end; }
+    const int ntile = kv_end > 0 ? (kv_end + 63) / 64 : 0;
+    int nunit_w = 0;                                  // this wave's units: two per 32-key step that holds a key one of its queries sees
+    if (qw0 < a.Sq && ntile > 0) {
+        int lastq = qw0 + 63; lastq = lastq < a.Sq ? lastq : a.Sq - 1;
+        int lastk = a.causal ? lastq + a.q_off : a.Sk - 1;
+        lastk = lastk < a.Sk ? lastk : a.Sk - 1;
+        int ns = lastk >= 0 ? lastk / 32 + 1 : 0;
+        ns = ns < 2 * ntile ? ns : 2 * ntile;
+        nunit_w = 2 * ns;
+    }
+
+    // Q / dO fragments and the row statistics of this lane's two queries
+    u32x4 qf[2][T::DS], dof[2][T::DS];
+    float lse2[2], dlt_s[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int qr = qw0 + 32 * qb + l31;
+        qr = qr < a.Sq ? qr : a.Sq - 1;
+        const bf16_t* qp = a.q + b * a.q_sb + (long)qr * a.q_ss + hq * a.q_sh;
+        const bf16_t* dp = a.dout + b * a.do_sb + (long)qr * a.do_ss + hq * a.do_sh;
+#pragma unroll
+        for (int ds = 0; ds < T::DS; ++ds) { qf[qb][ds] = ld16(qp + ds * 16 + 8 * h); dof[qb][ds] = ld16(dp + ds * 16 + 8 * h); }
+        const long lidx = ((long)b * a.Hq + hq) * a.Sq + qr;
+        lse2[qb] = a.lse[lidx] * kLog2e;
+        dlt_s[qb] = a.delta[lidx] * a.scale;
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int ds = 0; ds < T::DS; ++ds) { to_agpr(qf[qb][ds]); to_agpr(dof[qb][ds]); }
+    f32x16 dq[2][T::DB];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int i = 0; i < T::DB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[qb][i][r] = 0.f;
+
+    auto mask_byte = [&](int tile) -> int {
+        int kj = tile * 64 + lane;
+        const bool in = kj < a.Sk;
+        kj = in ? kj : a.Sk - 1;
+        int v = a.kmask ? (int)a.kmask[(long)b * a.Sk + kj] : 1;
+        return in ? v : 0;
+    };
+
+    f32x16 s[2], dp[2];                               // scores / dP of the unit in flight of block A / B
+    u32x4 dsp[2][2];                                  // packed dS of the last unit of block A / B
+    if (ntile > 0) {
+#pragma unroll
+        for (int i = 0; i < T::NDMA; ++i) dma_piece(i, 0, 0, 0);
+        int mb0 = mask_byte(0), mb1 = mask_byte(1);
+        wait_vmcnt<0>();
+        raw_barrier();
+        {
+            const int t1 = ntile > 1 ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < T::NDMA; ++i) dma_piece(i, t1, 1, 1);
+        }
+        uint64_t vcur = wave_ballot(mb0 != 0), vnext = wave_ballot(mb1 != 0);      // validity words of tiles (u / 4) and the next
+        int mb_pend = 0;
+        auto noop = [](int) {};
+        // masks of unit u (step j = u / 2, block x = u & 1), applied to its finished scores; vword = the validity word of tile j / 2
+        auto prep = [&](f32x16& sx, int u, uint64_t vword) {
+            const int j = u >> 1, x = u & 1, kv0s = 32 * j;
+            const uint32_t v32 = (uint32_t)(vword >> (32 * (j & 1)));
+            const bool full = v32 == 0xffffffffu && (!a.causal || kv0s + 31 <= qw0 + 32 * x + a.q_off);
+            if (!full) mask_scores4b(sx, v32, a.causal != 0, qw0 + 32 * x + l31 + a.q_off - kv0s, opaque_i(lane) >> 5);
+        };
+        const char* const tring = smem + T::OFF_T;
+        // generic phase(u): locations from u (cold form)
+        auto cold = [&](int u, uint64_t vw) {
+            const int x = u & 1;
+            const bool do_dq = u >= 1 && u <= nunit_w, do_el = u < nunit_w, do_sdp = u + 1 < nunit_w;
+            const int up = u - 1, jp = up >> 1, un = u + 1, jn = un >> 1;
+            const char* ktp = tring + (((jp >> 1) % 3 + 3) % 3) * T::TBYTES;
+            const char* rows = smem + ((jn >> 1) & 1) * T::RSLOT;
+            if (do_el) { if (x == 0) prep(s[0], u, vw); else prep(s[1], u, vw); }
+            if (x == 0) cold_phase4<HD>(cx, s[0], dp[0], s[1], dp[1], dsp[1], dsp[0], dq[1], qf[1], dof[1], lse2[0], dlt_s[0], ktp, jp & 1, rows, jn & 1,
+                                        do_dq, do_el, do_sdp);
+            else cold_phase4<HD>(cx, s[1], dp[1], s[0], dp[0], dsp[0], dsp[1], dq[0], qf[0], dof[0], lse2[1], dlt_s[1], ktp, jp & 1, rows, jn & 1,
+                                 do_dq, do_el, do_sdp);
+        };
+        if (nunit_w > 0) {
+            // S, dP of unit 0 (a phase that does nothing else), then phases 0 .. 2
+            cold_phase4<HD>(cx, s[1], dp[1], s[0], dp[0], dsp[0], dsp[1], dq[0], qf[0], dof[0], lse2[1], dlt_s[1], tring, 0, smem, 0, false, false, true);
+            cold(0, vcur); cold(1, vcur); cold(2, vcur);
+        }
+        // iteration t: phases 4 t + 3 .. 4 t + 6.  Reads K^T(t) half 1, K^T(t + 1) half 0, the row tiles of t + 1; issues tile t + 2.
+        // Hot loop: all four phases are full phases of this wave (4 t + 7 < nunit_w).
+        const int tmain = nunit_w >= 8 ? (nunit_w - 4) / 4 : 0;
+        int t = 0;
+        // (tile parities compile-time: row slot = tile & 1; the K^T ring has three slots, so the hot loop is unrolled over six tiles'
+        //  worth of slot indices by passing the ring slot as a run-time byte offset instead: only the K^T fragments pay a v_add)
+#define BRA_HOT_ITER(PAR)                                                                                                    \
+        {                                                                                                                  \
+            wait_vmcnt<0>();                                                                                               \
+            raw_barrier();                                                                                                 \
+            mb_pend = mask_byte(t + 2);                                                                                    \
+            int tn = t + 2;                                                                                                \
+            tn = tn < ntile ? tn : ntile - 1;                                                                              \
+            const int ts_new = (t + 2) % 3;                                                                                \
+            auto dma = [&](int i) { dma_piece(i, tn, PAR, ts_new); };                                                      \
+            const char* kt_t = tring + (t % 3) * T::TBYTES;                /* K^T(t) */                                   \
+            const char* kt_n = tring + ((t + 1) % 3) * T::TBYTES;          /* K^T(t + 1) */                               \
+            const char* rows_n = smem + (1 - (PAR)) * T::RSLOT;            /* K, V of tile t + 1 */                        \
+            /* phase 4 t + 3 (x = 1, step 2 t + 1): dQ of (2 t + 1, A); S, dP of (2 t + 2, A) */                            \
+            prep(s[1], 4 * t + 3, vcur);                                                                                   \
+            phase4<HD, true>(cx, s[1], dp[1], s[0], dp[0], dsp[0], dsp[1], dq[0], qf[0], dof[0], lse2[1], dlt_s[1], kt_t, 1, rows_n, 0, dma);   \
+            /* phase 4 t + 4 (x = 0, step 2 t + 2): dQ of (2 t + 1, B); S, dP of (2 t + 2, B) */                            \
+            prep(s[0], 4 * t + 4, vnext);                                                                                  \
+            phase4<HD, false>(cx, s[0], dp[0], s[1], dp[1], dsp[1], dsp[0], dq[1], qf[1], dof[1], lse2[0], dlt_s[0], kt_t, 1, rows_n, 0, noop); \
+            /* phase 4 t + 5 (x = 1, step 2 t + 2): dQ of (2 t + 2, A); S, dP of (2 t + 3, A) */                            \
+            prep(s[1], 4 * t + 5, vnext);                                                                                  \
+            phase4<HD, false>(cx, s[1], dp[1], s[0], dp[0], dsp[0], dsp[1], dq[0], qf[0], dof[0], lse2[1], dlt_s[1], kt_n, 0, rows_n, 1, noop); \
+            /* phase 4 t + 6 (x = 0, step 2 t + 3): dQ of (2 t + 2, B); S, dP of (2 t + 3, B) */                            \
+            prep(s[0], 4 * t + 6, vnext);                                                                                  \
+            phase4<HD, false>(cx, s[0], dp[0], s[1], dp[1], dsp[1], dsp[0], dq[1], qf[1], dof[1], lse2[0], dlt_s[0], kt_n, 0, rows_n, 1, noop); \
+            vcur = vnext;                                                                                                  \
+            vnext = wave_ballot(mb_pend != 0);                                                                             \
+            ++t;                                                                                                           \
+        }
+        while (t + 1 < tmain) { BRA_HOT_ITER(0) BRA_HOT_ITER(1) }
+        if (t < tmain) BRA_HOT_ITER(0)
+#undef BRA_HOT_ITER
+        for (; t < ntile; ++t) {
+            wait_vmcnt<0>();
+            raw_barrier();
+            mb_pend = mask_byte(t + 2);
+            int tn = t + 2;
+            tn = tn < ntile ? tn : ntile - 1;
+#pragma unroll
+            for (int i = 0; i < T::NDMA; ++i) dma_piece(i, tn, t & 1, (t + 2) % 3);
+            cold(4 * t + 3, vcur); cold(4 * t + 4, vnext); cold(4 * t + 5, vnext); cold(4 * t + 6, vnext);
+            vcur = vnext;
+            vnext = wave_ballot(mb_pend != 0);
+        }
+        wait_vmcnt<0>();
+    }
+
+    mfma_drain();
+    // ---- epilogue: dQ rows as bf16, 16-byte pieces (k_attn4.hip)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = qw0 + 32 * qb + l31;
+        bf16_t* op = a.dq + b * a.dq_sb + (long)(qi < a.Sq ? qi : 0) * a.dq_ss + hq * a.dq_sh;
+#pragma unroll
+        for (int db = 0; db < T::DB; ++db) {
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                uint32_t a0 = pack_bf2(dq[qb][db][4 * g + 0], dq[qb][db][4 * g + 1]);
+                uint32_t a1 = pack_bf2(dq[qb][db][4 * g + 2], dq[qb][db][4 * g + 3]);
+                uint32_t b0 = pack_bf2(dq[qb][db][4 * g + 4], dq[qb][db][4 * g + 5]);
+                uint32_t b1 = pack_bf2(dq[qb][db][4 * g + 6], dq[qb][db][4 * g + 7]);
+                xhalf_pair(a0, b0);
+                xhalf_pair(a1, b1);
+                u32x4 w = {a0, a1, b0, b1};
+                if (qi < a.Sq) st16(op + db * 32 + 8 * g + 8 * h, w);
+            }
+            sched_fence();
+        }
+    }
+}
+
+template <int HD>
+int launch_dq4(const AttnArgs& a, bra_stream_t st) {
+    BRA_ALLOW_SMEM((attn_dq4_kernel<HD>), (size_t)TB4<HD>::SMEM);
+    BRA_LAUNCH((attn_dq4_kernel<HD>), dim3((a.Sq + 255) / 256, a.Hq, a.B), dim3(256), (size_t)TB4<HD>::SMEM, st, a);
+    return BRA_LAUNCH_STATUS();
+}
+template int launch_dq4<128>(const AttnArgs&, bra_stream_t);
+template int launch_dq4<64>(const AttnArgs&, bra_stream_t);
+
+}  // namespace bra

@@ -15,6 +15,8 @@ if os.environ.get("AP_LIB"):                      # A/B against another build of
 
 if os.environ.get("AP_FWD4") is not None:
     _lib.use_debug_library().call("bra_attn_set_fwd4", int(os.environ["AP_FWD4"]))
+if os.environ.get("AP_BWD4") is not None:                      # bit 0: pipelined dQ kernel, bit 1: pipelined dK / dV kernels (k_attn4b.hip)
+    _lib.use_debug_library().call("bra_attn_set_bwd4", int(os.environ["AP_BWD4"]))
 dev = torch.device("cuda:0")
 Hq0, Hkv0 = int(os.environ.get("AP_HQ", 16)), int(os.environ.get("AP_HKV", 8))
 g = torch.Generator(device="cpu").manual_seed(0)
