@@ -104,5 +104,9 @@ extern template int launch_fwd4<64>(const AttnArgs&, bra_stream_t);
 template <int HD> int launch_dq4(const AttnArgs& a, bra_stream_t st);
 extern template int launch_dq4<128>(const AttnArgs&, bra_stream_t);
 extern template int launch_dq4<64>(const AttnArgs&, bra_stream_t);
+// ... and dK / dV (two launches: dV, then dK), 256 keys per workgroup
+template <int HD> int launch_dkv4(const AttnArgs& a, bra_stream_t st);
+extern template int launch_dkv4<128>(const AttnArgs&, bra_stream_t);
+extern template int launch_dkv4<64>(const AttnArgs&, bra_stream_t);
 
 }  // namespace bra

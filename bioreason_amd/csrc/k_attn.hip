@@ -953,9 +953,9 @@ static int launch_sum_parts(const float* part, int ns, int B, int H, int S, bf16
 }
 
 #ifdef BRA_EMU
-static int g_attn_bwd4 = 1;
+static int g_attn_bwd4 = 3;
 #else
-static std::atomic<int> g_attn_bwd4{1};
+static std::atomic<int> g_attn_bwd4{3};
 #endif
 
 template <int HD>
@@ -1006,6 +1006,10 @@ static int launch_dkv(const AttnArgs& a, bra_stream_t st) {
         rc = launch_sum_parts<HD>(a.part_dk, a.nsplit_kv, a.B, a.Hkv, a.Sk, a.dk, a.dk_sb, a.dk_ss, a.dk_sh, st);
         if (rc) return rc;
         return launch_sum_parts<HD>(a.part_dv, a.nsplit_kv, a.B, a.Hkv, a.Sk, a.dv, a.dv_sb, a.dv_ss, a.dv_sh, st);
+    }
+    // whole 256-key workgroups, long query loops: the pipelined 4-wave kernels (k_attn4b.hip; bra_attn_set_bwd4 bit 1)
+    if constexpr (HD >= 64) {
+        if ((g_attn_bwd4 & 2) && a.Sk > 128 && a.Sq > 128) return launch_dkv4<HD>(a, st);
     }
     if (HD < 128) return launch_dkv_v<HD, 0, 4>(a, st);
     constexpr int NW = HD >= 128 ? 8 : 4;              // 8 waves = 2 per SIMD share one staged query tile
@@ -1170,7 +1174,8 @@ extern "C" int bra_attn_bwd_split(const void* q, long q_sb, long q_ss, long q_sh
 extern "C" int bra_attn_set_block_order(int legacy) { g_attn_legacy_order = legacy ? 1 : 0; return 0; }
 // A/B knob: 0 = the 8-wave forward of rounds 1-5 for every shape, 1 (default) = the 4-wave kernel where it applies
 extern "C" int bra_attn_set_fwd4(int on) { g_attn_fwd4 = on ? 1 : 0; return 0; }
-// attention backward: bit 0 = the pipelined dQ kernel (k_attn4b.hip) where it applies (default 1), 0 = the kernels of rounds 1-5
+// attention backward: bit 0 = the pipelined dQ kernel, bit 1 = the pipelined dK / dV kernels (k_attn4b.hip) where they apply
+// (default 3), 0 = the kernels of rounds 1-5
 extern "C" int bra_attn_set_bwd4(int mask) { g_attn_bwd4 = mask; return 0; }
 // 80 x 8-byte device buffer that one workgroup of the next 4-wave forward launches fills with cycle counts (k_attn4.hip), or null
 extern "C" int bra_attn_set_probe(void* p) { g_attn_probe = (unsigned long long*)p; return 0; }

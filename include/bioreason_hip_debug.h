@@ -37,8 +37,8 @@ int bra_attn_set_block_order(int legacy);
 /* attention forward for grids of whole 256-query workgroups: 1 (default) = the pipelined kernel of k_attn4.hip (4 waves of 64
  * queries), 0 = the 8-wave kernel of rounds 1-5 for every shape (A/B measurements) */
 int bra_attn_set_fwd4(int on);
-/* attention backward: bit 0 = the pipelined dQ kernel of k_attn4b.hip for grids of whole 256-query workgroups (default: set),
- * 0 = the kernels of rounds 1-5 for every shape (A/B measurements) */
+/* attention backward: bit 0 = the pipelined dQ kernel, bit 1 = the pipelined dK / dV kernels of k_attn4b.hip for grids of whole
+ * 256-row workgroups (default: both set), 0 = the kernels of rounds 1-5 for every shape (A/B measurements) */
 int bra_attn_set_bwd4(int mask);
 /* 80 x 8-byte device buffer (or null) that one mid-sequence workgroup of the following 4-wave forward launches fills per wave with
  * cycle counts of its hot loop: DMA wait, barrier, step 1, step 2, loop tail, iterations, whole kernel, steps (diagnostics) */

@@ -286,6 +286,55 @@ def test_attn_fwd_pipelined_kernel(debug_backend, hd, Hq, Hkv, Sq, Sk, causal, p
         assert o4[~vq.expand_as(o4)].float().abs().max() == 0 and torch.equal(l4[~valid_q], l8[~valid_q])
 
 
+@pytest.mark.parametrize("hd,Hq,Hkv,Sq,Sk,causal,pad", [
+    (128, 2, 1, 700, 700, True, "left"),              # eleven tiles per (head, block): the interleaved loops in both slot parities + remainder
+    (128, 4, 2, 256, 700, True, "holes"),             # a prefix (Sk > Sq), masked keys inside tiles, a GQA group of two q-heads per kv-head
+    (128, 2, 2, 513, 513, True, None),                # last workgroups with one live row
+    (64, 2, 2, 400, 400, False, "right"),
+    (128, 2, 1, 129, 300, True, "right"),
+])
+def test_attn_bwd_pipelined_kernels(debug_backend, hd, Hq, Hkv, Sq, Sk, causal, pad):
+    """k_attn4b.hip (dQ: unit = key step x query block; dK / dV: unit = query half x key block; Q / dO resp. K / V fragments and the
+    accumulators resident in AGPRs) against the fp32 statement (TF:qwen3:185-207 backward) and against the kernels of rounds 1-5 on the
+    same inputs — the two differ only in the association of fp32 sums and in where `scale` enters dS"""
+    backend = debug_backend
+    lib = _lib.get_lib()
+    B = 2
+    q, k, v = rnd(B, Sq, Hq, hd, dev=backend, seed=1), rnd(B, Sk, Hkv, hd, dev=backend, seed=2), rnd(B, Sk, Hkv, hd, dev=backend, seed=3)
+    kmask = torch.ones(B, Sk, dtype=torch.uint8, device=backend)
+    if pad == "left":
+        kmask[0, :75] = 0
+    elif pad == "right":
+        kmask[1, Sk - 45:] = 0
+    elif pad == "holes":
+        kmask[0, 33:40] = 0
+        kmask[1, 200:290] = 0
+    km = kmask if pad else None
+    scale = hd ** -0.5
+    vt = ops.head_transpose(v)
+    o, lse = ops.attn_fwd(q, k, vt, km, causal, scale, nsplit=1)
+    qf, kf, vf = q.float().requires_grad_(True), k.float().requires_grad_(True), v.float().requires_grad_(True)
+    ro, rlse = _attn_ref(qf, kf, vf, km, causal, scale, Sk - Sq)
+    valid_q = torch.isfinite(rlse)
+    vq = valid_q.permute(0, 2, 1)[..., None]
+    dout = rnd(B, Sq, Hq, hd, dev=backend, seed=4) * vq.to(BF)
+    (ro.nan_to_num(0) * dout.float()).sum().backward()
+    res = {}
+    try:
+        for mask in (3, 0):
+            lib.call("bra_attn_set_bwd4", mask)
+            res[mask] = [t.float().cpu() for t in ops.attn_bwd(q, k, v, o, dout, lse, km, causal, scale, nsplit=(1, 1))]
+    finally:
+        lib.call("bra_attn_set_bwd4", 3)
+    vq = vq.cpu()
+    for i, (nm, want) in enumerate((("dq", qf.grad), ("dk", kf.grad), ("dv", vf.grad))):
+        w = want.cpu() * vq if nm == "dq" else want.cpu()
+        new, old = (res[3][i] * vq, res[0][i] * vq) if nm == "dq" else (res[3][i], res[0][i])
+        assert rel(new, w) < 1.5e-2, nm
+        assert rel(new, old) < 3e-4, nm
+        assert torch.isfinite(res[3][i]).all(), nm
+
+
 @pytest.mark.parametrize("hd,Hq,Hkv,Sq,Sk,causal,pad,ns", [(128, 4, 2, 300, 300, True, "left", (2, 2)), (128, 2, 1, 256, 700, True, None, (3, 1)),
                                                          (64, 2, 2, 200, 200, False, "right", (2, 3)), (128, 4, 1, 520, 520, True, None, (4, 4)),
                                                          (128, 2, 2, 600, 600, True, None, (1, 2))])

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
 for v in 1 0; do
   rm -rf /tmp/prof_$v
-  AP_BWD4=$v AP_FWD4=$v AP_SHAPES=${AP_SHAPES:-full} AP_N=10 rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o p --output-format csv -- python $ROOT/tools/attn_probe.py > /dev/null 2>&1
+  AP_BWD4=$((v*3)) AP_FWD4=$v AP_SHAPES=${AP_SHAPES:-full} AP_N=10 rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o p --output-format csv -- python $ROOT/tools/attn_probe.py > /dev/null 2>&1
   echo "== pipelined kernels = $v"
   f=$(find /tmp/prof_$v -name "*kernel_stats.csv" | head -1)
   python - "$f" <<'PY'
