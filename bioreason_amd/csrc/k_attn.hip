@@ -926,7 +926,14 @@ static int launch_fwd(const AttnArgs& a, bra_stream_t st) {
     const size_t smem = 2 * (Tile<HD>::KBYTES + Tile<HD>::TBYTES);
     // whole 256-query workgroups, no key split: the 4-wave kernel with 64 queries per wave (k_attn4.hip)
     if constexpr (HD >= 64) {
-        if (a.Sq > 128 && a.nsplit <= 1 && g_attn_fwd4) return launch_fwd4<HD>(a, st);
+        if (a.Sq > 128 && g_attn_fwd4) {
+            int rc = launch_fwd4<HD>(a, st);
+            if (rc || a.nsplit <= 1) return rc;
+            const long rows = (long)a.B * a.Hq * a.Sq;
+            constexpr int RPB = 256 / (HD / 4);
+            BRA_LAUNCH((attn_combine_kernel<HD>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, a);
+            return BRA_LAUNCH_STATUS();
+        }
     }
     if (HD >= 64 && a.Sq > 128) {
         const int ns = a.nsplit > 1 ? a.nsplit : 1;
@@ -963,7 +970,11 @@ static int launch_dq(const AttnArgs& a, bra_stream_t st) {
     const size_t smem = 2 * (2 * Tile<HD>::KBYTES + Tile<HD>::TBYTES);
     // whole 256-query workgroups, no key split: the pipelined 4-wave kernel (k_attn4b.hip)
     if constexpr (HD >= 64) {
-        if (a.Sq > 128 && a.nsplit <= 1 && (g_attn_bwd4 & 1)) return launch_dq4<HD>(a, st);
+        if (a.Sq > 128 && (g_attn_bwd4 & 1)) {
+            int rc = launch_dq4<HD>(a, st);
+            if (rc || a.nsplit <= 1) return rc;
+            return launch_sum_parts<HD>(a.part_o, a.nsplit, a.B, a.Hq, a.Sq, a.dq, a.dq_sb, a.dq_ss, a.dq_sh, st);
+        }
     }
     if (HD >= 64 && a.Sq > 128) {
         const int ns = a.nsplit > 1 ? a.nsplit : 1;
@@ -992,6 +1003,17 @@ static int launch_dkv_v(const AttnArgs& a, bra_stream_t st) {
 }
 template <int HD>
 static int launch_dkv(const AttnArgs& a, bra_stream_t st) {
+    // whole 256-key workgroups, long query loops: the pipelined 4-wave kernels (k_attn4b.hip; bra_attn_set_bwd4 bit 1), with the
+    // (q-head, query tile) loop in nsplit_kv parts for grids that cannot fill the chip
+    if constexpr (HD >= 64) {
+        if ((g_attn_bwd4 & 2) && a.Sk > 128 && a.Sq > 128) {
+            int rc = launch_dkv4<HD>(a, st);
+            if (rc || a.nsplit_kv <= 1) return rc;
+            rc = launch_sum_parts<HD>(a.part_dk, a.nsplit_kv, a.B, a.Hkv, a.Sk, a.dk, a.dk_sb, a.dk_ss, a.dk_sh, st);
+            if (rc) return rc;
+            return launch_sum_parts<HD>(a.part_dv, a.nsplit_kv, a.B, a.Hkv, a.Sk, a.dv, a.dv_sb, a.dv_ss, a.dv_sh, st);
+        }
+    }
     if (a.nsplit_kv > 1) {
         // (one prompt: 144 four-wave workgroups with a triangular load — the (q-head, query tile) loop of every key block in parts;
         //  only the one-launch dK + dV form is split: the shapes that take the two 8-wave kernels fill the chip)
@@ -1006,10 +1028,6 @@ static int launch_dkv(const AttnArgs& a, bra_stream_t st) {
         rc = launch_sum_parts<HD>(a.part_dk, a.nsplit_kv, a.B, a.Hkv, a.Sk, a.dk, a.dk_sb, a.dk_ss, a.dk_sh, st);
         if (rc) return rc;
         return launch_sum_parts<HD>(a.part_dv, a.nsplit_kv, a.B, a.Hkv, a.Sk, a.dv, a.dv_sb, a.dv_ss, a.dv_sh, st);
-    }
-    // whole 256-key workgroups, long query loops: the pipelined 4-wave kernels (k_attn4b.hip; bra_attn_set_bwd4 bit 1)
-    if constexpr (HD >= 64) {
-        if ((g_attn_bwd4 & 2) && a.Sk > 128 && a.Sq > 128) return launch_dkv4<HD>(a, st);
     }
     if (HD < 128) return launch_dkv_v<HD, 0, 4>(a, st);
     constexpr int NW = HD >= 128 ? 8 : 4;              // 8 waves = 2 per SIMD share one staged query tile

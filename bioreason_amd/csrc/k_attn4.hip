@@ -338,6 +338,11 @@ __global__ __launch_bounds__(512 / NQB) void attn_fwd4_kernel(AttnArgs a) {
     int bx_, hq, b;
     attn_block_coords(0, a.causal, bx_, hq, b);
     const int hkv = hq / (a.Hq / a.Hkv);
+    // key range in `nsp` parts (grids that cannot fill the chip: one prompt, a 256-query completion segment): part sp of a query block
+    // visits its tiles [tb, tb + ntile) and leaves the unnormalised O (fp32) and (reference maximum, sum) per query for attn_combine_kernel
+    const int nsp = a.nsplit > 1 ? a.nsplit : 1;
+    const int sp = nsp > 1 ? bx_ % nsp : 0;
+    if (nsp > 1) bx_ /= nsp;
     const int q0 = bx_ * 256, qw0 = q0 + wave * QW;
     // (uniform: the DMA source is this scalar base + a 32-bit lane offset, `global_load_lds_dwordx4 v, s[..]`)
     const char* kb_ = uniform_ptr(a.k + b * a.k_sb + hkv * a.k_sh);
@@ -369,6 +374,12 @@ __global__ __launch_bounds__(512 / NQB) void attn_fwd4_kernel(AttnArgs a) {
         const int u = 64 * (wave * T::TPW + i) + lane, d = u >> 3, c = (u & 7) ^ ((d >> 1) & 7);
         vsrc[i] = attn_mul24(d, (int)a.vt_sd * 2) + (unsigned)(c * 16);
     }
+    // this workgroup's key tiles, this wave's steps
+    int kv_end = a.Sk;
+    if (a.causal) { const int last = q0 + 255 + a.q_off + 1; kv_end = last < kv_end ? last : kv_end; }
+    const int ntile_all = kv_end > 0 ? (kv_end + 63) / 64 : 0;
+    const int tb = nsp > 1 ? (ntile_all * sp) / nsp : 0;                               // first tile of this part; tile / step indices below
+    const int ntile = (nsp > 1 ? (ntile_all * (sp + 1)) / nsp : ntile_all) - tb;       // are relative to it
     const int k_sbytes = (int)a.k_ss * 2;
     // The copies go through buffer descriptors of the (batch, kv-head) slices: lane offset (a loop constant) + scalar tile offset, no
     // address arithmetic per piece, and K rows beyond Sk are out of the descriptor's range — the hardware delivers zeros (their
@@ -379,16 +390,12 @@ __global__ __launch_bounds__(512 / NQB) void attn_fwd4_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < T::KPW; ++i) ksrc[i] = attn_mul24(krow[i], k_sbytes) + kcol[i];
     auto dma_k = [&](int i, int tile, int slot) {
-        dma16(kdesc, ksrc[i], (unsigned)(tile * 64) * (unsigned)k_sbytes, smem + slot * SLOT + (wave * T::KPW + i) * 1024);
+        dma16(kdesc, ksrc[i], (unsigned)((tb + tile) * 64) * (unsigned)k_sbytes, smem + slot * SLOT + (wave * T::KPW + i) * 1024);
     };
     auto dma_v = [&](int i, int tile, int slot) {
-        dma16(vdesc, vsrc[i], (unsigned)(tile * 128), smem + slot * SLOT + T::KBYTES + (wave * T::TPW + i) * 1024);
+        dma16(vdesc, vsrc[i], (unsigned)((tb + tile) * 128), smem + slot * SLOT + T::KBYTES + (wave * T::TPW + i) * 1024);
     };
 
-    // this workgroup's key tiles, this wave's steps
-    int kv_end = a.Sk;
-    if (a.causal) { const int last = q0 + 255 + a.q_off + 1; kv_end = last < kv_end ? last : kv_end; }
-    const int ntile = kv_end > 0 ? (kv_end + 63) / 64 : 0;
     // (a wave's own steps: under a causal mask the earlier waves of a workgroup finish up to six steps before the last one and then
     //  only take part in the staging; giving every wave the last wave's step count — fully masked steps, exact zeros — was
     //  measured and is slower: masking a step costs more than an interleaved step)
@@ -397,7 +404,8 @@ __global__ __launch_bounds__(512 / NQB) void attn_fwd4_kernel(AttnArgs a) {
         int lastq = qw0 + QW - 1; lastq = lastq < a.Sq ? lastq : a.Sq - 1;
         int lastk = a.causal ? lastq + a.q_off : a.Sk - 1;
         lastk = lastk < a.Sk ? lastk : a.Sk - 1;
-        nstep_w = lastk >= 0 ? lastk / 32 + 1 : 0;
+        nstep_w = lastk >= 0 ? lastk / 32 + 1 - 2 * tb : 0;
+        nstep_w = nstep_w > 0 ? nstep_w : 0;
         nstep_w = nstep_w < 2 * ntile ? nstep_w : 2 * ntile;
     }
 
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(512 / NQB) void attn_fwd4_kernel(AttnArgs a) {
 
     // key validity of a tile as a 64-bit word (bit = key of the tile); requested two tiles ahead
     auto mask_byte = [&](int tile) -> int {
-        int kj = tile * 64 + lane;
+        int kj = (tb + tile) * 64 + lane;
         const bool in = kj < a.Sk;
         kj = in ? kj : a.Sk - 1;
         int v = a.kmask ? (int)a.kmask[(long)b * a.Sk + kj] : 1;
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(512 / NQB) void attn_fwd4_kernel(AttnArgs a) {
         int mb_pend = 0;
         auto noop = [](int) {};
         auto prep = [&](f32x16 (&s)[NQB], int j, uint64_t vword) {        // masks of step j, applied to its finished scores
-            const int kv0s = 32 * j;
+            const int kv0s = 64 * tb + 32 * j;
             const uint32_t v32 = (uint32_t)(vword >> (32 * (j & 1)));
             const bool full = v32 == 0xffffffffu && (!a.causal || kv0s + 31 <= qw0 + a.q_off);
             if (!full) mask_scores4<NQB>(s, v32, a.causal != 0, qw0 + l31 + a.q_off - kv0s, opaque_i(lane) >> 5);
@@ -563,6 +571,27 @@ __global__ __launch_bounds__(512 / NQB) void attn_fwd4_kernel(AttnArgs a) {
     }
 
     mfma_drain();
+    if (nsp > 1) {
+        // this part's unnormalised O and (reference maximum, sum) per query; lane (query, h) owns d = 32 db + 8 g + 4 h + 0..3
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            const int qi = qw0 + 32 * qb + l31;
+            const float l_tot = xhalf_sum(l_run[qb]);
+            const long row = (((long)b * a.Hq + hq) * nsp + sp) * a.Sq + (qi < a.Sq ? qi : 0);
+            float* op = a.part_o + row * HD;
+#pragma unroll
+            for (int db = 0; db < T::DB; ++db) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 w = {o[qb][db][4 * g + 0], o[qb][db][4 * g + 1], o[qb][db][4 * g + 2], o[qb][db][4 * g + 3]};
+                    if (qi < a.Sq) *reinterpret_cast<f32x4*>(op + db * 32 + 8 * g + 4 * h) = w;
+                }
+                sched_fence();
+            }
+            if (h == 0 && qi < a.Sq) { a.part_ml[row * 2] = m_run[qb]; a.part_ml[row * 2 + 1] = l_tot; }
+        }
+        return;
+    }
     // ---- epilogue: normalise, bf16, whole 16-byte pieces of a row per store (lane pairs exchange their 8-byte halves) ---------------
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
@@ -599,7 +628,8 @@ template <int HD>
 int launch_fwd4(const AttnArgs& a, bra_stream_t st) {
     const size_t smem = 2 * (T4<HD, 2>::KBYTES + T4<HD, 2>::TBYTES);
     BRA_ALLOW_SMEM((attn_fwd4_kernel<HD, 2>), smem);
-    BRA_LAUNCH((attn_fwd4_kernel<HD, 2>), dim3((a.Sq + 255) / 256, a.Hq, a.B), dim3(256), smem, st, a);
+    const int ns = a.nsplit > 1 ? a.nsplit : 1;      // (the merge of the parts: attn_combine_kernel, launched by the caller)
+    BRA_LAUNCH((attn_fwd4_kernel<HD, 2>), dim3(((a.Sq + 255) / 256) * ns, a.Hq, a.B), dim3(256), smem, st, a);
     return BRA_LAUNCH_STATUS();
 }
 template int launch_fwd4<128>(const AttnArgs&, bra_stream_t);

@@ -202,6 +202,11 @@ __global__ __launch_bounds__(256) void attn_dq4_kernel(AttnArgs a) {
     int bx_, hq, b;
     attn_block_coords(0, a.causal, bx_, hq, b);
     const int hkv = hq / (a.Hq / a.Hkv);
+    // key range in `nsp` parts (grids that cannot fill the chip): part sp visits tiles [tb, tb + ntile) and leaves its dQ in fp32 for
+    // attn_sum_parts_kernel; tile / step / unit indices below are relative to tb
+    const int nsp = a.nsplit > 1 ? a.nsplit : 1;
+    const int sp = nsp > 1 ? bx_ % nsp : 0;
+    if (nsp > 1) bx_ /= nsp;
     const int q0 = bx_ * 256, qw0 = q0 + wave * 64;
     const char* kb_ = uniform_ptr(a.k + b * a.k_sb + hkv * a.k_sh);
     const char* vb_ = uniform_ptr(a.v + b * a.v_sb + hkv * a.v_sh);
@@ -221,6 +226,11 @@ __global__ __launch_bounds__(256) void attn_dq4_kernel(AttnArgs a) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) cx.tfo[kb][s2] = (unsigned)(l31 * 128 + (((4 * kb + 2 * s2 + h) ^ swv) << 4));
     }
+    int kv_end = a.Sk;
+    if (a.causal) { const int last = q0 + 255 + a.q_off + 1; kv_end = last < kv_end ? last : kv_end; }
+    const int ntile_all = kv_end > 0 ? (kv_end + 63) / 64 : 0;
+    const int tb = nsp > 1 ? (ntile_all * sp) / nsp : 0;
+    const int ntile = (nsp > 1 ? (ntile_all * (sp + 1)) / nsp : ntile_all) - tb;
     // DMA sources (byte offsets inside the (batch, kv-head) slices; rows beyond Sk are outside the descriptors: zeros)
     const int k_sbytes = (int)a.k_ss * 2, v_sbytes = (int)a.v_ss * 2;
     const BufDesc kdesc = make_bufdesc(kb_, (unsigned)((a.Sk - 1) * k_sbytes + HD * 2));
@@ -239,21 +249,19 @@ __global__ __launch_bounds__(256) void attn_dq4_kernel(AttnArgs a) {
         tsrc[i] = attn_mul24(d, (int)a.kt_sd * 2) + (unsigned)(c * 16);
     }
     auto dma_piece = [&](int i, int tile, int rslot, int tslot) {
-        if (i < T::KPW) dma16(kdesc, ksrc[i], (unsigned)(tile * 64) * (unsigned)k_sbytes, smem + rslot * T::RSLOT + (wave * T::KPW + i) * 1024);
-        else if (i < 2 * T::KPW) dma16(vdesc, vsrc[i - T::KPW], (unsigned)(tile * 64) * (unsigned)v_sbytes,
+        if (i < T::KPW) dma16(kdesc, ksrc[i], (unsigned)((tb + tile) * 64) * (unsigned)k_sbytes, smem + rslot * T::RSLOT + (wave * T::KPW + i) * 1024);
+        else if (i < 2 * T::KPW) dma16(vdesc, vsrc[i - T::KPW], (unsigned)((tb + tile) * 64) * (unsigned)v_sbytes,
                                        smem + rslot * T::RSLOT + T::KBYTES + (wave * T::KPW + i - T::KPW) * 1024);
-        else dma16(tdesc, tsrc[i - 2 * T::KPW], (unsigned)(tile * 128), smem + T::OFF_T + tslot * T::TBYTES + (wave * T::TPW + i - 2 * T::KPW) * 1024);
+        else dma16(tdesc, tsrc[i - 2 * T::KPW], (unsigned)((tb + tile) * 128), smem + T::OFF_T + tslot * T::TBYTES + (wave * T::TPW + i - 2 * T::KPW) * 1024);
     };
 
-    int kv_end = a.Sk;
-    if (a.causal) { const int last = q0 + 255 + a.q_off + 1; kv_end = last < kv_end ? last : kv_end; }
-    const int ntile = kv_end > 0 ? (kv_end + 63) / 64 : 0;
     int nunit_w = 0;                                  // this wave's units: two per 32-key step that holds a key one of its queries sees
     if (qw0 < a.Sq && ntile > 0) {
         int lastq = qw0 + 63; lastq = lastq < a.Sq ? lastq : a.Sq - 1;
         int lastk = a.causal ? lastq + a.q_off : a.Sk - 1;
         lastk = lastk < a.Sk ? lastk : a.Sk - 1;
-        int ns = lastk >= 0 ? lastk / 32 + 1 : 0;
+        int ns = lastk >= 0 ? lastk / 32 + 1 - 2 * tb : 0;
+        ns = ns > 0 ? ns : 0;
         ns = ns < 2 * ntile ? ns : 2 * ntile;
         nunit_w = 2 * ns;
     }
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(256) void attn_dq4_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) dq[qb][i][r] = 0.f;
 
     auto mask_byte = [&](int tile) -> int {
-        int kj = tile * 64 + lane;
+        int kj = (tb + tile) * 64 + lane;
         const bool in = kj < a.Sk;
         kj = in ? kj : a.Sk - 1;
         int v = a.kmask ? (int)a.kmask[(long)b * a.Sk + kj] : 1;
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256) void attn_dq4_kernel(AttnArgs a) {
         auto noop = [](int) {};
         // masks of unit u (step j = u / 2, block x = u & 1), applied to its finished scores; vword = the validity word of tile j / 2
         auto prep = [&](f32x16& sx, int u, uint64_t vword) {
-            const int j = u >> 1, x = u & 1, kv0s = 32 * j;
+            const int j = u >> 1, x = u & 1, kv0s = 64 * tb + 32 * j;
             const uint32_t v32 = (uint32_t)(vword >> (32 * (j & 1)));
             const bool full = v32 == 0xffffffffu && (!a.causal || kv0s + 31 <= qw0 + 32 * x + a.q_off);
             if (!full) mask_scores4b(sx, v32, a.causal != 0, qw0 + 32 * x + l31 + a.q_off - kv0s, opaque_i(lane) >> 5);
@@ -388,6 +396,23 @@ __global__ __launch_bounds__(256) void attn_dq4_kernel(AttnArgs a) {
     }
 
     mfma_drain();
+    if (nsp > 1) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qi = qw0 + 32 * qb + l31;
+            float* op = a.part_o + ((((long)b * a.Hq + hq) * nsp + sp) * a.Sq + (qi < a.Sq ? qi : 0)) * HD;
+#pragma unroll
+            for (int db = 0; db < T::DB; ++db) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 w = {dq[qb][db][4 * g + 0], dq[qb][db][4 * g + 1], dq[qb][db][4 * g + 2], dq[qb][db][4 * g + 3]};
+                    if (qi < a.Sq) *reinterpret_cast<f32x4*>(op + db * 32 + 8 * g + 4 * h) = w;
+                }
+                sched_fence();
+            }
+        }
+        return;
+    }
     // ---- epilogue: dQ rows as bf16, 16-byte pieces (k_attn4.hip)
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -635,6 +660,11 @@ __global__ __launch_bounds__(256) void attn_dkv4_kernel(AttnArgs a) {
     int bx_, hkv, b;
     attn_block_coords(0, 0, bx_, hkv, b);             // (causal: key block 0 is the heaviest — ascending order is heaviest first)
     const int group = a.Hq / a.Hkv;
+    // the (q-head, query tile) iterations in `nsp` parts (bra_attn_bwd_split's nsplit_kv): part sp runs iterations [it_first, it_first + nit)
+    // and leaves its accumulators in fp32 for attn_sum_parts_kernel; iteration / unit indices below are relative to it_first
+    const int nsp = a.nsplit_kv > 1 ? a.nsplit_kv : 1;
+    const int sp = nsp > 1 ? bx_ % nsp : 0;
+    if (nsp > 1) bx_ /= nsp;
     const int k0 = bx_ * 256, kw0 = k0 + wave * 64;
 
     CtxB4<HD> cx;
@@ -687,7 +717,9 @@ __global__ __launch_bounds__(256) void attn_dkv4_kernel(AttnArgs a) {
     if (a.causal) { const int first = k0 - a.q_off; qt_begin = first > 0 ? first / 64 : 0; }
     const int qt_end = (a.Sq + 63) / 64;
     const int per_head = qt_end > qt_begin ? qt_end - qt_begin : 0;
-    const int nit = per_head * group;
+    const int nit_all = per_head * group;
+    const int it_first = nsp > 1 ? (nit_all * sp) / nsp : 0;
+    const int nit = (nsp > 1 ? (nit_all * (sp + 1)) / nsp : nit_all) - it_first;
     const int nunit = kw0 < a.Sk ? 4 * nit : 0;       // this wave's units (a wave without keys only takes part in the staging)
 
     // DMA sources: lane offsets inside the (batch, q-head) slices (loop constants); the slice bases change with the iteration's head
@@ -705,8 +737,8 @@ __global__ __launch_bounds__(256) void attn_dkv4_kernel(AttnArgs a) {
         const int u = 64 * (wave * T::TPW + i) + lane, d = u >> 3, c = (u & 7) ^ ((d >> 1) & 7);
         tsrc[i] = attn_mul24(d, t_sd2) + (unsigned)(c * 16);
     }
-    auto it_head = [&](int it) -> int { return hkv * group + (per_head > 0 ? it / per_head : 0); };
-    auto it_s0 = [&](int it) -> int { return (qt_begin + (per_head > 0 ? it % per_head : 0)) * 64; };
+    auto it_head = [&](int it) -> int { return hkv * group + (per_head > 0 ? (it_first + it) / per_head : 0); };
+    auto it_s0 = [&](int it) -> int { return (qt_begin + (per_head > 0 ? (it_first + it) % per_head : 0)) * 64; };
     float st_reg = 0.f;                               // staged statistic of the tile after next: lanes 0..63 of wave 0 lse2, of wave 1 delta * scale
     // the copies of one (q-head, query tile): descriptors of the head's slices + the tile's offsets, then NDMA pieces + the statistic
     struct Stage { BufDesc qd, dd, td; unsigned q_off, d_off, t_off; int rslot, tslot; long stat_idx; };
@@ -831,6 +863,23 @@ __global__ __launch_bounds__(256) void attn_dkv4_kernel(AttnArgs a) {
     }
 
     mfma_drain();
+    if (nsp > 1) {
+        float* const part = DK ? a.part_dk : a.part_dv;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            float* op = part + ((((long)b * a.Hkv + hkv) * nsp + sp) * a.Sk + (kj[x] < a.Sk ? kj[x] : 0)) * HD;
+#pragma unroll
+            for (int db = 0; db < T::DB; ++db) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 w = {acc[x][db][4 * g + 0], acc[x][db][4 * g + 1], acc[x][db][4 * g + 2], acc[x][db][4 * g + 3]};
+                    if (kj[x] < a.Sk) *reinterpret_cast<f32x4*>(op + db * 32 + 8 * g + 4 * h) = w;
+                }
+                sched_fence();
+            }
+        }
+        return;
+    }
     bf16_t* const outb = DK ? a.dk + b * a.dk_sb + hkv * a.dk_sh : a.dv + b * a.dv_sb + hkv * a.dv_sh;
     const long o_ss = DK ? a.dk_ss : a.dv_ss;
 #pragma unroll
@@ -857,7 +906,8 @@ __global__ __launch_bounds__(256) void attn_dkv4_kernel(AttnArgs a) {
 template <int HD>
 int launch_dkv4(const AttnArgs& a, bra_stream_t st) {
     constexpr size_t smem_v = TK4<HD, 1>::SMEM, smem_k = TK4<HD, 2>::SMEM;
-    const dim3 grid((a.Sk + 255) / 256, a.Hkv, a.B);
+    const int ns = a.nsplit_kv > 1 ? a.nsplit_kv : 1;   // (the sums of the parts: attn_sum_parts_kernel, launched by the caller)
+    const dim3 grid(((a.Sk + 255) / 256) * ns, a.Hkv, a.B);
     BRA_ALLOW_SMEM((attn_dkv4_kernel<HD, 1>), smem_v);
     BRA_LAUNCH((attn_dkv4_kernel<HD, 1>), grid, dim3(256), smem_v, st, a);
     int rc = BRA_LAUNCH_STATUS();
@@ -872,7 +922,8 @@ template int launch_dkv4<64>(const AttnArgs&, bra_stream_t);
 template <int HD>
 int launch_dq4(const AttnArgs& a, bra_stream_t st) {
     BRA_ALLOW_SMEM((attn_dq4_kernel<HD>), (size_t)TB4<HD>::SMEM);
-    BRA_LAUNCH((attn_dq4_kernel<HD>), dim3((a.Sq + 255) / 256, a.Hq, a.B), dim3(256), (size_t)TB4<HD>::SMEM, st, a);
+    const int ns = a.nsplit > 1 ? a.nsplit : 1;      // (the sum of the parts: attn_sum_parts_kernel, launched by the caller)
+    BRA_LAUNCH((attn_dq4_kernel<HD>), dim3(((a.Sq + 255) / 256) * ns, a.Hq, a.B), dim3(256), (size_t)TB4<HD>::SMEM, st, a);
     return BRA_LAUNCH_STATUS();
 }
 template int launch_dq4<128>(const AttnArgs&, bra_stream_t);

@@ -342,9 +342,8 @@ def attn_bwd_split_parts(B: int, Hq: int, Hkv: int, Sq: int, Sk: int, hd: int, c
     ns_dq = attn_fwd_split_parts(B, Hq, Sq, Sk, hd, causal)              # same grid as the forward: 256-query workgroups
     ns_kv = 1
     if ATTN_SPLIT and hd >= 64 and Sq >= 1024 and Sk > 128:
-        wgs = ((Sk + 127) // 128) * Hkv * B                              # 128-key workgroups of the one-launch form
-        fused = hd < 128 or ((Sk + 255) // 256) * Hkv * B < 256          # (k_attn.hip launch_dkv: Sq > 512 here)
-        if fused and wgs < 200:
+        wgs = ((Sk + 255) // 256) * Hkv * B                              # 256-key workgroups of the pipelined kernels (k_attn4b.hip)
+        if wgs < 200:
             ns_kv = max(1, min(4, (300 + wgs // 2) // wgs))
     return ns_dq, ns_kv
 
