@@ -1124,7 +1124,7 @@ template <typename T> struct knob_t {
 #endif
 static knob_t<int> g_forced_variant(-1);
 static knob_t<int> g_forced_w4(0);             // 1..4: gemm_w4_kernel at 160x256 / 128x256 / 160x128 / 128x128 (bra_gemm_set_variant(11..14))
-static knob_t<int> ring_min_fill_pct(75);
+static knob_t<int> ring_min_fill_pct(60);
 static knob_t<int> ring_two_phase(1);
 static knob_t<int> ring_row_split(1);
 
@@ -1137,7 +1137,10 @@ static int pick_variant(const GemmArgs& g) {
     if (g.K % 64 == 0 && g.K2 % 64 == 0 && g.split_k <= 1) {
         // 256 x 256 ring kernel: the fastest inner loop (measured 1.07-1.15x the 256 x 128 kernel per tile-flop,
         // profiles/r2_gemm_variants.txt), but half as many tiles — take it when a single partial round still beats two
-        // rounds of the smaller tile (>= 140 tiles), or when its rounds fill most of the 256 CUs
+        // rounds of the smaller tile (>= 140 tiles), or when its rounds fill most of the 256 CUs.  (round 6: the gate is 60 %, was 75 %:
+        // SFT's M = 17 440 rows make the N = 2048 projections 552 tiles = 2.16 rounds (72 %), which the old gate sent to 192-row LDS-DMA
+        // tiles; on the ring kernel the row split below covers the 40 remaining tiles with a short second launch: down 894 -> 1166,
+        // d_gate_up 872 -> 1217, d_qkv 890 -> 1123 TFLOP/s, profiles/r6_k_gemm_sft_shapes.txt)
         const long t = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
         const long rounds = (t + 255) / 256;
         if (t >= 140 && (t <= 256 || 100 * t >= ring_min_fill_pct * rounds * 256)) return 6;

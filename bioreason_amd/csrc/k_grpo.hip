@@ -476,6 +476,184 @@ __global__ __launch_bounds__(64) void sample_tiles_kernel(const float* logits, l
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The tile-maxima sampler as ONE launch (round 6; VERDICT r5 #9: two launches were 9.6 + 17.9 us per token for no bytes).  One
+// 1024-thread workgroup per row:
+//   A  every thread holds EPT tile maxima (strided: tile = tid + 1024 e); each of the 64 lane-rows of 16 extracts ITS k best with k
+//      rounds of a row-wide maximum (as topk_slices_kernel) -> 64 sorted lists in LDS;
+//   B  wave 0, lane = list: k rounds over the 64 list heads -> the k best tiles (a strict total order: the same k tiles whatever the
+//      partition into lists);  C / D  as sample_tiles_kernel: the 16 k logits of those tiles, k rounds, the draw, the embedding row.
+// Against the two launches this drops one launch boundary, the round trip of the candidate lists through memory and one of the four
+// k-round stages.  Wave 0 alone gathers the embedding row so that the RMSNorm statistic is summed in the order of
+// sample_tiles_kernel (bit-identical x / ss, hence identical tokens downstream).
+template <int EPT, int NU>
+__global__ __launch_bounds__(1024) void sample_tiles_one_kernel(const float* logits, long ldl, int V, const float* tmax, long ldm, int ntiles,
+                                                                int k, float temperature, float top_p, int do_sample, uint32_t seed,
+                                                                const int* step_ptr, int step_arg, uint8_t* finished, int pad_id, int eos_id,
+                                                                int eos_id2, int* out_ids, float* out_logp, int* tokens_out, long ldt,
+                                                                const bf16_t* E, long lde, int H, bf16_t* x, long ldx, float* ss, int nss,
+                                                                const int* pos0, int* pos_out, const float* cosT, const float* sinT, int hd,
+                                                                float* rope_rows) {
+    __shared__ uint64_t lists[64][64];            // [lane-row of the workgroup][rank]
+    __shared__ int tsel[64];
+    __shared__ float top_v[64];
+    __shared__ int top_i[64];
+    __shared__ float pick_ws[64];
+    const int row = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* tr = tmax + (long)row * ldm;
+    // every first-round request up front, from clamped addresses (no branch around a load)
+    float val[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + 1024 * e;
+        val[e] = tr[i < ntiles ? i : ntiles - 1];
+    }
+    uint32_t step_w = 0, fin_w = 0, pos_w = 0;
+    float rr[2] = {0.f, 0.f};
+    if (wave == 0) {
+        step_w = *reinterpret_cast<const uint32_t*>(step_ptr ? (const void*)step_ptr : (const void*)tr);
+        fin_w = *(finished ? finished + row : reinterpret_cast<const uint8_t*>(tr));
+        pos_w = *reinterpret_cast<const uint32_t*>(pos0 ? (const void*)(pos0 + row) : (const void*)tr);
+    }
+    // ---- A: per lane-row extraction
+    {
+        uint64_t key[EPT];
+        uint64_t best = 0ull;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + 1024 * e;
+            const uint64_t kk = cand_key(val[e], i);
+            key[e] = i < ntiles ? kk : 0ull;
+            best = key[e] > best ? key[e] : best;
+        }
+        const int lrow = tid >> 4;                // 0 .. 63
+        for (int round = 0; round < k; ++round) {
+            const uint64_t w = row_max_u64(best);
+            if ((lane & 15) == 0) lists[lrow][round] = w;
+            if (best == w && w != 0ull) {
+                best = 0ull;
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    key[e] = key[e] == w ? 0ull : key[e];
+                    best = key[e] > best ? key[e] : best;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    pin_u32(step_w); pin_u32(fin_w); pin_u32(pos_w);
+    const int step_v = step_ptr ? (int)step_w : step_arg, fin_v = finished ? (int)(fin_w & 0xffu) : 0;
+    // the rotary row of the position this token is fed at: requested now, stored at the end (hd <= 128: two floats per lane)
+    const int p_new = (int)pos_w + step_v;
+    const int half = hd >> 1;
+    if (rope_rows) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int d = lane + 64 * u;
+            const int dc = d < hd ? d : 0;
+            const float* tp = dc < half ? cosT + ((long)p_new * half + dc) : sinT + ((long)p_new * half + dc - half);
+            rr[u] = *tp;
+        }
+    }
+    // ---- B: lane = list; k rounds over the heads -> the k best tiles
+    {
+        int ptr = 0;
+        uint64_t head = lists[lane][0];
+        for (int round = 0; round < k; ++round) {
+            const uint64_t w = wave_max_u64(head);
+            if (lane == 0) tsel[round] = w ? 0x7fffffff - (int)(uint32_t)w : -1;
+            if (head == w && w != 0ull) {
+                ++ptr;
+                head = ptr < k ? lists[lane][ptr] : 0ull;
+            }
+        }
+    }
+    __syncthreads();                              // (one wave left: an LDS fence)
+    // ---- C: the logits of those tiles (16 k <= 64 NU values), all requested before the first is used
+    const float* lr = logits + (long)row * ldl;
+    float gv[NU];
+    int gi[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int j = lane + 64 * u;
+        const int tq = j >> 4;
+        const int t = tsel[tq < k ? tq : k - 1];
+        const int idx = t * 16 + (j & 15);
+        const bool ok = tq < k && t >= 0 && idx < V;
+        gi[u] = ok ? idx : -1;
+        gv[u] = lr[ok ? idx : 0];
+    }
+    uint64_t key[NU];
+    uint64_t best = 0ull;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        key[u] = gi[u] >= 0 ? cand_key(gv[u], gi[u]) : 0ull;
+        best = key[u] > best ? key[u] : best;
+    }
+    for (int round = 0; round < k; ++round) {
+        const uint64_t w = wave_max_u64(best);
+        if (lane == 0) {
+            top_v[round] = w ? unord_f32((uint32_t)(w >> 32)) : -3.0e38f;
+            top_i[round] = w ? 0x7fffffff - (int)(uint32_t)w : 0x7fffffff;
+        }
+        if (best == w && w != 0ull) {
+            best = 0ull;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                key[u] = key[u] == w ? 0ull : key[u];
+                best = key[u] > best ? key[u] : best;
+            }
+        }
+    }
+    __syncthreads();                              // (one wave left: an LDS fence)
+    int tok = 0;
+    if (lane == 0)
+        tok = sample_pick(pick_ws, top_v, top_i, k, row, temperature, top_p, do_sample, seed, step_v, fin_v, finished, pad_id,
+                          eos_id, eos_id2, out_ids, out_logp, tokens_out, ldt);
+    tok = wave_shfl_i(tok, 0);
+    if (rope_rows) {
+        if (hd <= 128) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int d = lane + 64 * u; if (d < hd) rope_rows[(long)row * hd + d] = rr[u]; }
+        } else {
+            for (int d = lane; d < hd; d += 64)
+                rope_rows[(long)row * hd + d] = d < half ? cosT[(long)p_new * half + d] : sinT[(long)p_new * half + d - half];
+        }
+    }
+    if (pos_out && lane == 0) pos_out[row] = p_new;
+    if (!E) return;
+    float acc = 0.f;
+    const int nch = H / 8;
+    const bf16_t* er = E + (long)tok * lde;
+    u32x4 ev[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int j = lane + 64 * u; ev[u] = ld16(er + (j < nch ? j : 0) * 8); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pin_u32x4(ev[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = lane + 64 * u;
+        if (j < nch) {
+            st16(x + (long)row * ldx + j * 8, ev[u]);
+            float f[8];
+            unpack8(ev[u], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += f[i] * f[i];
+        }
+    }
+    for (int j = lane + 256; j < nch; j += 64) {
+        const u32x4 v = ld16(er + j * 8);
+        st16(x + (long)row * ldx + j * 8, v);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += f[i] * f[i];
+    }
+    acc = wave_sum<64>(acc);
+    if (ss) for (int c = lane; c < nss; c += 64) ss[(long)row * nss + c] = c == 0 ? acc : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // General sampler: top_k = 0 (HF: top-k "disabled") or top_k > 64 — the warped distribution can then have thousands of survivors,
 // so the fast paths above (temperature / top-p / multinomial over <= 64 sorted survivors) do not apply.  One workgroup per row,
 // everything by passes over the row's logits (L2-resident: 600 KB at Qwen3's vocabulary):
@@ -796,6 +974,13 @@ extern "C" int bra_tile_max(const float* logits, long ldl, int B, int V, float* 
     return BRA_LAUNCH_STATUS();
 }
 
+// 1 = the one-launch form (sample_tiles_one_kernel) wherever the row's tile maxima fit 16 per thread (V <= 262 144); 0 = the two
+// launches of round 4 (larger vocabularies; A/B runs through the debug library's bra_sample_set_one_launch)
+static int g_sample_one_launch = 1;
+#ifdef BRA_DEBUG
+extern "C" int bra_sample_set_one_launch(int on) { g_sample_one_launch = on; return 0; }
+#endif
+
 // The sampler over tile maxima (see sample_tiles_kernel): logits fp32 [B, V] with tmax [B, ceil(V / 16)] = the maximum of every
 // 16-column tile (lm_head epilogue of the decode step, or bra_tile_max).  Same tokens as bra_sample / bra_sample_embed for the
 // same inputs.  ws: bra_sample_ws_floats words.  `step_ptr` null: the step index is `step`.  E / x / ss as bra_sample_embed.
@@ -817,6 +1002,17 @@ extern "C" int bra_sample_tiles(const float* logits, long ldl, const float* tmax
     if (ldm < ntiles) return BRA_ERR_ARG;
     if ((ntiles + kTileSlices - 1) / kTileSlices > 4096) return BRA_ERR_UNSUPPORTED;
     const int k = do_sample ? top_k : 1;
+    if (g_sample_one_launch && ntiles <= 1024 * 16) {
+#define BRA_ST1(EPT_, NU_)                                                                                                          \
+        BRA_LAUNCH((sample_tiles_one_kernel<EPT_, NU_>), dim3(B), dim3(1024), 0, stream, logits, ldl, V, tmax, ldm, ntiles, k,        \
+                   temperature, top_p, do_sample, (uint32_t)seed, step_ptr, step, (uint8_t*)finished, pad_id, eos_id, eos_id2,     \
+                   out_ids, out_logp, tokens_out, ldt, (const bf16_t*)E, lde, H, (bf16_t*)x, ldx, ss, nss, pos0, pos_out, cosT,    \
+                   sinT, hd, rope_rows)
+        if (ntiles <= 1024 * 10) { if (k <= 20) BRA_ST1(10, 5); else BRA_ST1(10, 16); }
+        else { if (k <= 20) BRA_ST1(16, 5); else BRA_ST1(16, 16); }
+#undef BRA_ST1
+        return BRA_LAUNCH_STATUS();
+    }
     float* cv = (float*)ws;
     int* ci = (int*)ws + (long)B * kTileSlices * k;
     const int per = (ntiles + kTileSlices - 1) / kTileSlices;

@@ -23,6 +23,11 @@ if os.environ.get("GV_SMALLM") == "1":
                    (tag + "_down", M, 2048, 6144, 64), (tag + "_d_gate_up", M, 2048, 12288, 128), (tag + "_d_down", M, 6144, 2048, 64),
                    (tag + "_d_qkv", M, 2048, 4096, 64), (tag + "_d_o", M, 2048, 2048, 64)]
     shapes += [("e_qkv", 2052, 3072, 1024, 0), ("e_o", 2052, 1024, 1024, 0), ("e_ffn_up", 2052, 8192, 1024, 0), ("e_ffn_dn", 2052, 1024, 4096, 0)]
+elif os.environ.get("GV_SFT") == "1":
+    # SFT (cfg-2) rows: M = 8 x 2180 = 17 440 — 68.1 tile-rows of 256: the N = 2048 projections are 552 ring tiles = 2.16 rounds
+    M = 17440
+    shapes = [("s_qkv", M, 4096, 2048, 128), ("s_o", M, 2048, 2048, 64), ("s_gate_up", M, 12288, 2048, 64), ("s_down", M, 2048, 6144, 64),
+              ("s_d_gate_up", M, 2048, 12288, 128), ("s_d_down", M, 6144, 2048, 64), ("s_d_qkv", M, 2048, 4096, 64), ("s_d_o", M, 2048, 2048, 64)]
 elif os.environ.get("GV_PREFILL") == "1":
     # one-prompt prefill / encoder shapes (M ~ 2 k): fewer than 192 256x128 tiles
     shapes = [("p_qkv", P1, 4096, 2048, 128), ("p_o", P1, 2048, 2048, 64), ("p_gate_up", P1, 12288, 2048, 64), ("p_down", P1, 2048, 6144, 64),
@@ -47,7 +52,15 @@ for name, M, N, K, K2 in shapes:
             get_lib().call("bra_gemm_set_variant", vv); c6 = ops.gemm_nt(a, b, a2=a2, b2=b2).float()
             print(name, "variant", vv, "max |v - v5| / max|v5| =", float((c6 - c5).abs().max() / c5.abs().max()), "mismatching elements", int((c6 != c5).sum()), flush=True)
         del c5, c6
-    for v in ((5, 9, 10, 7, 11, 12, 13, 14, -2, -1) if os.environ.get('GV_SMALLM') == '1' else ((5, 6, 7) if os.environ.get('GV_FAST') == '1' else (0, 4, 5, 6, 7))):
+    if os.environ.get("GV_SFT") == "1":
+        # current choice (auto at the 75 % ring fill gate), the ring gate at 70 % (ring + row split for 2.16 rounds), pinned tiles
+        for tag, v, fill in (("auto75", -1, 75), ("auto70", -1, 70), ("auto60", -1, 60), ("glds256", 5, 75), ("glds192", 9, 75), ("ring", 7, 75)):
+            get_lib().call("bra_gemm_set_variant", v); get_lib().call("bra_gemm_set_ring_fill", fill)
+            ms = timeit(lambda: ops.gemm_nt(a, b, a2=a2, b2=b2, out=c, res=rs))
+            res[tag] = round(2.0 * M * N * (K + K2) / ms / 1e9)
+        get_lib().call("bra_gemm_set_variant", -1); get_lib().call("bra_gemm_set_ring_fill", 60)
+    vs = (5, 9, 10, 7, 11, 12, 13, 14, -2, -1) if os.environ.get('GV_SMALLM') == '1' else ((5, 6, 7) if os.environ.get('GV_FAST') == '1' else (0, 4, 5, 6, 7))
+    for v in (() if os.environ.get("GV_SFT") == "1" else vs):
         get_lib().call("bra_gemm_set_variant", v)
         ms = timeit(lambda: ops.gemm_nt(a, b, a2=a2, b2=b2, out=c, res=rs))
         res[v] = round(2.0 * M * N * (K + K2) / ms / 1e9)
