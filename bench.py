@@ -702,6 +702,8 @@ def main():
     ap.add_argument("--round3-kernels", action="store_true",
                     help="A/B on one box: round 3's kernel choices (256-row LDS-DMA tiles only, block-index-fastest attention grids, "
                          "full-scan sampler + advance_counters launch); a secondary measurement, never the headline")
+    ap.add_argument("--one-launch-sampler", action="store_true",
+                    help="A/B on one box: the tile-maxima sampler as ONE launch (debug library knob; measured neutral, profiles/r6_l_sampler_ab.txt)")
     ap.add_argument("--completion-len", type=int, default=None)
     ap.add_argument("--lora-dropout", type=float, default=LORA_DROPOUT, help="PEFT lora_dropout of the policy pass (reference: 0.05)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the oracle timing leg and print its JSON")
@@ -750,13 +752,16 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
 
     from bioreason_amd import ops
-    if (args.no_w4_gemm or args.round3_kernels) and not dims.dry:
+    if (args.no_w4_gemm or args.round3_kernels or args.one_launch_sampler) and not dims.dry:
         # A/B flags pin tile variants: those knobs exist only in the debug build (include/bioreason_hip_debug.h), never in the product library
         from bioreason_amd import _lib as _bra_lib
         _bra_lib.use_debug_library()
     if args.no_w4_gemm:
         from bioreason_amd._lib import get_lib
         get_lib().call("bra_gemm_set_variant", -2)
+    if args.one_launch_sampler and not dims.dry:
+        from bioreason_amd._lib import get_lib
+        get_lib().call("bra_sample_set_one_launch", 1)
     if args.round3_kernels:
         from bioreason_amd._lib import get_lib
         get_lib().call("bra_gemm_set_variant", -2)

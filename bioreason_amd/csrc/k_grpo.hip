@@ -974,9 +974,12 @@ extern "C" int bra_tile_max(const float* logits, long ldl, int B, int V, float* 
     return BRA_LAUNCH_STATUS();
 }
 
-// 1 = the one-launch form (sample_tiles_one_kernel) wherever the row's tile maxima fit 16 per thread (V <= 262 144); 0 = the two
-// launches of round 4 (larger vocabularies; A/B runs through the debug library's bra_sample_set_one_launch)
-static int g_sample_one_launch = 1;
+// 0 = the two launches of round 4 (the product path); 1 = the one-launch form (sample_tiles_one_kernel, V <= 262 144), reachable
+// through the debug library's bra_sample_set_one_launch.  Measured on one MI355X (profiles/r6_l_sampler_ab.txt, r6_m_sampler_trace.txt):
+// the one launch takes 31.2 us against 9.6 + 18.2 us for the two (its extraction stage puts 16 waves of 64-bit compare / select
+// rounds on 8 CUs where the two-launch form spreads them over 64), the token step is the same within 0.5 us (1.1858 / 1.1841 against
+// 1.1862 / 1.1848 ms): the boundary it removes is worth what the concentration costs.  Kept for the A/B, not chosen.
+static int g_sample_one_launch = 0;
 #ifdef BRA_DEBUG
 extern "C" int bra_sample_set_one_launch(int on) { g_sample_one_launch = on; return 0; }
 #endif

@@ -28,7 +28,7 @@ int bra_gemm_set_ring_fill(int pct);
 /* row split of the per-shape choice (default on): when the last round of 256 x 256 tiles would be less than half full, the
  * tile-rows that fill whole rounds go to the ring kernel and the remaining rows to the 256 x 128 kernel (two launches) */
 int bra_gemm_set_row_split(int on);
-/* bra_sample_tiles as ONE launch (sample_tiles_one_kernel, default on) or as the two launches of round 4 (0): same tokens, A/B timing */
+/* bra_sample_tiles as ONE launch (sample_tiles_one_kernel; 1) or as the two launches of round 4 (0, the default): same tokens, A/B timing */
 int bra_sample_set_one_launch(int on);
 /* tile height of the LDS-DMA kernel (round 4): 0 = chosen per call (256 / 192 / 128 rows, whichever fills the 256 CUs best),
  * 256 = rounds 1-3 (A/B measurements); bra_gemm_set_variant(9 / 10) pins 192 / 128 together with the kernel */

@@ -758,6 +758,49 @@ def test_sampler_two_eos_ids_and_forced_token(backend):
     assert out.tolist() == [11, 44, 33]
 
 
+@pytest.mark.parametrize("V,k", [(151936, 20), (5003, 20), (9000, 1), (6000, 64), (300, 7), (200000, 20)])
+def test_one_launch_sampler_equals_two_launches(debug_backend, V, k):
+    """sample_tiles_one_kernel (round 6: the tile-maxima sampler as one 1024-thread workgroup per row — measured neutral, kept as an
+    opt-in of the debug library) draws the tokens, log-probs, embedding rows, RMSNorm statistics and rotary rows of the two-launch
+    form bit for bit: the k best tiles under a strict total order do not depend on how the maxima are dealt to the lists."""
+    from bioreason_amd._lib import get_lib
+    backend = debug_backend
+    B, H, hd = 3, 256, 64
+    g = torch.Generator().manual_seed(V * 3 + k)
+    logits = torch.randn(B, V, generator=g)
+    logits[1] = torch.round(logits[1] * 2) / 2
+    logits[2, :] = -1.0
+    logits[2, V - 1] = logits[2, 17] = logits[2, 16] = 3.0
+    dl = logits.to(backend)
+    tmax = ops.tile_max(dl)
+    E = (torch.randn(V, H, generator=g) * 0.05).to(torch.bfloat16).to(backend)
+    cosT = torch.randn(64, hd // 2, generator=g).to(backend)
+    sinT = torch.randn(64, hd // 2, generator=g).to(backend)
+    pos0 = torch.tensor([3, 9, 0], dtype=torch.int32, device=backend)
+    do_sample = k > 1
+    res = []
+    try:
+        for one in (0, 1):
+            get_lib().call("bra_sample_set_one_launch", one)
+            outs = []
+            for s_ in range(2 if backend.type == "cpu" else 24):
+                out = torch.empty(B, dtype=torch.int32, device=backend)
+                lp = torch.empty(B, device=backend)
+                x = torch.zeros(B, H, dtype=torch.bfloat16, device=backend)
+                ss = torch.zeros(B, 4, device=backend)
+                pos = torch.zeros(B, dtype=torch.int32, device=backend)
+                rows = torch.zeros(B, hd, device=backend)
+                ops.sample_tiles(dl, tmax, 0.7, k if do_sample else 0, 0.9, do_sample, 31, s_, None, 0, out, out_logp=lp,
+                                 embed=(E, x, ss), advance=(pos0, pos, cosT, sinT, hd, rows))
+                outs.append([t.cpu().clone() for t in (out, lp, x.float(), ss, pos, rows)])
+            res.append(outs)
+    finally:
+        get_lib().call("bra_sample_set_one_launch", 0)
+    for a, b in zip(res[0], res[1]):
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta, tb)
+
+
 @pytest.mark.parametrize("V,k", [(5000, 20), (5003, 20), (9000, 1), (6000, 64), (300, 7)])
 def test_sampler_over_tile_maxima_equals_full_scan(backend, V, k):
     """bra_sample_tiles (top-k over the maxima of the logits' 16-column tiles, then over the 16 k logits of the k best tiles) draws
