@@ -566,6 +566,7 @@ def make_grpo_leg(model, dims: Dims, R: int, Cn: int, rank: int, dev, args, eos_
                      overlap_rollout_weights=not getattr(args, "no_overlap_weights", False),
                      overlap_ref_chains=bool(getattr(args, "overlap_ref_chains", False)),
                      rollout_fp8=bool(getattr(args, "rollout_fp8", False)) if fp8 is None else bool(fp8),
+                     ref_fp8=bool(getattr(args, "ref_fp8", False)) if fp8 is None else bool(fp8),
                      grad_allreduce_dtype="bf16" if getattr(args, "grad_bf16", False) else "fp32")
     # the reference's reward hop runs inside the timed step: ids -> host -> decode -> the five python reward functions
     # reason.py:291-296 enables by default -> device (a synthetic id -> text table stands in for the tokenizer files)
@@ -696,6 +697,8 @@ def main():
                     help="BASELINE config 5's weight format in the token loop: e4m3 images of the merged weights, one fp32 scale per output "
                          "row (half the streamed bytes; W8A16).  An opt-in configuration with its own parity criterion "
                          "(tests/test_fp8_rollout.py), never the bf16 headline: the default run reports it as the secondary leg `rollout_fp8`")
+    ap.add_argument("--ref-fp8", action="store_true",
+                    help="with --rollout-fp8: the no-grad reference pass on the fp8 MFMA path too (GRPOConfig.ref_fp8; e4m3 images of the base weights)")
     ap.add_argument("--grad-bf16", action="store_true", help="gradient buckets travel as bf16 images (GRPOConfig.grad_allreduce_dtype); N > 1 only")
     ap.add_argument("--no-w4-gemm", action="store_true",
                     help="A/B on one box: the per-shape GEMM choice without the four-wave large-tile kernel (bra_gemm_set_variant(-2))")
@@ -856,10 +859,12 @@ def main():
                     "ms_per_token_step": e_tok,
                     "weight_bytes_per_token_step": fp8_weight_bytes(model),
                     "hbm_frac_of_peak": ((fp8_weight_bytes(model) + 0.366e9) / (e_tok * 1e-3) / 1e9 / PEAK_HBM_GBS) if e_tok else None,
-                    "workload": "the headline GRPO step with the rollout's token loop streaming fp8 (OCP e4m3) images of the merged, "
-                                "norm-folded weights — one fp32 scale per output row, decoded to bf16 in registers in front of the bf16 MFMAs "
-                                "(W8A16), lm_head included; prompt pass, reference pass, policy pass and gradients in bf16.  Rollouts are "
-                                "sampled from the quantised policy (BASELINE config 5 'fp8 weights'); parity: tests/test_fp8_rollout.py"}
+                    "workload": "the headline GRPO step with fp8 (OCP e4m3) images of the merged, norm-folded weights, one fp32 scale per output "
+                                "row: the token loop streams them and decodes to bf16 in registers in front of the bf16 MFMAs (W8A16, lm_head "
+                                "included); the rollout's PROMPT PASS and the no-grad REFERENCE pass run their projections on the fp8 MFMA path "
+                                "(v_mfma_scale_f32_16x16x128_f8f6f4, W8A8 with per-token activation scales; round 6); policy pass and gradients "
+                                "in bf16.  Rollouts are sampled from the quantised policy (BASELINE config 5 'fp8 weights'); parity: "
+                                "tests/test_fp8_rollout.py, tests/test_fp8_gemm.py"}
                 model.text_model.rollout_fp8 = False
                 del e_runner, e_step
             except Exception as e:

@@ -351,6 +351,41 @@ __device__ __forceinline__ u32x4 f8x8_to_bf16x8(unsigned lo, unsigned hi) {
 }
 #endif
 
+// ---- fp8 (OCP e4m3) MFMA, K = 128 per instruction: v_mfma_scale_f32_16x16x128_f8f6f4 — the matrix pipe's double-rate form on
+// gfx950 (MI355X_MICROARCH.md: MX-scaled K = 128 >= 4.66 PF/s; the non-scaled 16x16x32 fp8 form runs at the bf16 rate).  Operand layout
+// found by experiment (tools/ubench/mfma_fp8_layout.hip, profiles/r6_n_mfma_fp8_layout.txt): lane l of operand a holds 32 consecutive
+// bytes of row l & 15, k-group l >> 4 (the same for b with the column), a position of a meets the position of b with the same k-group
+// and byte; C/D as every 16 x 16 shape (row 4 (l >> 4) + r of a's rows, column l & 15 of b's).  Block scales (E8M0, one byte per lane
+// and operand) are passed as 2^0: the per-row / per-token fp32 scales of the GEMM are applied to the accumulators in its epilogue.
+#ifdef BRA_EMU
+__device__ inline f32x4 mfma_fp8_16x16x128(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x4 c) {
+    uint32_t mine[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const uint32_t* x = bra_emu::wave_exchange(mine, 16);
+    const int l = bra_emu::lane_id();
+    const int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t* la = x + (size_t)(row + 16 * g) * 16;
+            const uint32_t* lb = x + (size_t)(col + 16 * g) * 16 + 8;
+            for (int j = 0; j < 32; ++j)
+                acc += e4m3_to_f32((la[j >> 2] >> (8 * (j & 3))) & 0xffu) * e4m3_to_f32((lb[j >> 2] >> (8 * (j & 3))) & 0xffu);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+#else
+__device__ __forceinline__ f32x4 mfma_fp8_16x16x128(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x4 c) {
+    typedef int i32x8_hw __attribute__((ext_vector_type(8)));
+    const i32x8_hw a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    const i32x8_hw b = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+#endif
+
+
 // returns x but hides its origin from the compiler: address arithmetic built on it cannot be hoisted out of a loop
 // (hipcc otherwise computes every lane-constant address at kernel entry and spills it around the tile loop)
 #ifdef BRA_EMU

@@ -670,6 +670,137 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------
+// fp8 x fp8 GEMM on the double-rate matrix path (round 6; BASELINE config 5 "fp8 weights (CDNA4 fp8 MFMA)"):
+//   C[m, n] = sa[m] * sb[n] * sum_k A8[m, k] * B8[n, k]  (+ res),   A8 / B8 OCP e4m3 bytes, K % 128 == 0,
+// sa = one fp32 scale per activation row (per token), sb = one per weight row (per output feature), both applied to the fp32
+// accumulators in the epilogue.  The structure is gemm_glds_kernel's with the byte geometry unchanged — a K-tile is 128 fp8 = the
+// same 128 bytes per row, LDS-DMA pieces of 8 rows, XOR swizzle on the source side, three stages, counted vmcnt — and ONE
+// v_mfma_scale_f32_16x16x128_f8f6f4 per (16 x 16 fragment pair, K-tile): a lane's operand is the two 16-byte chunks 2 fq, 2 fq + 1 of
+// its row (bra_device.h: mfma_fp8_16x16x128).  Per K-tile and wave: (MI + 4) x 2 ds_read_b128 for 4 MI MFMAs of 8 passes each —
+// the same LDS bytes per matrix-pipe cycle as the bf16 kernel.  The K-tile is computed in two halves (fragment columns 0-1, then
+// 2-3) with the reads of the second half issued before the MFMAs of the first.
+struct Gemm8Args {
+    const unsigned char* A; long lda;
+    const unsigned char* B; long ldb;
+    const float* sa;
+    const float* sb;
+    GemmArgs e;                       // C, ldc, M, N, alpha, bias, res, ldres of the shared epilogues (K / A / B unused)
+    int K;
+};
+
+template <int EPI, int MI = 4>
+__global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Args g8) {
+    constexpr int BM = 64 * MI, BN = 128, BKB = 128;                  // BKB: bytes (= fp8 elements) per row and K-tile
+    constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB, STAGE = A_BYTES + B_BYTES;
+    const GemmArgs& g = g8.e;
+    BRA_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = (int)xcd_remap(blockIdx.x, (unsigned)ntiles);
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int gid = bid / per_group;
+    const int first_m = gid * GROUP;
+    const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int tile_m = first_m + (bid % per_group) % gsize;
+    const int tile_n = (bid % per_group) / gsize;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nt = g8.K / BKB;
+
+    const int prow = lane >> 3, lchunk = ((lane & 7) ^ (lane >> 3)) * 16;
+    int rowA[MI], rowB[2];
+#pragma unroll
+    for (int j = 0; j < MI; ++j) { int r = m0 + wave * (8 * MI) + j * 8 + prow; rowA[j] = r < g.M ? r : g.M - 1; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { int r = n0 + wave * 16 + j * 8 + prow; rowB[j] = r < g.N ? r : g.N - 1; }
+    auto issue = [&](int kt, int stage) {
+        char* sa_ = smem + stage * STAGE + wave * (8 * MI * 128);
+        char* sb_ = smem + stage * STAGE + A_BYTES + wave * (16 * 128);
+        const unsigned char* Ap = g8.A + (long)kt * BKB + lchunk;
+        const unsigned char* Bp = g8.B + (long)kt * BKB + lchunk;
+#pragma unroll
+        for (int j = 0; j < MI; ++j) glds16(Ap + (long)rowA[j] * g8.lda, sa_ + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(Bp + (long)rowB[j] * g8.ldb, sb_ + j * 1024);
+    };
+    constexpr int NDMA = MI + 2;
+
+    f32x4 acc[4][MI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    auto read_a = [&](int stg, u32x4 (&fa)[MI][2]) {
+        const char* sa_ = smem + stg * STAGE;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int rowa = wm * (16 * MI) + i * 16 + fr;
+            fa[i][0] = ld16(sa_ + rowa * 128 + swz_chunk<64>(rowa, 2 * fq) * 16);
+            fa[i][1] = ld16(sa_ + rowa * 128 + swz_chunk<64>(rowa, 2 * fq + 1) * 16);
+        }
+    };
+    auto read_b = [&](int stg, int half, u32x4 (&fb)[2][2]) {
+        const char* sb_ = smem + stg * STAGE + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rowb = wn * 64 + (2 * half + i) * 16 + fr;
+            fb[i][0] = ld16(sb_ + rowb * 128 + swz_chunk<64>(rowb, 2 * fq) * 16);
+            fb[i][1] = ld16(sb_ + rowb * 128 + swz_chunk<64>(rowb, 2 * fq + 1) * 16);
+        }
+    };
+    auto mma = [&](int half, const u32x4 (&fa)[MI][2], const u32x4 (&fb)[2][2]) {
+        setprio(1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                acc[2 * half + i][mi] = mfma_fp8_16x16x128(fb[i][0], fb[i][1], fa[mi][0], fa[mi][1], acc[2 * half + i][mi]);
+        setprio(0);
+    };
+
+    issue(0, 0);
+    if (nt > 1) { issue(1, 1); wait_vmcnt<NDMA>(); } else { wait_vmcnt<0>(); }
+    raw_barrier();
+    int stage = 0;
+    u32x4 fa[MI][2], fb0[2][2], fb1[2][2];
+    read_a(0, fa);
+    read_b(0, 0, fb0);
+    for (int t = 0; t < nt; ++t) {
+        int s2 = stage + 2; s2 = s2 >= 3 ? s2 - 3 : s2;
+        const int s1 = stage + 1 == 3 ? 0 : stage + 1;
+        const bool ahead = t + 2 < nt;
+        if (ahead) issue(t + 2, s2);                       // stage s2 was last read during step t - 1: every wave is past that barrier
+        read_b(stage, 1, fb1);
+        mma(0, fa, fb0);
+        mma(1, fa, fb1);
+        if (ahead) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();
+        raw_barrier();                                     // all reads of `stage` are done, tile t + 1 has landed
+        if (t + 1 < nt) { read_a(s1, fa); read_b(s1, 0, fb0); }
+        stage = s1;
+    }
+    // the two scale vectors: lane owns C[mw0 + 16 mi + fr][nw0 + 16 ni + 4 fq .. + 3]
+    const int mw0 = m0 + wm * (16 * MI), nw0 = n0 + wn * 64;
+    float sm[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) { const int m = mw0 + mi * 16 + fr; sm[mi] = g8.sa[m < g.M ? m : g.M - 1]; }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        float sn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int n = nw0 + ni * 16 + 4 * fq + r; sn[r] = g8.sb[n < g.N ? n : g.N - 1]; }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ni][mi][r] *= sm[mi] * sn[r];
+    }
+    gemm_epilogue_w<EPI, MI>(g, acc, mw0, nw0, lane);
+}
+
+// ---------------------------------------------------------------------------
 // FOUR waves with LARGE per-wave tiles (late round 4; opt-in: bra_gemm_set_variant(11..14)).  What the tuned library runs on the
 // one-prompt shapes (profiles/r4_l_hipblaslt_kernels.txt): one wave per SIMD with the whole register file, a 16 WM x 16 WN tile per
 // wave (2 x 2 waves: macro tile 32 WM x 32 WN), i.e. (WM + WN) fragment reads per WM x WN MFMAs — 0.33 for 5 x 8 against 0.5 / 0.75 of
@@ -1386,6 +1517,35 @@ extern "C" int bra_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb
     if (M <= 16) return launch_skinny(g, out_f32, (bra_stream_t)stream);   // decode: weight-streaming kernel
     if (out_f32) return dispatch_bk<EPI_F32>(g, (bra_stream_t)stream);
     return dispatch_bk<EPI_BF16>(g, (bra_stream_t)stream);
+}
+
+// fp8 x fp8 GEMM (gemm_fp8_kernel): C [M, N] bf16 (or fp32) = sa[m] sb[n] (A8 B8^T) (+ res).  A8 [M, K], B8 [N, K]: OCP e4m3 bytes, row
+// strides in bytes (multiples of 16); K % 128 == 0.  The quantised images come from bra_quant_rows_fp8 / bra_swiglu_quant_fp8.
+extern "C" int bra_gemm_fp8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, void* C, long ldc,
+                               int M, int N, int K, const void* res, long ldres, int out_f32, void* stream) {
+    if (M == 0 || N == 0) return 0;
+    if (M < 0 || N < 0 || K <= 0 || K % 128 || !A8 || !B8 || !sa || !sb || !C || lda % 16 || ldb % 16 || ldc % 4) return BRA_ERR_ARG;
+    if (out_f32 && res) return BRA_ERR_ARG;
+    Gemm8Args g8 = {};
+    g8.A = (const unsigned char*)A8; g8.lda = lda; g8.B = (const unsigned char*)B8; g8.ldb = ldb; g8.sa = sa; g8.sb = sb; g8.K = K;
+    g8.e.C = C; g8.e.ldc = ldc; g8.e.M = M; g8.e.N = N; g8.e.K = K; g8.e.alpha = 1.f; g8.e.res = (const bf16_t*)res; g8.e.ldres = ldres;
+    // tile height as for the bf16 LDS-DMA kernel: rounds of 256 workgroups x rows / relative efficiency
+    const int rows = pick_glds_rows(g8.e);
+    bra_stream_t st = (bra_stream_t)stream;
+#define BRA_G8(EPI_, MI_)                                                                                             \
+    do {                                                                                                              \
+        constexpr int BM_ = 64 * MI_;                                                                                 \
+        const int tiles = ((M + BM_ - 1) / BM_) * ((N + 127) / 128);                                                  \
+        const size_t smem = 3 * (size_t)(BM_ + 128) * 128;                                                            \
+        BRA_ALLOW_SMEM((gemm_fp8_kernel<EPI_, MI_>), smem);                                                           \
+        BRA_LAUNCH((gemm_fp8_kernel<EPI_, MI_>), dim3(tiles), dim3(512), smem, st, g8);                                \
+        return BRA_LAUNCH_STATUS();                                                                                   \
+    } while (0)
+    if (out_f32) { if (rows == 128) BRA_G8(EPI_F32, 2); if (rows == 192) BRA_G8(EPI_F32, 3); BRA_G8(EPI_F32, 4); }
+    if (rows == 128) BRA_G8(EPI_BF16, 2);
+    if (rows == 192) BRA_G8(EPI_BF16, 3);
+    BRA_G8(EPI_BF16, 4);
+#undef BRA_G8
 }
 
 extern "C" int bra_gemm_bf16_nt_splitk(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M,

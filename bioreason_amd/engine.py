@@ -227,10 +227,76 @@ class QwenEngine:
             raise NotImplementedError("LoRA dropout needs r = 32 (one mask stream per 32-column rank block)")
         return (m.drop_p, lora_drop_seeds(m.drop_seed, li, group, len(G.n_sizes)))
 
+    # ------------------------------------------------------------------ fp8 x fp8 projections (opt-in; BASELINE config 5)
+    def use_fp8(self, W8):
+        """context: every no-grad layer forward issued inside runs its four projections on the fp8 MFMA path (ops.gemm_fp8_nt) over
+        `W8` = one record per layer {"Wqkv": (q, s), "Wo": .., "Wgu": .., "Wd": ..} of row-major e4m3 images + row scales
+        (fp8_weight_images) — the prompt pass of an fp8 rollout (merged policy weights) and, with GRPOConfig.ref_fp8, the reference
+        pass (base weights).  None = the bf16 path."""
+        eng = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.prev = getattr(eng, "_fp8", None)
+                eng._fp8 = W8
+
+            def __exit__(self_, *a):
+                eng._fp8 = self_.prev
+        return _Ctx()
+
+    def fp8_supported(self) -> bool:
+        """the fp8 GEMM takes K % 128 == 0 (one MFMA per 128-byte K-tile) and row strides of whole 16-byte chunks"""
+        return self.H % 128 == 0 and self.F % 128 == 0 and self.Nq % 128 == 0
+
+    def fp8_weight_images(self, merged=None):
+        """row-major e4m3 images of the layers' projections: q[n, k] = e4m3(W[n, k] w[k] / s[n]) with the input's RMSNorm weight w
+        folded into Wqkv / Wgu (bra_dec_pack_weights_fp8's rule: the token loop's fragment-ordered image holds the same bytes).
+        merged: per-layer dicts {"Wqkv", "Wo", "Wgu", "Wd"} of LoRA-merged weights ([gate; up] rows NOT interleaved); None = base."""
+        out = []
+        for li, L in enumerate(self.layers):
+            W = merged[li] if merged is not None else {"Wqkv": L.Wqkv, "Wo": L.Wo, "Wgu": L.Wgu, "Wd": L.Wd}
+            out.append({"Wqkv": ops.quant_rows_fp8(W["Wqkv"], colw=L.ln1), "Wo": ops.quant_rows_fp8(W["Wo"]),
+                        "Wgu": ops.quant_rows_fp8(W["Wgu"], colw=L.ln2), "Wd": ops.quant_rows_fp8(W["Wd"])})
+        return out
+
+    def _layer_fwd_fp8(self, li: int, x: torch.Tensor, m: SeqMeta, kv_out, R):
+        """layer_fwd(save=False) with W8A8 projections: activations quantised per token (e4m3, absmax / 448), the RMSNorm row factor on
+        the activation scale (y = rstd (x (W w)^T), as the token loop computes it), fp32 accumulation, bf16 outputs; attention,
+        rotary, q / k norms and the residual stream stay bf16.  No LoRA branch: `R` holds merged (or base) weights."""
+        L = self.layers[li]
+        B, S, T = m.B, m.S, m.B * m.S
+        cosT, sinT = self.rope(m.max_pos or m.S)
+        xq, xs = ops.quant_rows_fp8(x, rms_eps=self.eps)
+        qkv = ops.gemm_fp8_nt(xq, xs, R["Wqkv"][0], R["Wqkv"][1])
+        q = torch.empty((B, S, self.Hq, self.hd), dtype=BF16, device=x.device)
+        if kv_out is None:
+            k = torch.empty((B, S, self.Hkv, self.hd), dtype=BF16, device=x.device)
+            v = torch.empty((B, S, self.Hkv, self.hd), dtype=BF16, device=x.device)
+            s_off = 0
+        else:
+            kc, vc, s_off = kv_out[:3]
+            k, v = kc.permute(0, 2, 1, 3), vc.permute(0, 2, 1, 3)
+        ops.qk_norm_rope_fwd(qkv, L.qn, L.kn, cosT, sinT, m.pos, S, self.Hq, self.Hkv, self.hd, self.eps, 1.0, q, k, v, s_off)
+        if kv_out is not None:
+            k, v = k[:, :s_off + S], v[:, :s_off + S]
+        vt = ops.head_transpose(v)
+        if kv_out is not None and len(kv_out) > 3 and kv_out[3] is not None:
+            kv_out[3].append(vt)
+        o, _ = ops.attn_fwd(q, k, vt, m.kmask, True, self.scale, need_lse=False)
+        oq, os_ = ops.quant_rows_fp8(o.view(T, self.Nq))
+        h = ops.gemm_fp8_nt(oq, os_, R["Wo"][0], R["Wo"][1], res=x)
+        hq, hs = ops.quant_rows_fp8(h, rms_eps=self.eps)
+        gu = ops.gemm_fp8_nt(hq, hs, R["Wgu"][0], R["Wgu"][1])
+        aq, as_ = ops.swiglu_quant_fp8(gu)
+        return ops.gemm_fp8_nt(aq, as_, R["Wd"][0], R["Wd"][1], res=h)
+
     # ------------------------------------------------------------------ one decoder layer
     def layer_fwd(self, li: int, x: torch.Tensor, m: SeqMeta, save: bool, kv_out=None):
         """x [T, H] bf16 -> y [T, H].  kv_out = (kcache, vcache, s_off): also write K/V rows into a cache
         [B, Hkv, Smax, hd] (prefill) and attend over the cache view."""
+        w8 = getattr(self, "_fp8", None)
+        if w8 is not None and not save:
+            return self._layer_fwd_fp8(li, x, m, kv_out, w8[li]), None
         L = self.layers[li]
         B, S, T = m.B, m.S, m.B * m.S
         cosT, sinT = self.rope(m.max_pos or m.S)

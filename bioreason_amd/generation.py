@@ -33,9 +33,15 @@ class KVCache:
 
 @torch.no_grad()
 def prefill(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, cache: KVCache, pos: torch.Tensor,
-            vt_sink=None):
-    """Runs the prompt through the stack writing K/V into the cache; returns the last-position hidden rows [B, H]."""
+            vt_sink=None, decode_rows: int = 8):
+    """Runs the prompt through the stack writing K/V into the cache; returns the last-position hidden rows [B, H].
+    In an fp8 rollout (rollout_fp8_enabled) the projections run on the fp8 MFMA path over the quantised weights the token loop streams
+    (decode_rows: the batch of that loop — its weight set is the one consulted)."""
     eng = model.ensure_packed()
+    w8 = prefill_fp8_weights(model, decode_rows)
+    if w8 is not None and getattr(eng, "_fp8", None) is None:
+        with eng.use_fp8(w8):
+            return prefill(model, inputs_embeds, attention_mask, cache, pos, vt_sink=vt_sink, decode_rows=decode_rows)
     B, S, H = inputs_embeds.shape
     kmask = attention_mask.to(torch.uint8).contiguous()
     dev = inputs_embeds.device
@@ -192,6 +198,11 @@ def rollout_weights(model, rows: int = 8):
                     for nm, (q, sc) in q8.items():
                         rec[nm + "_q"], rec[nm + "_s"] = q, sc
                     rec["fp8"], rec["folded"] = True, True
+                    if fp8_prefill_enabled() and eng.fp8_supported():
+                        # the same quantised weights, row-major, for the prompt pass on the fp8 MFMA path (engine._layer_fwd_fp8):
+                        # same rule and rounding as the fragment-ordered image above ([gate; up] rows not interleaved there)
+                        rec["rm8"] = {"Wqkv": ops.quant_rows_fp8(rec["Wqkv"], colw=L.ln1), "Wo": ops.quant_rows_fp8(rec["Wo"]),
+                                      "Wgu": ops.quant_rows_fp8(wgu, colw=L.ln2), "Wd": ops.quant_rows_fp8(rec["Wd"])}
                     for nm in ("Wqkv", "Wo", "Wgu", "Wd"):
                         rec[nm + "_p"] = rec[nm + "_q"]            # (one pointer set for `_packed_ok` / the descriptor table)
                     out.append(rec)
@@ -204,6 +215,21 @@ def rollout_weights(model, rows: int = 8):
         out.append(rec)
     eng._rollout = (key, out)
     return out
+
+
+def fp8_prefill_enabled() -> bool:
+    """the prompt pass of an fp8 rollout on the fp8 MFMA path (default with rollout_fp8; BRA_FP8_PREFILL=0: bf16 prompt pass, round 5's form)"""
+    return os.environ.get("BRA_FP8_PREFILL", "1") == "1"
+
+
+def prefill_fp8_weights(model, decode_rows: int):
+    """per-layer row-major e4m3 images of the merged policy weights, or None (bf16 rollout, wide decode, a layer the fp8 kernels refuse)"""
+    if not (rollout_fp8_enabled(model) and fp8_prefill_enabled()):
+        return None
+    rw = rollout_weights(model, rows=decode_rows)
+    if not all(r.get("rm8") is not None for r in rw):
+        return None
+    return [r["rm8"] for r in rw]
 
 
 def rollout_fp8_enabled(model) -> bool:
@@ -600,7 +626,7 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
     use_shared = (grp is not None and shared_prefix_decode and native_step and decode_impl == "fused" and eng.hd >= 64 and rows_ok)
     if prompt_alias is None:
         cache = KVCache(eng, B, Smax, dev)
-        hid = prefill(model, inputs_embeds, attention_mask, cache, pos_prompt)
+        hid = prefill(model, inputs_embeds, attention_mask, cache, pos_prompt, decode_rows=B)
     else:
         # identical prompts (GRPO: the G copies of a prompt, grpo_trainer.py:107-116) are prefetched once: the rows of a
         # batched forward are independent, so the K/V rows and the last hidden state of a copy equal its representative's
@@ -612,13 +638,13 @@ def generate(model, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, m
             # decode reads ONE copy of the prompt K / V^T per prompt (bra_dec_attn_shared); no per-copy replication
             cache_r = KVCache(eng, len(reps), P, dev)
             vtp = []
-            hid_r = prefill(model, inputs_embeds[sel], attention_mask[sel], cache_r, pos_prompt[sel], vt_sink=vtp)
+            hid_r = prefill(model, inputs_embeds[sel], attention_mask[sel], cache_r, pos_prompt[sel], vt_sink=vtp, decode_rows=B)
             shared = SharedDecodeState(model, cache_r, vtp, grp[0], grp[1], P, max_new_tokens)
             pmask = am[sel].to(torch.uint8).contiguous()
             cache = None
         else:
             cache_r = KVCache(eng, len(reps), Smax, dev)
-            hid_r = prefill(model, inputs_embeds[sel], attention_mask[sel], cache_r, pos_prompt[sel])
+            hid_r = prefill(model, inputs_embeds[sel], attention_mask[sel], cache_r, pos_prompt[sel], decode_rows=B)
             cache = KVCache.__new__(KVCache)
             cache.Smax = Smax
             cache.k = [t.index_select(0, gmap) for t in cache_r.k]

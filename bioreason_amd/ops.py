@@ -620,6 +620,39 @@ def dec_pack_weights_fp8(W: torch.Tensor, act: bool = False, out_f32: bool = Fal
     return q, scale
 
 
+def quant_rows_fp8(x: torch.Tensor, colw: Optional[torch.Tensor] = None, rms_eps: Optional[float] = None):
+    """x [M, K] bf16 -> (q uint8 [M, K] e4m3, scale fp32 [M]) (bra_quant_rows_fp8).  colw: bf16 [K] multiplied in first (a weight with
+    its input's RMSNorm weight folded); rms_eps given: scale = rstd * absmax / 448 (rows feeding a folded-norm projection)."""
+    M, K = x.shape
+    q = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    scale = torch.empty((M,), dtype=torch.float32, device=x.device)
+    get_lib().call("bra_quant_rows_fp8", x, _ld(x), M, K, colw, q, K, scale, int(rms_eps is not None),
+                   float(rms_eps if rms_eps is not None else 0.0), current_stream(x))
+    return q, scale
+
+
+def swiglu_quant_fp8(gu: torch.Tensor):
+    """[gate | up] rows [M, 2 F] bf16 -> (q uint8 [M, F], scale [M]) of act = bf16(bf16(silu(gate)) up) (bra_swiglu_quant_fp8)"""
+    M, F2 = gu.shape
+    F = F2 // 2
+    q = torch.empty((M, F), dtype=torch.uint8, device=gu.device)
+    scale = torch.empty((M,), dtype=torch.float32, device=gu.device)
+    get_lib().call("bra_swiglu_quant_fp8", gu, _ld(gu), M, F, q, F, scale, current_stream(gu))
+    return q, scale
+
+
+def gemm_fp8_nt(a8: torch.Tensor, sa: torch.Tensor, b8: torch.Tensor, sb: torch.Tensor, res: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+    """C [M, N] = sa[m] sb[n] (a8 b8^T) (+ res) on the fp8 MFMA path (bra_gemm_fp8_nt); a8 [M, K], b8 [N, K] uint8 (e4m3), K % 128 == 0"""
+    M, K = a8.shape
+    N = b8.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=a8.device)
+    get_lib().call("bra_gemm_fp8_nt", a8, a8.stride(0), sa, b8, b8.stride(0), sb, out, _ld(out), M, N, K, res,
+                   _ld(res) if res is not None else 0, int(out_f32), current_stream(a8))
+    return out
+
+
 def dec_gemm2_fp8(x, Wq, scale, ss_in=None, eps=1e-6, res=None, act=False, out_f32=False, want_ss=False, tile_max=None):
     """decode-time projection over fp8 weights (bra_dec_gemm2_fp8): y = [rstd] scale[n] (x q^T) (+res | SwiGLU | fp32);
     `ss_in` given = the input's RMSNorm weight was folded into the weights; returns (y, ss_out or None); None when unsupported"""

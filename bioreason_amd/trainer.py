@@ -65,6 +65,11 @@ class GRPOConfig:
     # the reference pass and the gradients stay bf16 — i.e. the behaviour policy differs from the trained one by quantisation noise, as
     # with any fp8 rollout engine; never on in the bf16 headline.
     rollout_fp8: bool = False
+    # opt-in, with rollout_fp8 (round 6): the prompt pass of the rollout runs its projections on the fp8 MFMA path over the same quantised
+    # weights (generation.prefill: W8A8, per-token activation scales — on by default with rollout_fp8, BRA_FP8_PREFILL=0 restores the bf16
+    # prompt pass); ref_fp8 also runs the no-grad REFERENCE pass that way over e4m3 images of the base weights (the KL term then measures
+    # the distance to the quantised reference policy).  The policy pass and every gradient stay bf16.
+    ref_fp8: bool = False
     grad_buckets: int = 4
     # transport dtype of the gradient all-reduce: "fp32" (default: the flat arena itself, 148 MB) or "bf16" (each bucket is rounded to a
     # bf16 image, summed over the ranks in bf16 and widened back: half the xGMI bytes, one rounding per rank and per sum step — DDP's
@@ -322,7 +327,15 @@ class GRPOStepRunner(_DataParallelStep):
         ref_join = None
         if c.beta != 0.0:
             def ref_pass():
-                with torch.no_grad(), m.text_model.disable_adapter():
+                eng_ = m.text_model.ensure_packed()
+                w8 = None
+                if c.ref_fp8 and eng_.fp8_supported():          # (other widths keep the bf16 reference pass: the flag never fails a run)
+                    sig = getattr(m.text_model, "_packed_sig", None)
+                    cached = getattr(eng_, "_ref_fp8", None)
+                    if cached is None or cached[0] != sig:
+                        cached = eng_._ref_fp8 = (sig, eng_.fp8_weight_images())      # base weights: static, built once
+                    w8 = cached[1]
+                with torch.no_grad(), m.text_model.disable_adapter(), eng_.use_fp8(w8):
                     if batch.get("prompt_alias") is not None:
                         return grpo.per_token_logps_shared_prefix(m, prompt_ids, prompt_mask, completion_ids, cmask,
                                                                   batch["prompt_alias"], side=ref_side2, **mm)

@@ -220,6 +220,22 @@ int bra_dec_pack_weights_fp8(const void* W, long ldw, int N, int K, int act, int
 int bra_dec_gemm2_fp8(const void* x, long ldx, const float* ss_in, int nss_in, float eps, const void* Wq, const float* wscale,
                       const void* res, long ldres, void* out, long ldo, float* ss_out, int nss_out, int M, int N, int K, int act,
                       int out_f32, int norm_folded, void* stream);
+/* ---- fp8 x fp8 GEMM on the fp8 MFMA path (round 6; BASELINE config 5 "fp8 weights (CDNA4 fp8 MFMA)"; k_gemm.hip gemm_fp8_kernel,
+ * k_quant.hip) — the prompt pass and the no-grad reference pass of an fp8 rollout run: the behaviour policy's MFMA-bound passes on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 (OCP e4m3 operands, fp32 accumulation, block scales 2^0), per-row fp32 scales in the epilogue.
+ * bra_quant_rows_fp8: x [M, K] bf16 -> q [M, K] e4m3 (ldq bytes) + scale [M]: a = max_k |x colw| / 448 (1 for a zero row),
+ *   q = e4m3(x colw / a) round-to-nearest-even, saturating; colw (optional, bf16 [K]) is multiplied in first — with W and the input's
+ *   RMSNorm weight this is bra_dec_pack_weights_fp8's rule, so the token loop's image of the weight holds the same bytes in another
+ *   order.  rms != 0: scale = a * rsqrt(mean_k x^2 + eps): the row factor of a folded-norm projection, y = rstd (x (W w)^T).
+ * bra_swiglu_quant_fp8: [gate | up] rows -> the e4m3 image + scale of act = bf16(bf16(silu(gate)) up) (bra_swiglu_fwd's roundings).
+ * bra_gemm_fp8_nt: C [M, N] (bf16, or fp32 with out_f32) = sa[m] sb[n] (A8 B8^T) (+ res bf16); K % 128 == 0, lda / ldb bytes % 16.
+ * Replaces the nn.Linear forwards of TF:qwen3:225-236, :81-83 under W8A8 per-row / per-token quantisation (opt-in; the bf16 path
+ * never calls these). */
+int bra_quant_rows_fp8(const void* x, long ldx, int M, int K, const void* colw, void* q, long ldq, float* scale, int rms, float eps,
+                       void* stream);
+int bra_swiglu_quant_fp8(const void* gu, long ldgu, int M, int F, void* q, long ldq, float* scale, void* stream);
+int bra_gemm_fp8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, void* C, long ldc, int M, int N,
+                    int K, const void* res, long ldres, int out_f32, void* stream);
 /* W [N, K] -> the fragment order bra_dec_gemm2 streams with `packed` = 1 (same act / out_f32 flags as the projection it feeds:
  * they select the tile mode): every wave-instruction of the weight stream then reads one contiguous KiB of full 128-byte lines
  * instead of 16 row segments of 64 bytes.  out: N * K bf16.  BRA_ERR_UNSUPPORTED when N, K are not tile multiples.

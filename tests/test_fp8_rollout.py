@@ -181,7 +181,8 @@ def test_rollout_over_fp8_weights_against_the_oracle_with_the_same_fake_quantise
     from bioreason_amd import configs, generation
     from bioreason_amd.modeling import Qwen3ForCausalLM
     from oracle import dna_llm_oracle as O
-    dev = hip_device
+    monkeypatch.setenv("BRA_FP8_PREFILL", "0")        # this test pins the TOKEN LOOP (W8A16) against an oracle whose prompt K / V are bf16;
+    dev = hip_device                                  # the W8A8 prompt pass has its own oracle: tests/test_fp8_gemm.py
     L, V, P, T, copies = 2, 8192, 200, 12, 8
     tc = dict(vocab_size=V, hidden_size=2048, intermediate_size=6144, num_hidden_layers=L, num_attention_heads=16, num_key_value_heads=8,
               head_dim=128, rope_theta=1e6, max_position_embeddings=4096)
