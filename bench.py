@@ -810,6 +810,14 @@ def main():
     # hipMalloc inside a measured phase has been seen to cost 100 ms on a loaded host —, the second one is reported)
     step(args.warmup + args.steps, timing=True)
     step(args.warmup + args.steps, timing=True)
+    # N > 1 (or the one-rank RCCL rehearsal): one more untimed, overlapped step with per-bucket stamps — when each gradient bucket was
+    # handed to the collective and when the step had waited for it, against the end of the backward (trainer.bucket_report)
+    dp_buckets = None
+    if getattr(runner, "dp", False) and dev.type == "cuda" and hasattr(runner, "bucket_report"):
+        runner.trace_buckets = True
+        step(args.warmup + args.steps + 2)
+        dp_buckets = runner.bucket_report()
+        runner.trace_buckets = False
     # the same GEMM family with the chains of the step issued on ONE stream (one more untimed step): in the timed steps the reference
     # pass and the two chains of the policy pass run concurrently, so a HIP-event pair around a launch also spans time in which the
     # kernel shares the chip (or waits for a CU) — this figure is the per-kernel one that a rocprof trace of a serial run would give
@@ -970,6 +978,7 @@ def main():
             "phases_ms": {k: round(v, 2) for k, v in headline_timers.items()},
             "loss": loss,
             "timed_region_diagnostics": headline_diag,
+            **({"dp_buckets": dp_buckets} if dp_buckets else {}),
             "hbm_reserved_gib": (torch.cuda.max_memory_reserved(dev) / 2.0 ** 30) if dev.type == "cuda" else None,   # peak of the caching allocator over all legs run so far (of 288)
             "parity_tolerance": "bf16-noise-relative: every compared quantity within 1.25x the reference's OWN bf16-vs-fp32 distance "
                                 "(tests/test_fullsize_parity.py, tests/test_model_parity.py); north_star's 1e-3 rel is below one bf16 "

@@ -125,6 +125,12 @@ class _DataParallelStep:
         self.dp = dist.is_initialized() and (self.world > 1 or os.environ.get("BRA_DP_SINGLE_RANK") == "1")
         self.timers: Dict[str, float] = {}
         self._handles: List = []
+        # per-bucket stamps of ONE backward (trace_buckets = True, read with bucket_report()): when each gradient bucket was handed to
+        # the collective relative to the start of the backward, and how long the step then WAITED for it after the backward — the first
+        # multi-GPU run shows overlap per bucket instead of one total
+        self.trace_buckets = False
+        self._trace: List[dict] = []
+        self._trace_t0 = None
         self._cuts: Dict[int, tuple] = {}
         self._n_buckets = max(1, int(n_buckets))
         arena = model.arena
@@ -162,6 +168,12 @@ class _DataParallelStep:
     def _issue(self, lo: int, hi: int):
         """asynchronous sum of the gradient range [lo, hi) over the ranks, in the configured transport dtype"""
         g = self.model.arena.grads[lo:hi]
+        tr = None
+        if self.trace_buckets and g.device.type == "cuda":
+            tr = {"lo": int(lo), "hi": int(hi), "bytes": int((hi - lo) * (2 if self._grad_bf16 else 4)), "first_handle": len(self._handles),
+                  "issue": torch.cuda.Event(enable_timing=True)}
+            tr["issue"].record()                     # on the stream the hook runs on: everything the bucket depends on is ordered before it
+            self._trace.append(tr)
         if not self._grad_bf16:
             self._handles.append(dist.all_reduce(g, async_op=True))
             return
@@ -192,6 +204,10 @@ class _DataParallelStep:
 
     def begin_backward(self):
         self._handles = []
+        if self.trace_buckets and torch.cuda.is_available() and self.dp:
+            self._trace = []
+            self._trace_t0 = torch.cuda.Event(enable_timing=True)
+            self._trace_t0.record()
         eng = self.model.text_model.engine
         eng.layer_done_hook = self._layer_done if (self.dp and self._cuts) else None
 
@@ -204,13 +220,35 @@ class _DataParallelStep:
         g = self.model.arena.grads
         hi = self._tail_hi if self._cuts else g.numel()
         self._issue(0, hi)
-        for h in self._handles:
+        tracing = self.trace_buckets and self._trace and self._trace_t0 is not None
+        if tracing:
+            self._trace_join = torch.cuda.Event(enable_timing=True)
+            self._trace_join.record()                # the backward's last launch: waits from here on are exposed
+            firsts = {t["first_handle"]: t for t in self._trace}
+            nxt = sorted(firsts) + [len(self._handles)]
+        for i, h in enumerate(self._handles):
             h.wait()
+            if tracing and (i + 1) in nxt:           # the last handle of a bucket has been joined into the compute stream
+                t = firsts[nxt[nxt.index(i + 1) - 1]]
+                t["done"] = torch.cuda.Event(enable_timing=True)
+                t["done"].record()
         self._handles = []
         for lo, hi_, img in self._bf_images:                    # widen the summed bf16 images back into the arena
             ops.cast_grad(img, g[lo:hi_])
         self._bf_images = []
         return 1.0 / self.world
+
+    def bucket_report(self) -> List[dict]:
+        """stamps of the last traced backward, in ms: `issued_at` = hand-off of the bucket to the collective after the start of the
+        backward; `joined_at` = when the compute stream had waited for it; `backward_end` = the backward's own last launch.  A bucket
+        whose joined_at equals backward_end (within the event resolution) was fully hidden behind the backward."""
+        if not self._trace or self._trace_t0 is None:
+            return []
+        torch.cuda.synchronize()
+        end = self._trace_t0.elapsed_time(self._trace_join)
+        return [{"range": [t["lo"], t["hi"]], "bytes": t["bytes"], "issued_at_ms": round(self._trace_t0.elapsed_time(t["issue"]), 3),
+                 "joined_at_ms": round(self._trace_t0.elapsed_time(t["done"]), 3) if "done" in t else None,
+                 "backward_end_ms": round(end, 3)} for t in self._trace]
 
     def _marks(self, timing: bool, dev):
         marks: List = []
