@@ -278,6 +278,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {}
 __device__ __forceinline__ void raw_barrier() { bra_emu::block_sync(); }
 __device__ __forceinline__ void bare_barrier() { bra_emu::block_sync(); }
 __device__ __forceinline__ void wait_lds() {}
+// LDS words written by one lane of a wave and read by another lane of the SAME wave: the device needs the writes retired (lockstep
+// does the rest), the emulator's lanes are fibers and need a rendezvous
+__device__ __forceinline__ void wave_lds_sync() { bra_emu::wave_sync(); }
 __device__ __forceinline__ int uniform_i(int v) { return v; }
 #else
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -293,6 +296,7 @@ __device__ __forceinline__ void raw_barrier() {
 // s_barrier alone (LDS reads issued before it may still be in flight: wait_lds() after it, before their first use)
 __device__ __forceinline__ void bare_barrier() { __builtin_amdgcn_s_barrier(); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 

@@ -148,6 +148,90 @@ __device__ __forceinline__ bool epi_interior(const GemmArgs& g, int mw0, int nw0
     return mw0 + rows <= g.M && nw0 + 64 <= g.N && !(g.ldc & 3) && !(g.ldres & 3);
 }
 
+// ---- the same interior epilogue with the wave's 16 MI x 64 block turned through LDS (round 6; VERDICT r5 #5: the direct form stores 8 bytes
+// per lane — a wave instruction is 16 rows x 32 bytes, every 128-byte line of C is written by four instructions and the residual is
+// fetched in the same shape: ~2.7 TB/s, 8 - 25 us of every one-prompt launch, profiles/r5_l_gemm_fixed_probe.txt).  Here the rounded
+// bf16 product (alpha acc + bias: the FIRST rounding of the direct form) is written to a wave-private LDS block [16 MI][144 B] (row stride
+// padded by 16 B), read back as 16-byte chunks with lane l on (row l >> 3, chunk l & 7), and stored / added to the residual as 8 rows x
+// 128 bytes per wave instruction: full lines.  Same values bit for bit (the residual add works on the same rounded product).
+// `lw`: 16 MI * 144 bytes of LDS private to this wave, free of pending reads (every kernel calls this behind its last K-loop barrier).
+constexpr int EPI_RS = 144;
+#if defined(BRA_DEBUG) && !defined(BRA_EMU)
+__device__ int epi_via_lds = 1;                  // A/B knob of the debug library (bra_gemm_set_epi_lds): 0 = the direct 8-byte stores
+#else
+constexpr int epi_via_lds = 1;
+#endif
+__device__ __forceinline__ bool epi_lds_ok(const GemmArgs& g) {
+    return !(g.ldc & 7) && !(g.ldres & 7) && !((size_t)g.C & 15) && !((size_t)g.res & 15);
+}
+template <int MI, bool BIAS>
+__device__ __forceinline__ void epi_bf16_interior_lds_b(const GemmArgs& g, f32x4 (&acc)[4][MI], int mw0, int nw0, int lane, char* lw) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const float alpha = g.alpha;
+    const int rrow = lane >> 3, rch = lane & 7;
+    // the residual rows first: their latency hides behind the staging
+    u32x4 rv[2 * MI];
+    if (g.res) {
+        const bf16_t* rp = g.res + ((long)(mw0 + rrow) * g.ldres + nw0 + 8 * rch);
+        const long rstep = 8 * g.ldres;
+#pragma unroll
+        for (int j = 0; j < 2 * MI; ++j) rv[j] = ld16(rp + j * rstep);
+    }
+    float bz[4][4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bz[ni][r] = 0.f;
+    if (BIAS) {
+        const int col = nw0 + 4 * fq;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const u32x2 b = ld8(g.bias + col + 16 * ni);
+            bz[ni][0] = bf_lo(b.x); bz[ni][1] = bf_hi(b.x); bz[ni][2] = bf_lo(b.y); bz[ni][3] = bf_hi(b.y);
+        }
+    }
+    char* wp = lw + fr * EPI_RS + 8 * fq;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = epi_scale_bias<BIAS>(acc[ni][mi][r], alpha, bz[ni][r]);
+            u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+            st8(wp + mi * (16 * EPI_RS) + ni * 32, o);
+        }
+    wave_lds_sync();
+    sched_fence();
+    const char* rdp = lw + rrow * EPI_RS + 16 * rch;
+    bf16_t* cp = (bf16_t*)g.C + ((long)(mw0 + rrow) * g.ldc + nw0 + 8 * rch);
+    const long cstep = 8 * g.ldc;
+    u32x4 xv[2 * MI];
+#pragma unroll
+    for (int j = 0; j < 2 * MI; ++j) xv[j] = ld16(rdp + j * (8 * EPI_RS));
+    if (g.res) {
+#pragma unroll
+        for (int j = 0; j < 2 * MI; ++j) {
+            float x[8], r8[8];
+            unpack8(xv[j], x);
+            unpack8(rv[j], r8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] += r8[i];
+            st16(cp + j * cstep, pack8(x));
+        }
+        wave_lds_sync();
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * MI; ++j) st16(cp + j * cstep, xv[j]);
+    wave_lds_sync();                 // (a caller may reuse the block for its next column group)
+}
+template <int MI>
+__device__ __forceinline__ void epi_bf16_interior_lds(const GemmArgs& g, f32x4 (&acc)[4][MI], int mw0, int nw0, int lane, char* lw) {
+    if (g.bias) epi_bf16_interior_lds_b<MI, true>(g, acc, mw0, nw0, lane, lw);
+    else epi_bf16_interior_lds_b<MI, false>(g, acc, mw0, nw0, lane, lw);
+}
+
 // ---- epilogue: lane owns C[m][n..n+3], m = m0 + wm*64 + 16*mi + fr, n = n0 + wn*64 + 16*ni + 4*fq
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn,
@@ -261,9 +345,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
 
 // the same epilogues for a wave that owns MI x 4 fragments at (mw0, nw0): lane owns C[mw0 + 16 mi + fr][nw0 + 16 ni + 4 fq ..+3]
 template <int EPI, int MI>
-__device__ __forceinline__ void gemm_epilogue_w(const GemmArgs& g, f32x4 (&acc)[4][MI], int mw0, int nw0, int lane) {
+__device__ __forceinline__ void gemm_epilogue_w(const GemmArgs& g, f32x4 (&acc)[4][MI], int mw0, int nw0, int lane, char* lw = nullptr) {
     if (EPI == EPI_BF16 && epi_interior(g, mw0, nw0, 16 * MI)) {
-        epi_bf16_interior<MI>(g, acc, mw0, nw0, lane);
+        if (lw && epi_lds_ok(g) && epi_via_lds) epi_bf16_interior_lds<MI>(g, acc, mw0, nw0, lane, lw);
+        else epi_bf16_interior<MI>(g, acc, mw0, nw0, lane);
         return;
     }
     const int fr = lane & 15, fq = lane >> 4;
@@ -666,7 +751,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmArgs g) {
             stage = s1;
         }
     }
-    gemm_epilogue_w<EPI, MI>(g, acc, m0 + wm * (16 * MI), n0 + wn * 64, lane);
+    gemm_epilogue_w<EPI, MI>(g, acc, m0 + wm * (16 * MI), n0 + wn * 64, lane, smem + wave * (16 * MI * EPI_RS));
 }
 
 // ---------------------------------------------------------------------------
@@ -797,7 +882,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Args g8) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[ni][mi][r] *= sm[mi] * sn[r];
     }
-    gemm_epilogue_w<EPI, MI>(g, acc, mw0, nw0, lane);
+    gemm_epilogue_w<EPI, MI>(g, acc, mw0, nw0, lane, smem + wave * (16 * MI * EPI_RS));
 }
 
 // ---------------------------------------------------------------------------
@@ -951,7 +1036,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmArgs g) {
     for (; t < nt; ++t) body(t, std::false_type{});
 #pragma unroll
     for (int hcol = 0; hcol < WN / 4; ++hcol)
-        gemm_epilogue_w<EPI, WM>(g, *reinterpret_cast<f32x4 (*)[4][WM]>(&acc[4 * hcol]), m0 + wm * (16 * WM), n0 + wn * (16 * WN) + 64 * hcol, lane);
+        gemm_epilogue_w<EPI, WM>(g, *reinterpret_cast<f32x4 (*)[4][WM]>(&acc[4 * hcol]), m0 + wm * (16 * WM), n0 + wn * (16 * WN) + 64 * hcol, lane,
+                                 smem + wave * (16 * WM * EPI_RS));
 }
 
 // ---------------------------------------------------------------------------
@@ -1124,7 +1210,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs g) {
             rb2 = rb2 + 4 >= NSLOT ? rb2 + 4 - NSLOT : rb2 + 4;
         }
         if (wr == 0) bare_barrier();
-        gemm_epilogue_w<EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane);
+        gemm_epilogue_w<EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * (128 * EPI_RS));
         return;
     }
     // prologue: stream indices 0..6 (K-tile 0 whole, K-tile 1 up to its first A half); K-tile 0 landed before phase 0
@@ -1165,7 +1251,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs g) {
     }
     if (wr == 0) bare_barrier();                 // re-join the groups (equal barrier counts)
 
-    gemm_epilogue_w<EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane);
+    gemm_epilogue_w<EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * (128 * EPI_RS));
 }
 
 // ---------------------------------------------------------------------------
@@ -1497,6 +1583,14 @@ extern "C" int bra_gemm_set_glds_rows(int rows) {
     return 0;
 }
 extern "C" int bra_gemm_set_ring_fill(int pct) { bra::ring_min_fill_pct = pct; return 0; }
+extern "C" int bra_gemm_set_epi_lds(int on) {
+#ifndef BRA_EMU
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(bra::epi_via_lds), &on, sizeof(int));
+#else
+    (void)on;
+    return 0;
+#endif
+}
 extern "C" int bra_gemm_set_row_split(int on) { bra::ring_row_split = on; return 0; }
 #endif
 

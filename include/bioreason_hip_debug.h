@@ -28,6 +28,9 @@ int bra_gemm_set_ring_fill(int pct);
 /* row split of the per-shape choice (default on): when the last round of 256 x 256 tiles would be less than half full, the
  * tile-rows that fill whole rounds go to the ring kernel and the remaining rows to the 256 x 128 kernel (two launches) */
 int bra_gemm_set_row_split(int on);
+/* interior bf16 epilogue of the tiled GEMMs through LDS (full 128-byte lines per row; default on) or as direct 8-byte stores (0): same
+ * values bit for bit, A/B timing */
+int bra_gemm_set_epi_lds(int on);
 /* bra_sample_tiles as ONE launch (sample_tiles_one_kernel; 1) or as the two launches of round 4 (0, the default): same tokens, A/B timing */
 int bra_sample_set_one_launch(int on);
 /* tile height of the LDS-DMA kernel (round 4): 0 = chosen per call (256 / 192 / 128 rows, whichever fills the 256 CUs best),
