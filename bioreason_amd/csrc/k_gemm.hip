@@ -28,6 +28,7 @@ enum : int {
     EPI_LSE = 2,      // no C; per (row, 64-col chunk) running max / sum-exp of rnd(acc), + target logit
     EPI_DLOGIT = 3,   // C bf16 = rnd(coef[m] * ((n==tgt[m]) - exp(rnd(acc) - lse[m])))
     EPI_ATOMIC = 4,   // C f32 += alpha*acc with atomics (split-K)
+    EPI_SWIGLU = 5,   // ring kernel only: B = [gate rows | up rows] ([2 F, K]); C bf16 [M, F] = rnd(rnd(silu(rnd(g))) * rnd(u)) (no-grad passes)
 };
 
 struct GemmArgs {
@@ -51,6 +52,7 @@ struct GemmArgs {
     const float* lse;     // [M]
     const float* coef;    // [M]
     int nchunk;
+    int swiglu_F;         // EPI_SWIGLU: F (N = 2 F); B row of local tile row `loc` = (loc >> 5) * 16 + (loc & 15) + 128 tile_n (+ F when loc & 16)
 };
 
 template <int BK>
@@ -1040,6 +1042,44 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmArgs g) {
                                  smem + wave * (16 * WM * EPI_RS));
 }
 
+// ---- EPI_SWIGLU epilogue of the ring kernel (round 6): the wave's accumulator blocks are (gate, up, gate, up) of 2 x 16 features for
+// 128 rows; act = bf16(bf16(silu(bf16(alpha g))) * bf16(alpha u)) — the roundings of the gate/up GEMM followed by bra_swiglu_fwd —
+// goes through a wave-private LDS block [128][80 B] and leaves as 16-byte chunks, 16 rows x 64 bytes per wave instruction.
+// Removes the [M, 2 F] store of the projection, its re-read and the SwiGLU launch from the no-grad passes (encoder FFN, reference
+// pass, prompt pass): TF:qwen3:81-83, NT-v2 hub FFN.
+constexpr int SWG_RS = 80;
+__device__ __forceinline__ float silu_epi(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ void ring_epilogue_swiglu(const GemmArgs& g, f32x4 (&acc)[4][8], int mw0, int f0, int lane, char* lw) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const float alpha = g.alpha;
+    char* wp = lw + fr * SWG_RS + 8 * fq;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gb = round_bf(acc[2 * j][mi][r] * alpha), ub = round_bf(acc[2 * j + 1][mi][r] * alpha);
+                v[r] = round_bf(silu_epi(gb)) * ub;
+            }
+            u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+            st8(wp + mi * (16 * SWG_RS) + j * 32, o);
+        }
+    wave_lds_sync();
+    sched_fence();
+    const int rrow = lane >> 2, rch = lane & 3;
+    const char* rdp = lw + rrow * SWG_RS + 16 * rch;
+    bf16_t* cp = (bf16_t*)g.C + ((long)(mw0 + rrow) * g.ldc + f0 + 8 * rch);
+    const long cstep = 16 * g.ldc;
+    const bool full = mw0 + 128 <= g.M;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const u32x4 xv = ld16(rdp + jj * (16 * SWG_RS));
+        if (full || mw0 + rrow + 16 * jj < g.M) st16(cp + jj * cstep, xv);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // 256 x 256 output tile, 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 8 x 4 fragments of v_mfma_f32_16x16x32_bf16
 // (128 accumulator registers), BK = 64.  Against the 256 x 128 kernel above: per-wave tile 128 x 64 instead of
@@ -1104,7 +1144,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int loc = (i >> 1) * 128 + wave * 16 + (i & 1) * 8 + prow;
-        int rb = n0 + loc; rowB[i] = rb < g.N ? rb : g.N - 1;
+        int rb = n0 + loc;
+        // EPI_SWIGLU: the tile's 16 blocks of 16 B-rows alternate gate / up rows of the SAME 16 features, so that a wave's accumulator
+        // blocks (ni = 0, 1) and (2, 3) hold gate and up of one feature in the same lane and register: the SwiGLU is register-local
+        if (EPI == EPI_SWIGLU) rb = tile_n * 128 + (loc >> 5) * 16 + (loc & 15) + ((loc & 16) ? g.swiglu_F : 0);
+        rowB[i] = rb < g.N ? rb : g.N - 1;
         int ra = m0 + loc; rowA[i] = ra < g.M ? ra : g.M - 1;
     }
     // stream element (K-tile tt relative to kt_begin, half H) -> slot `slot`; H is a compile-time constant at every call
@@ -1210,7 +1254,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs g) {
             rb2 = rb2 + 4 >= NSLOT ? rb2 + 4 - NSLOT : rb2 + 4;
         }
         if (wr == 0) bare_barrier();
-        gemm_epilogue_w<EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * (128 * EPI_RS));
+        if constexpr (EPI == EPI_SWIGLU) ring_epilogue_swiglu(g, acc, m0 + wr * 128, tile_n * 128 + wc * 32, lane, smem + wave * (128 * SWG_RS));
+        else gemm_epilogue_w<EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * (128 * EPI_RS));
         return;
     }
     // prologue: stream indices 0..6 (K-tile 0 whole, K-tile 1 up to its first A half); K-tile 0 landed before phase 0
@@ -1251,7 +1296,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs g) {
     }
     if (wr == 0) bare_barrier();                 // re-join the groups (equal barrier counts)
 
-    gemm_epilogue_w<EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * (128 * EPI_RS));
+    if constexpr (EPI == EPI_SWIGLU) ring_epilogue_swiglu(g, acc, m0 + wr * 128, tile_n * 128 + wc * 32, lane, smem + wave * (128 * SWG_RS));
+    else gemm_epilogue_w<EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * (128 * EPI_RS));
 }
 
 // ---------------------------------------------------------------------------
@@ -1640,6 +1686,24 @@ extern "C" int bra_gemm_fp8_nt(const void* A8, long lda, const float* sa, const 
     if (rows == 192) BRA_G8(EPI_BF16, 3);
     BRA_G8(EPI_BF16, 4);
 #undef BRA_G8
+}
+
+// gate/up projection with the SwiGLU in its epilogue (gemm_ring_kernel<EPI_SWIGLU>): act [M, F] bf16 = swiglu(A W^T + A2 B2^T), W [2 F, K]
+// = [gate rows | up rows] (B2 [2 F, K2] likewise: the LoRA rank part, optional).  The values are those of bra_gemm_bf16_nt followed by
+// bra_swiglu_fwd, bit for bit; the [M, 2 F] intermediate never exists — for passes that keep nothing for a backward (encoder FFN,
+// reference pass, prompt pass).  BRA_ERR_UNSUPPORTED unless K % 64 == 0, K2 % 64 == 0, F % 128 == 0, M > 16.
+extern "C" int bra_gemm_swiglu_bf16_nt(const void* A, long lda, const void* W, long ldw, const void* A2, long lda2, const void* B2, long ldb2,
+                                       int K2, void* C, long ldc, int M, int F, int K, float alpha, void* stream) {
+    if (M == 0 || F == 0) return 0;
+    GemmArgs g = {};
+    g.A = (const bf16_t*)A; g.lda = lda; g.B = (const bf16_t*)W; g.ldb = ldw;
+    g.A2 = (const bf16_t*)A2; g.lda2 = lda2; g.B2 = (const bf16_t*)B2; g.ldb2 = ldb2;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = 2 * F; g.K = K; g.K2 = K2; g.alpha = alpha; g.swiglu_F = F;
+    int e = check_common(g);
+    if (e) return e;
+    if (!C || ldc % 8 || ((size_t)C & 15)) return BRA_ERR_ARG;
+    if (K % 64 || K2 % 64 || F % 128 || M <= 16) return BRA_ERR_UNSUPPORTED;
+    return launch_ring<EPI_SWIGLU>(g, (bra_stream_t)stream);
 }
 
 extern "C" int bra_gemm_bf16_nt_splitk(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M,

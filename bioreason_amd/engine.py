@@ -125,6 +125,9 @@ def _mix32(a: int, b: int) -> int:
 
 
 import contextlib as _contextlib
+import os as _os
+# no-grad passes: SwiGLU in the epilogue of the gate/up projection (ops.gemm_swiglu); BRA_FUSE_SWIGLU=0 keeps the two launches (A/B runs)
+FUSE_SWIGLU = _os.environ.get("BRA_FUSE_SWIGLU", "1") == "1"
 
 _nullctx = _contextlib.nullcontext
 
@@ -320,8 +323,22 @@ class QwenEngine:
         o2 = o.view(T, self.Nq)
         h, t2 = self._lora_fwd(o2, L.Wo, L.lora["o"], m.lora_on, res=x, drop=self._drop(m, li, "o"))
         hn = ops.rmsnorm_fwd(h, L.ln2, self.eps)
-        gu, t3 = self._lora_fwd(hn, L.Wgu, L.lora["gu"], m.lora_on, drop=self._drop(m, li, "gu"))
-        act = ops.swiglu_fwd(gu)
+        gu = t3 = act = None
+        if not save and FUSE_SWIGLU:
+            # nothing is kept for a backward: the SwiGLU rides in the epilogue of the gate/up projection (ops.gemm_swiglu: the same
+            # values in one launch, no [T, 2 F] intermediate); None where the fused kernel does not apply
+            G3, d3 = L.lora["gu"], self._drop(m, li, "gu")
+            if G3 is not None and m.lora_on:
+                t3 = ops.lora_down_drop(hn, G3.A, G3.scaling, d3[0], d3[1]) if d3 is not None else self._down(hn, G3.A, G3.scaling, len(G3.n_sizes) * G3.r)
+                act = ops.gemm_swiglu(hn, L.Wgu, a2=t3, b2=G3.B)
+            else:
+                act = ops.gemm_swiglu(hn, L.Wgu)
+        if act is None:
+            if t3 is not None:
+                gu = ops.gemm_nt(hn, L.Wgu, a2=t3, b2=L.lora["gu"].B)
+            else:
+                gu, t3 = self._lora_fwd(hn, L.Wgu, L.lora["gu"], m.lora_on, drop=self._drop(m, li, "gu"))
+            act = ops.swiglu_fwd(gu)
         y, t4 = self._lora_fwd(act, L.Wd, L.lora["d"], m.lora_on, res=h, drop=self._drop(m, li, "d"))
         saved = (x, xn, t1, qkv, q, k, v, o, lse, t2, h, hn, t3, gu, act, t4) if save else None
         return y, saved
@@ -517,7 +534,8 @@ class EsmEngine:
             o, _ = ops.attn_fwd(q, k, vt, mask_u8, False, 1.0, need_lse=False)     # scaling 1.0: q was pre-scaled (TF:esm:345,374)
             x = ops.gemm_nt(o.view(T, self.H), L.Wo, bias=L.bo, res=x)
             xn = ops.layernorm_fwd(x, L.ln2_w, L.ln2_b, self.eps)
-            up = ops.gemm_nt(xn, L.Wup)
-            act = ops.swiglu_fwd(up)
+            act = ops.gemm_swiglu(xn, L.Wup) if FUSE_SWIGLU else None
+            if act is None:
+                act = ops.swiglu_fwd(ops.gemm_nt(xn, L.Wup))
             x = ops.gemm_nt(act, L.Wdown, res=x)
         return ops.layernorm_fwd(x, self.lnf_w, self.lnf_b, self.eps)

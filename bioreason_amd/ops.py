@@ -249,6 +249,20 @@ def layernorm_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float)
     return y.view(x.shape)
 
 
+def gemm_swiglu(x: torch.Tensor, W: torch.Tensor, a2: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """act [M, F] = swiglu_fwd(gemm_nt(x, W [2 F, K], a2=a2, b2=b2)) in ONE launch (bra_gemm_swiglu_bf16_nt; same values), or None where
+    the fused kernel does not apply (the caller runs the two launches)"""
+    M, K = x.shape
+    F = W.shape[0] // 2
+    K2 = a2.shape[1] if a2 is not None else 0
+    if M <= 16 or K % 64 or K2 % 64 or F % 128 or W.shape[0] != 2 * F:
+        return None
+    act = torch.empty((M, F), dtype=BF16, device=x.device)
+    rc = get_lib().call_rc("bra_gemm_swiglu_bf16_nt", x, _ld(x), W, _ld(W), a2, _ld(a2) if a2 is not None else 0, b2,
+                           _ld(b2) if b2 is not None else 0, K2, act, _ld(act), M, F, K, 1.0, current_stream(x))
+    return None if rc != 0 else act        # (call_rc raises on every status but BRA_ERR_UNSUPPORTED)
+
+
 def swiglu_fwd(gu: torch.Tensor) -> torch.Tensor:
     gu2 = _as2d(gu)
     F = gu2.shape[1] // 2

@@ -220,6 +220,12 @@ int bra_dec_pack_weights_fp8(const void* W, long ldw, int N, int K, int act, int
 int bra_dec_gemm2_fp8(const void* x, long ldx, const float* ss_in, int nss_in, float eps, const void* Wq, const float* wscale,
                       const void* res, long ldres, void* out, long ldo, float* ss_out, int nss_out, int M, int N, int K, int act,
                       int out_f32, int norm_folded, void* stream);
+/* gate/up projection with the SwiGLU in the GEMM epilogue (round 6): act [M, F] = bra_swiglu_fwd(bra_gemm_bf16_nt(A, W [2 F, K] = [gate | up]
+ * rows (+ the LoRA rank part A2 B2^T))), bit for bit, without the [M, 2 F] intermediate — no-grad passes only (the backward of a training
+ * forward needs gate and up).  BRA_ERR_UNSUPPORTED unless K % 64 == 0, K2 % 64 == 0, F % 128 == 0, M > 16 (callers fall back to the two
+ * launches).  Replaces TF:qwen3:81-83 / the NT-v2 FFN in the encoder, the reference pass and the prompt pass. */
+int bra_gemm_swiglu_bf16_nt(const void* A, long lda, const void* W, long ldw, const void* A2, long lda2, const void* B2, long ldb2, int K2,
+                            void* C, long ldc, int M, int F, int K, float alpha, void* stream);
 /* ---- fp8 x fp8 GEMM on the fp8 MFMA path (round 6; BASELINE config 5 "fp8 weights (CDNA4 fp8 MFMA)"; k_gemm.hip gemm_fp8_kernel,
  * k_quant.hip) — the prompt pass and the no-grad reference pass of an fp8 rollout run: the behaviour policy's MFMA-bound passes on
  * v_mfma_scale_f32_16x16x128_f8f6f4 (OCP e4m3 operands, fp32 accumulation, block scales 2^0), per-row fp32 scales in the epilogue.

@@ -997,6 +997,21 @@ def test_lmhead_lse_at_full_vocab(hip_device):
     assert rel(logp, ref_lp) < 2e-3
 
 
+@pytest.mark.parametrize("M,F,K,K2", [(300, 128, 128, 0), (256, 256, 64, 64), (530, 384, 192, 128), (17, 128, 64, 0)])
+def test_gemm_swiglu_equals_gemm_then_swiglu(backend, M, F, K, K2):
+    """bra_gemm_swiglu_bf16_nt (round 6: SwiGLU in the epilogue of the ring kernel, gate / up rows of the same features interleaved on
+    the DMA source side) against bra_gemm_bf16_nt + bra_swiglu_fwd on the same operands: the same roundings, bit for bit — ragged row
+    counts (rows past M are computed and never stored), with and without the LoRA rank part.  TF:qwen3:81-83."""
+    a, w = rnd(M, K, dev=backend, seed=21), rnd(2 * F, K, dev=backend, seed=22)
+    a2 = rnd(M, K2, dev=backend, seed=23) if K2 else None
+    b2 = rnd(2 * F, K2, dev=backend, seed=24) if K2 else None
+    want = ops.swiglu_fwd(ops.gemm_nt(a, w, a2=a2, b2=b2))
+    got = ops.gemm_swiglu(a, w, a2=a2, b2=b2)
+    assert got is not None
+    assert torch.equal(got.cpu(), want.cpu()), float((got.float() - want.float()).abs().max())
+    assert ops.gemm_swiglu(a, rnd(2 * 96, K, dev=backend, seed=25)) is None          # F % 128 != 0: the caller takes the two launches
+
+
 @pytest.mark.parametrize("variant", [0, 5, 7, 9, 10, 11, 12, 13, 14])
 def test_gemm_bf16_epilogue_interior_and_edge_waves(debug_backend, variant):
     backend = debug_backend
