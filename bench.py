@@ -60,7 +60,7 @@ PEAK_HBM_GBS = 8000.0
 SD, TEXT_LEN, NDNA, G, C = 1024, 128, 2, 8, 256
 LORA_DROPOUT = 0.05          # reason.py:266 / train_dna_qwen.py:1038
 SFT_LABEL_TAIL = 64
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r5_pmc_gemm.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r6_pmc_gemm.json")
 DRYRUN = os.environ.get("BENCH_DRYRUN") == "1"
 
 
