@@ -14,11 +14,11 @@ elif [ "$NOCPU" = "1" ]; then timeout 300 python $R/bench.py --no-cpu-baseline -
 else timeout 1200 python $R/bench.py --steps 5 2>$out/${tag}_bench.err | tail -1 > $out/${tag}_bench.json; fi
 [ "$PMC_ONLY" = "1" ] || { rm -rf /tmp/ev_stats; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ev_stats -o r --output-format csv -- $BENCH > /tmp/ev_stats.log 2>&1
 f=$(find /tmp/ev_stats -name "*kernel_stats.csv" | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats --output-format csv -- $BENCH   (MI355X, $tag; 3 GRPO steps in the trace: warm-up, timed, instrumented)"; cat $f; } > $out/${tag}_bench_kernel_stats.csv; }
+{ echo "# rocprofv3 --kernel-trace --stats --output-format csv -- $BENCH   (MI355X, $tag; 4 GRPO steps in the trace: warm-up, timed, two instrumented)"; cat $f; } > $out/${tag}_bench_kernel_stats.csv; }
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU"; do
   name=$(echo $pass | awk '{print $1}')
   rm -rf /tmp/ev_pmc; timeout 400 rocprofv3 --pmc $pass --kernel-trace -d /tmp/ev_pmc -o r --output-format csv -- $BENCH > /tmp/ev_pmc_$name.log 2>&1
   python $R/tools/pmc_summarize.py /tmp/ev_pmc $out/${tag}_pmc_$name.csv >> /tmp/ev_pmc_$name.log 2>&1
 done
-python $R/tools/pmc_to_json.py $out $tag $R 3
+python $R/tools/pmc_to_json.py $out $tag $R 4
 ls -la $out

@@ -11,4 +11,4 @@ for name in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/ev_pmc; timeout ${T:-80} rocprofv3 --pmc $name --kernel-trace -d /tmp/ev_pmc -o r --output-format csv -- $BENCH > /tmp/ev_pmc_$name.log 2>&1
   python $R/tools/pmc_summarize.py /tmp/ev_pmc $out/${tag}_pmc_$name.csv >> /tmp/ev_pmc_$name.log 2>&1
 done
-python $R/tools/pmc_to_json.py $out $tag $R 3 | head -30
+python $R/tools/pmc_to_json.py $out $tag $R 4 | head -30
