@@ -171,13 +171,16 @@ __device__ __forceinline__ void epi_bf16_interior_lds_b(const GemmArgs& g, f32x4
     const int fr = lane & 15, fq = lane >> 4;
     const float alpha = g.alpha;
     const int rrow = lane >> 3, rch = lane & 7;
-    // the residual rows first: their latency hides behind the staging
-    u32x4 rv[2 * MI];
+    // the first residual rows are requested before the staging (their latency hides behind it), the rest batch by batch: holding all
+    // 2 MI x 4 words beside the accumulators spilled in the four-wave kernel (656 bytes of scratch at 5 x 8 fragments, tests/test_isa.py)
+    constexpr int NB = 4;                               // 16-byte rows per batch
+    constexpr int NJ = 2 * MI;
+    const bf16_t* rp = g.res ? g.res + ((long)(mw0 + rrow) * g.ldres + nw0 + 8 * rch) : nullptr;
+    const long rstep = 8 * g.ldres;
+    u32x4 rv[NB];
     if (g.res) {
-        const bf16_t* rp = g.res + ((long)(mw0 + rrow) * g.ldres + nw0 + 8 * rch);
-        const long rstep = 8 * g.ldres;
 #pragma unroll
-        for (int j = 0; j < 2 * MI; ++j) rv[j] = ld16(rp + j * rstep);
+        for (int j = 0; j < NB && j < NJ; ++j) rv[j] = ld16(rp + j * rstep);
     }
     float bz[4][4];
 #pragma unroll
@@ -208,24 +211,30 @@ __device__ __forceinline__ void epi_bf16_interior_lds_b(const GemmArgs& g, f32x4
     const char* rdp = lw + rrow * EPI_RS + 16 * rch;
     bf16_t* cp = (bf16_t*)g.C + ((long)(mw0 + rrow) * g.ldc + nw0 + 8 * rch);
     const long cstep = 8 * g.ldc;
-    u32x4 xv[2 * MI];
 #pragma unroll
-    for (int j = 0; j < 2 * MI; ++j) xv[j] = ld16(rdp + j * (8 * EPI_RS));
-    if (g.res) {
+    for (int j0 = 0; j0 < NJ; j0 += NB) {
+        u32x4 xv[NB];
 #pragma unroll
-        for (int j = 0; j < 2 * MI; ++j) {
-            float x[8], r8[8];
-            unpack8(xv[j], x);
-            unpack8(rv[j], r8);
+        for (int j = 0; j < NB && j0 + j < NJ; ++j) xv[j] = ld16(rdp + (j0 + j) * (8 * EPI_RS));
+        if (g.res) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) x[i] += r8[i];
-            st16(cp + j * cstep, pack8(x));
+            for (int j = 0; j < NB && j0 + j < NJ; ++j) {
+                float x[8], r8[8];
+                unpack8(xv[j], x);
+                unpack8(rv[j], r8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] += r8[i];
+                st16(cp + (j0 + j) * cstep, pack8(x));
+            }
+            if (j0 + NB < NJ) {
+#pragma unroll
+                for (int j = 0; j < NB && j0 + NB + j < NJ; ++j) rv[j] = ld16(rp + (j0 + NB + j) * rstep);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB && j0 + j < NJ; ++j) st16(cp + (j0 + j) * cstep, xv[j]);
         }
-        wave_lds_sync();
-        return;
     }
-#pragma unroll
-    for (int j = 0; j < 2 * MI; ++j) st16(cp + j * cstep, xv[j]);
     wave_lds_sync();                 // (a caller may reuse the block for its next column group)
 }
 template <int MI>
@@ -1036,10 +1045,17 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmArgs g) {
     int t = 0;
     for (; t + LOOK < nt; ++t) body(t, std::true_type{});
     for (; t < nt; ++t) body(t, std::false_type{});
-#pragma unroll
-    for (int hcol = 0; hcol < WN / 4; ++hcol)
+    // one call per 64-column group, the group index a compile-time constant: left as a `#pragma unroll` loop the (now larger) epilogue body
+    // was NOT unrolled, `acc[4 * hcol]` became a run-time index and all 160 accumulators of the 5 x 8 tile went through scratch
+    // (656 bytes; tests/test_isa.py)
+    auto epi_group = [&](auto HC) {
+        constexpr int hcol = decltype(HC)::value;
         gemm_epilogue_w<EPI, WM>(g, *reinterpret_cast<f32x4 (*)[4][WM]>(&acc[4 * hcol]), m0 + wm * (16 * WM), n0 + wn * (16 * WN) + 64 * hcol, lane,
                                  smem + wave * (16 * WM * EPI_RS));
+    };
+    epi_group(std::integral_constant<int, 0>{});
+    if constexpr (WN / 4 > 1) epi_group(std::integral_constant<int, 1>{});
+    static_assert(WN / 4 <= 2, "two 64-column groups per wave at most");
 }
 
 // ---- EPI_SWIGLU epilogue of the ring kernel (round 6): the wave's accumulator blocks are (gate, up, gate, up) of 2 x 16 features for
