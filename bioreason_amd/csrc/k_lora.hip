@@ -188,6 +188,10 @@ __global__ __launch_bounds__(256) void lora_up_drop_kernel(LoraUpArgs g) {
     }
     const int k_lo = (int)blockIdx.y * g.k_chunk;
     int k_hi = k_lo + g.k_chunk; k_hi = k_hi < g.K ? k_hi : g.K;
+    constexpr int UP_SP = 64 + 8;                               // staged row pitch (elements): 144 bytes
+    __shared__ __attribute__((aligned(16))) bf16_t stage[4][32 * UP_SP];
+    bf16_t* sw = stage[wave];
+    const bool vec_ok = !(g.ldo & 7) && !((size_t)g.out & 15) && !(k_lo & 7);
     for (int k0 = k_lo; k0 < k_hi; k0 += 32) {
         const int kc = k0 + (lane & 31);
         const int kr = kc < g.K ? kc : g.K - 1;
@@ -220,12 +224,32 @@ __global__ __launch_bounds__(256) void lora_up_drop_kernel(LoraUpArgs g) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) o[q] += ((hh[q] >> fsh) & 0x7fffu) >= g.d.thr16 ? acc[q] : 0.f;
         }
-        if (kc < g.K) {
+        // round 6: the tile is turned through a wave-private LDS block and leaves as 16 bytes per lane — two 32-column tiles side by
+        // side, 8 rows x 128 bytes per store instruction.  (Before: sixteen 2-byte stores per lane and tile, a wave instruction = 2 rows x
+        // 64 bytes: lora_up_drop wrote its [M, K] output at ~1 TB/s, profiles/r6_j_sft_breakdown.md.)
+        const int side = ((k0 - k_lo) >> 5) & 1;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int m = m_base + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (m < g.M) g.out[(long)m * g.ldo + kc] = f2bf(o[q] * g.d.inv_keep);
+        for (int q = 0; q < 16; ++q)
+            sw[((q & 3) + 8 * (q >> 2) + 4 * h) * UP_SP + 32 * side + (lane & 31)] = kc < g.K ? f2bf(o[q] * g.d.inv_keep) : (bf16_t)0;
+        if (side == 1 || k0 + 32 >= k_hi) {
+            wave_lds_sync();
+            const int kf = k0 - 32 * side;                      // first column of the staged block
+            const int ncol = 32 * (side + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 8 * j + (lane >> 3), c8 = 8 * (lane & 7);
+                const int m = m_base + row;
+                const u32x4 v = ld16(&sw[row * UP_SP + c8]);
+                if (m < g.M && c8 < ncol) {
+                    bf16_t* op = g.out + (long)m * g.ldo + kf + c8;
+                    if (vec_ok && kf + c8 + 8 <= g.K) st16(op, v);
+                    else {
+                        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+                        for (int i = 0; i < 8; ++i) if (kf + c8 + i < g.K) op[i] = e[i];
+                    }
+                }
             }
+            wave_lds_sync();
         }
     }
 }
@@ -259,7 +283,11 @@ extern "C" int bra_lora_down_drop(const void* x, long ldx, const void* A, long l
 extern "C" int bra_lora_down_splitk_plan(int M, int K) {
     // workgroups per row block so that the grid reaches ~2 per CU while every workgroup keeps >= 3 K steps (its prologue is one step)
     const int gx = (M + 31) / 32, nstep = (K + 127) / 128;
-    if (gx <= 0 || gx >= 192 || nstep < 6) return 1;
+    // many row blocks (SFT / the full-row pass, M = 17 - 19 k): the chip is full either way, but a workgroup that walks 48 K steps alone
+    // (down_proj, K = 6144) is a long latency chain — four K slices: 64.9 -> 52.6 us at M = 17 440, 65.6 -> 57.6 at 19 488; K = 2048: no
+    // gain (profiles/r6_aa_lora_split_probe.txt)
+    if (gx >= 192) return nstep >= 32 ? 4 : 1;
+    if (gx <= 0 || nstep < 6) return 1;
     int want = 512 / gx, cap = nstep / 3;
     int ks = want < cap ? want : cap;
     if (ks < 2) return 1;

@@ -1185,7 +1185,8 @@ def test_lora_down_drop_split_k(backend, M, K, R, nlive):
     deterministic from call to call"""
     from bioreason_amd._lib import get_lib
     p, seeds = 0.25, [11, 22, 33, 44][:nlive]
-    assert get_lib()._dll.bra_lora_down_splitk_plan(M, K) >= 2 and get_lib()._dll.bra_lora_down_splitk_plan(19488, K) == 1
+    # (big M: no split for K = 2048 — the chip is full; four slices for the long chain of K = 6144, round 6)
+    assert get_lib()._dll.bra_lora_down_splitk_plan(M, K) >= 2 and get_lib()._dll.bra_lora_down_splitk_plan(19488, K) == (4 if K >= 4096 else 1)
     x, A = rnd(M, K, dev=backend), rnd(R, K, dev=backend, scale=K ** -0.5)
     A[32 * nlive:] = 0
     masks = [ops.dropout_mask(M, K, p, seeds[j], backend).float().cpu() for j in range(nlive)]
