@@ -118,9 +118,12 @@ class _StackFn(torch.autograd.Function):
     hand-written layer backward (engine.layer_bwd) and deposits LoRA gradients in the arena."""
 
     @staticmethod
-    def forward(ctx, x, anchor, model, meta):
+    def forward(ctx, x, anchor, model, meta, grad_mode=True):
         eng = model.engine
-        need = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])   # False under torch.no_grad()
+        # `needs_input_grad` reflects the inputs' requires_grad, NOT the caller's grad mode (and grad mode is always off inside a Function's
+        # forward): the caller passes torch.is_grad_enabled() — a no-grad pass keeps no tape and may take the no-grad kernels
+        # (fused SwiGLU epilogue, the fp8 path under engine.use_fp8)
+        need = bool(grad_mode and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
         hid, tape = eng.forward_hidden(x, meta, save=need)
         ctx.model, ctx.meta, ctx.tape = model, meta, tape
         return hid
@@ -131,16 +134,16 @@ class _StackFn(torch.autograd.Function):
         eng.ensure_transposed()
         dx = eng.backward_hidden(dhid.contiguous(), ctx.tape, ctx.meta)
         ctx.tape = None
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 class _SharedStackFn(torch.autograd.Function):
     """The decoder stack over (distinct prompts, per-copy completions) as one autograd node (engine.forward_hidden_shared)."""
 
     @staticmethod
-    def forward(ctx, xp, xc, anchor, model, mp, mc, copies, side):
+    def forward(ctx, xp, xc, anchor, model, mp, mc, copies, side, grad_mode=True):
         eng = model.engine
-        need = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[2])
+        need = bool(grad_mode and (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]))
         hid_last, hid_c, tape = eng.forward_hidden_shared(xp, mp, xc, mc, copies, save=need, side=side)
         ctx.model, ctx.mp, ctx.mc, ctx.copies, ctx.tape, ctx.side = model, mp, mc, copies, tape, side
         return hid_last, hid_c
@@ -151,7 +154,7 @@ class _SharedStackFn(torch.autograd.Function):
         eng.ensure_transposed()
         dxp, dxc = eng.backward_hidden_shared(dlast.contiguous(), dc.contiguous(), ctx.tape, ctx.mp, ctx.mc, ctx.copies, side=ctx.side)
         ctx.tape = None
-        return dxp, None, None, None, None, None, None, None
+        return dxp, None, None, None, None, None, None, None, None
 
 
 class _ExpandGroupsFn(torch.autograd.Function):
@@ -442,7 +445,7 @@ class Qwen3ForCausalLM(nn.Module):
         if x.dtype != BF16:
             x = x.to(BF16)
         anchor = self.arena.anchor if self.arena is not None else x.new_zeros(1, dtype=torch.float32)
-        return _StackFn.apply(x.contiguous(), anchor, self, meta)
+        return _StackFn.apply(x.contiguous(), anchor, self, meta, torch.is_grad_enabled())
 
     def hidden_states_shared(self, prompt_embeds: torch.Tensor, prompt_mask: torch.Tensor, completion_ids: torch.Tensor,
                              completion_mask: torch.Tensor, copies: int, side=None):
@@ -477,7 +480,7 @@ class Qwen3ForCausalLM(nn.Module):
         xc = torch.empty((B * C, H), dtype=BF16, device=dev)
         ops.embed_scatter_fwd(completion_ids.to(torch.int32).reshape(-1).contiguous(), None, eng.E, None, xc)
         anchor = self.arena.anchor if self.arena is not None else xp.new_zeros(1, dtype=torch.float32)
-        return _SharedStackFn.apply(xp.contiguous(), xc, anchor, self, mp, mc, copies, side)
+        return _SharedStackFn.apply(xp.contiguous(), xc, anchor, self, mp, mc, copies, side, torch.is_grad_enabled())
 
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, labels=None, position_ids=None,
                 return_logits: bool = True, **unused):

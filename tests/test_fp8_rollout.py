@@ -297,3 +297,95 @@ def test_rollout_fp8_falls_back_to_bf16_where_the_shapes_do_not_fit(backend):
     assert not any(R.get("fp8") for R in generation.rollout_weights(m.text_model, rows=got.shape[0]))
     from bioreason_amd.trainer import GRPOConfig
     assert GRPOConfig().rollout_fp8 is False                                      # opt-in only
+
+
+def test_ref_fp8_runs_the_reference_pass_on_the_fp8_path_and_falls_back_where_the_widths_do_not_fit(backend):
+    """`GRPOConfig.ref_fp8` on the tiny fixture (hidden 128: the fp8 GEMM's K % 128 == 0 holds): the no-grad reference pass runs W8A8
+    (engine.use_fp8 over e4m3 images of the base weights) — its log-probs differ from the bf16 reference pass by quantisation noise, not by
+    nothing and not by garbage, and the step trains; the rollout keeps its bf16 weights there (the token loop's fp8 kernel refuses shapes
+    outside its single-register-round form) and samples the same tokens.  Widths the fp8 GEMM does not take report `fp8_supported() ==
+    False` and keep the bf16 reference pass: the flags never fail a run."""
+    from test_model_parity import GOLD, build, to_dev
+    from bioreason_amd import configs
+    from bioreason_amd.modeling import Qwen3ForCausalLM
+    from bioreason_amd.trainer import GRPOConfig, GRPOStepRunner
+    fix = torch.load(os.path.join(GOLD, "tiny_a.pt"), weights_only=False)
+    res = []
+    for fp8 in (False, True):
+        m = build(fix, backend, True)
+        assert m.text_model.ensure_packed().fp8_supported()
+        b = to_dev(fix["batch"], backend)
+        b.pop("labels")
+        runner = GRPOStepRunner(m, GRPOConfig(num_generations=2, max_completion_length=4, eos_token_id=None, seed=7, learning_rate=1e-3,
+                                              rollout_fp8=fp8, ref_fp8=fp8),
+                                lambda ids, mask: torch.stack([(ids[:, 0] % 5).float(), (ids[:, 1] % 3).float()], dim=1))
+        out = runner.step(b)
+        inp = runner._buffered_inputs[0]
+        res.append((inp["ref_per_token_logps"].float().cpu().clone(), inp["completion_ids"].cpu().clone(), float(out["loss_t"])))
+    (lp16, ids16, l16), (lp8, ids8, l8) = res
+    assert torch.equal(ids16, ids8)                                    # same rollout: the token loop kept bf16 weights on these shapes
+    assert not torch.equal(lp16, lp8)                                  # the fp8 reference pass ran ...
+    assert float((lp16 - lp8).abs().mean()) < 0.3 and torch.isfinite(lp8).all()       # ... and differs by W8A8 noise only
+    assert abs(l8) < 10 and l8 == l8
+    small = Qwen3ForCausalLM(configs.qwen3_config(vocab_size=64, hidden_size=64, intermediate_size=96, num_hidden_layers=1, num_attention_heads=2,
+                                                  num_key_value_heads=1, head_dim=32, rope_theta=1e4, max_position_embeddings=64), device=backend)
+    small.init_weights(0.02, seed=1)
+    assert not small.ensure_packed().fp8_supported()
+
+
+@pytest.mark.gpu
+def test_fp8_prompt_pass_and_reference_pass_in_a_step_at_qwen3_widths(hip_device, monkeypatch):
+    """Qwen3-1.7B widths x 2 layers, one prompt x 8 rollouts: (a) the rollout's prompt pass on the fp8 MFMA path (default with rollout_fp8)
+    against the bf16 prompt pass (BRA_FP8_PREFILL=0) — the first-step logits differ by W8A8 noise, not by nothing and not by garbage, the
+    K / V cache is written; (b) `per_token_logps_shared_prefix` under engine.use_fp8 (what GRPOConfig.ref_fp8 runs) against the bf16 reference
+    pass: log-probs within the same noise band; both deterministic from call to call."""
+    from bioreason_amd import configs, generation, grpo
+    from bioreason_amd.modeling import Qwen3ForCausalLM
+    dev = hip_device
+    L, V, P, T, copies = 2, 8192, 300, 6, 8
+    tc = dict(vocab_size=V, hidden_size=2048, intermediate_size=6144, num_hidden_layers=L, num_attention_heads=16, num_key_value_heads=8,
+              head_dim=128, rope_theta=1e6, max_position_embeddings=4096)
+    m = Qwen3ForCausalLM(configs.qwen3_config(**tc), device=dev)
+    m.init_weights(0.02, seed=1)
+    eng = m.ensure_packed()
+    assert eng.fp8_supported()
+    g = torch.Generator().manual_seed(3)
+    emb = (torch.randn(1, P, 2048, generator=g) * 0.02).to(BF).to(dev).repeat(copies, 1, 1)
+    mask = torch.ones(copies, P, dtype=torch.long, device=dev)
+    kw = dict(max_new_tokens=T, do_sample=False, eos_token_id=None, prompt_alias=[0] * copies, use_graph=False)
+    m.rollout_fp8 = True
+    tr_a, tr_b, tr_c = [], [], []
+    monkeypatch.setenv("BRA_FP8_PREFILL", "0")
+    tok0 = generation.generate(m, emb, mask, trace_logits=tr_a, **kw)
+    monkeypatch.setenv("BRA_FP8_PREFILL", "1")
+    m.ensure_packed()._rollout = None                                   # (the weight set is cached: rebuild it with the row-major images)
+    tok1 = generation.generate(m, emb, mask, force_tokens=tok0, trace_logits=tr_b, **kw)
+    tok2 = generation.generate(m, emb, mask, force_tokens=tok0, trace_logits=tr_c, **kw)
+    rw = generation.rollout_weights(m, rows=copies)
+    assert all(R.get("rm8") is not None for R in rw), "the row-major e4m3 images were not built"
+    la, lb, lc = (torch.stack([t_[0].float().cpu() for t_ in tr]) for tr in (tr_a, tr_b, tr_c))
+    assert torch.equal(lb, lc)                                          # deterministic
+    d = rel(lb, la)
+    assert 1e-3 < d < 0.25, d                                           # W8A8 prompt K / V under a W8A16 token loop vs bf16 prompt K / V
+    # (b) reference-type pass (no adapters) over prompt + completion, bf16 vs fp8 MFMA path
+    m.rollout_fp8 = False
+
+    class Wrap:                                                         # the DNALLMModel surface per_token_logps_shared_prefix uses
+        text_model = m
+
+        @staticmethod
+        def _inputs_embeds(ids, *a):
+            return emb
+    pids = torch.zeros(copies, P, dtype=torch.long, device=dev)
+    cids = tok0[:, :T].to(torch.long)
+    cmask = torch.ones(copies, T, dtype=torch.int32, device=dev)
+    with torch.no_grad():
+        lp16 = grpo.per_token_logps_shared_prefix(Wrap, pids, mask, cids, cmask, [0] * copies)
+        w8 = eng.fp8_weight_images()
+        with eng.use_fp8(w8):
+            lp8 = grpo.per_token_logps_shared_prefix(Wrap, pids, mask, cids, cmask, [0] * copies)
+            lp8b = grpo.per_token_logps_shared_prefix(Wrap, pids, mask, cids, cmask, [0] * copies)
+    assert torch.equal(lp8, lp8b)
+    assert torch.isfinite(lp8).all()
+    dlp = float((lp8.float() - lp16.float()).abs().mean())
+    assert 1e-4 < dlp < 0.5, dlp
