@@ -612,7 +612,11 @@ __global__ __launch_bounds__(512 / NQB) void attn_fwd4_kernel(AttnArgs a) {
                 xhalf_pair(a1, b1);
                 // lower half: [own group g | partner's group g] = d 32 db + 8 g + 0..7; upper half: d 32 db + 8 (g + 1) + 0..7
                 u32x4 w = {a0, a1, b0, b1};
+#ifdef BRA_A4_NOSTORE      // (timing probe: what the per-lane row-strided O stores of the block cost — never true at run time, garbage results)
+                if (a.Sq < 0) st16(op + db * 32 + 8 * g + 8 * h, w);
+#else
                 if (qi < a.Sq) st16(op + db * 32 + 8 * g + 8 * h, w);
+#endif
             }
             sched_fence();
         }
