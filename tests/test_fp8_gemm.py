@@ -117,7 +117,8 @@ def test_gemm_fp8_nt_against_decoded_products(backend, M, N, K, res, f32):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(2180, 4096, 2048), (2048, 2048, 6144), (2180, 12288, 2048), (17440, 2048, 2048)])
+@pytest.mark.parametrize("M,N,K", [(2180, 4096, 2048), (2048, 2048, 6144), (2180, 12288, 2048), (17440, 2048, 2048),
+                                   (2180, 2560, 9728), (2181, 6144, 2560)])          # (the last two: Qwen3-4B widths, a ragged row count)
 def test_gemm_fp8_nt_model_shapes(hip_device, M, N, K):
     """the projections of one prompt / eight completions / the SFT rows: quantised from bf16 operands by the kernels themselves,
     against the oracle with the same fake-quantised weights and activations"""

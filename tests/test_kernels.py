@@ -997,6 +997,19 @@ def test_lmhead_lse_at_full_vocab(hip_device):
     assert rel(logp, ref_lp) < 2e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,F,K,K2", [(2180, 6144, 2048, 64), (16384, 4096, 1024, 0), (2181, 9728, 2560, 64)])
+def test_gemm_swiglu_at_model_shapes(hip_device, M, F, K, K2):
+    """the fused gate/up + SwiGLU launch at the shapes it runs in the step (one prompt with the LoRA rank part, the NT-v2 FFN, Qwen3-4B
+    widths with a ragged row count): bit-identical to bra_gemm_bf16_nt + bra_swiglu_fwd"""
+    dev = hip_device
+    a, w = rnd(M, K, dev=dev, seed=31), rnd(2 * F, K, dev=dev, seed=32, scale=0.05)
+    a2 = rnd(M, K2, dev=dev, seed=33) if K2 else None
+    b2 = rnd(2 * F, K2, dev=dev, seed=34, scale=0.05) if K2 else None
+    got = ops.gemm_swiglu(a, w, a2=a2, b2=b2)
+    assert got is not None and torch.equal(got, ops.swiglu_fwd(ops.gemm_nt(a, w, a2=a2, b2=b2)))
+
+
 @pytest.mark.parametrize("M,F,K,K2", [(300, 128, 128, 0), (256, 256, 64, 64), (530, 384, 192, 128), (17, 128, 64, 0)])
 def test_gemm_swiglu_equals_gemm_then_swiglu(backend, M, F, K, K2):
     """bra_gemm_swiglu_bf16_nt (round 6: SwiGLU in the epilogue of the ring kernel, gate / up rows of the same features interleaved on
