@@ -25,7 +25,8 @@ def ref_quant(x: torch.Tensor, colw=None):
     return q, a
 
 
-@pytest.mark.parametrize("M,K,colw,rms", [(9, 256, False, False), (5, 512, True, False), (7, 384, False, True)])
+@pytest.mark.parametrize("M,K,colw,rms", [(9, 256, False, False), (5, 512, True, False), (7, 384, False, True), (6, 4096, True, True),
+                                          (5, 6144, False, False), (4, 9728, False, True)])        # (every register-chunk count of the kernel)
 def test_quant_rows_fp8(backend, M, K, colw, rms):
     g = torch.Generator().manual_seed(M * K)
     x = (torch.randn(M, K, generator=g) * 3).to(BF16)
@@ -66,8 +67,9 @@ def test_quant_encoder_is_nearest_even_over_every_bf16_value(backend):
     assert torch.equal(got, want), (got != want).nonzero()[:5]
 
 
-def test_swiglu_quant_fp8(backend):
-    M, F = 6, 256
+@pytest.mark.parametrize("F", [256, 6144, 9728])
+def test_swiglu_quant_fp8(backend, F):
+    M = 6
     g = torch.Generator().manual_seed(3)
     gu = (torch.randn(M, 2 * F, generator=g) * 2).to(BF16)
     q, s = ops.swiglu_quant_fp8(gu.to(backend))
